@@ -1,0 +1,71 @@
+"""
+ctypes binding of libira.so (the C-ABI declared in include/ira.h).
+
+There is NO fallback: if the shared library is missing or fails to load, importing the product path
+raises.  Build it with `python -m audio_analysis_amd.build` (hipcc, gfx950).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libira.so"
+_lib = None
+
+c_f32p = C.c_void_p
+c_i64p = C.c_void_p
+c_i32p = C.c_void_p
+c_f64p = C.c_void_p
+vp = C.c_void_p
+i32 = C.c_int32
+f64 = C.c_double
+f32 = C.c_float
+
+# name -> (restype, argtypes); must list every symbol include/ira.h declares (checked by tests).
+PROTOTYPES = {
+    "ira_abi_version": (i32, []),
+    "ira_error_string": (C.c_char_p, [i32]),
+    "ira_peak_index": (i32, [vp, vp, vp, i32, vp, vp, vp]),
+    "ira_edc_db": (i32, [vp, vp, vp, i32, f64, f64, vp, vp, vp, vp, vp]),
+    "ira_curve_fits": (i32, [vp, vp, vp, i32, i32, f32, f32, vp, C.POINTER(f64), i32, i32, C.POINTER(f64), i32, i32,
+                             f64, f64, vp, vp, vp]),
+    "ira_stft_mag_db": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, f64, vp, vp, vp, vp, vp]),
+}
+
+
+class IraError(RuntimeError):
+    pass
+
+
+def lib_path() -> Path:
+    return _LIB_PATH
+
+
+def load():
+    """Load libira.so once; raise loudly if it is absent (no CPU fallback exists by design)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise IraError(
+            f"{_LIB_PATH} not found. The HIP library is the product path and has no fallback; "
+            "build it with `python -m audio_analysis_amd.build`."
+        )
+    lib = C.CDLL(str(_LIB_PATH))
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().ira_error_string(rc)
+        raise IraError(f"libira {what} failed with code {rc}: {msg.decode() if msg else '?'}")
+
+
+def dbl_array(values):
+    arr = (f64 * max(1, len(values)))(*[float(v) for v in values])
+    return arr

@@ -1,0 +1,77 @@
+"""
+Build libira.so (hand-written HIP kernels + C-ABI) in-tree for gfx950 with hipcc.
+
+    python -m audio_analysis_amd.build            # incremental
+    python -m audio_analysis_amd.build --force
+
+hipcc cross-compiles without a GPU.  The shared object lands next to the sources
+(audio_analysis_amd/csrc/libira.so) so it travels with the repo snapshot to the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+CSRC = Path(__file__).resolve().parent / "csrc"
+LIB = CSRC / "libira.so"
+ARCH = "gfx950"
+
+# per-file extra flags; -ffp-contract=off where f64 arithmetic must round like NumPy's (no FMA fusion)
+SOURCES = {
+    "ira_api.hip": [],
+    "ira_edc.hip": ["-ffp-contract=off"],
+    "ira_stft.hip": [],
+}
+COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(exe).exists():
+        raise RuntimeError("hipcc not found; libira cannot be built")
+    return exe
+
+
+def _stale(obj: Path, deps) -> bool:
+    if not obj.exists():
+        return True
+    t = obj.stat().st_mtime
+    return any(Path(d).stat().st_mtime > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    hipcc = _hipcc()
+    headers = list(CSRC.glob("*.h")) + [CSRC.parent.parent / "include" / "ira.h"]
+    jobs = []
+    objs = []
+    for name, extra in SOURCES.items():
+        src = CSRC / name
+        obj = CSRC / (src.stem + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src, Path(__file__)] + headers):
+            jobs.append([hipcc, *COMMON, *extra, "-c", str(src), "-o", str(obj)])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            print(r.stderr, flush=True)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            list(ex.map(run, jobs))
+    if jobs or force or _stale(LIB, objs):
+        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, objs), "-o", str(LIB)])
+    return LIB
+
+
+if __name__ == "__main__":
+    p = build(force="--force" in sys.argv, verbose=True)
+    print(p)

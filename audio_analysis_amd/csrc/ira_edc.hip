@@ -1,0 +1,438 @@
+// Peak pick, Schroeder energy-decay curve, threshold crossings and decay-line fits.
+// Compiled with -ffp-contract=off: the f64 interpolation/regression arithmetic must round like
+// NumPy's (no fused multiply-add), see reference analyse/decay.py:173-260.
+#include "ira_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// a2: argmax |x| with first-maximum-wins.  Key = (bits(|x|) << 32) | (0xFFFFFFFF - index):
+// unsigned 64-bit max picks the largest magnitude, then the smallest index.
+// ------------------------------------------------------------------------------------------------
+constexpr int PEAK_THREADS = 256;
+constexpr int PEAK_CHUNK = 16384;  // samples per workgroup
+
+__global__ __launch_bounds__(PEAK_THREADS) void peak_partial_kernel(
+    const float* __restrict__ x, const int64_t* __restrict__ off, const int64_t* __restrict__ len,
+    unsigned long long* __restrict__ keys) {
+  const int s = blockIdx.y;
+  const int64_t n = len[s];
+  const int64_t c0 = (int64_t)blockIdx.x * PEAK_CHUNK;
+  if (c0 >= n) return;
+  const int64_t c1 = (c0 + PEAK_CHUNK < n) ? c0 + PEAK_CHUNK : n;
+  const float* p = x + off[s];
+  unsigned long long best = 0ull;
+  for (int64_t i = c0 + threadIdx.x; i < c1; i += PEAK_THREADS) {
+    const float a = fabsf(p[i]);
+    const unsigned long long k =
+        ((unsigned long long)__float_as_uint(a) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
+    best = k > best ? k : best;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long other = __shfl_xor(best, o, 64);
+    best = other > best ? other : best;
+  }
+  __shared__ unsigned long long wbest[PEAK_THREADS / IRA_WAVE];
+  if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < PEAK_THREADS / IRA_WAVE; ++w) best = wbest[w] > best ? wbest[w] : best;
+    atomicMax(&keys[s], best);
+  }
+}
+
+__global__ void peak_decode_kernel(unsigned long long* __restrict__ keys, float* __restrict__ peak_abs,
+                                   int nseg) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nseg) return;
+  const unsigned long long k = keys[s];
+  // an all-zero (or empty) segment leaves key 0 or (0<<32 | ~i): index 0 by construction
+  const uint32_t inv = (uint32_t)(k & 0xFFFFFFFFull);
+  const int64_t idx = (k == 0ull) ? 0 : (int64_t)(0xFFFFFFFFu - inv);
+  if (peak_abs) peak_abs[s] = __uint_as_float((uint32_t)(k >> 32));
+  reinterpret_cast<int64_t*>(keys)[s] = idx;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a3: Schroeder EDC.  One 1024-thread workgroup per segment walks 4096-sample tiles from the end of
+// the segment to its start (that is the direction numpy.cumsum(e[::-1]) accumulates in).  Pass 1
+// records the running carry per tile; pass 2 re-scans with the carries, now knowing edc[0], and
+// emits 10*log10(max(edc,eps)/edc[0]) floored, as float32.  Both passes run the SAME scan code so the
+// value used as edc[0] is bit-identical to the value the emit pass produces at index 0 (=> exactly 0 dB).
+// ------------------------------------------------------------------------------------------------
+constexpr int EDC_THREADS = 1024;
+constexpr int EDC_PER_THREAD = 4;
+constexpr int EDC_TILE = EDC_THREADS * EDC_PER_THREAD;
+
+struct EdcShared {
+  float stage[EDC_TILE];
+  double wave_tot[EDC_THREADS / IRA_WAVE];
+  double total;
+};
+
+// Suffix sums of one tile.  local index i in [0, tile_len); thread t owns i = 4t..4t+3.
+// On return s[0..3] hold the inclusive suffix sums (within the tile) at the thread's four positions and the
+// function result is the suffix sum at local index 0 (thread 0's s[0], broadcast), i.e. the tile total in
+// exactly the association order the emit pass uses.
+__device__ __forceinline__ double tile_suffix_scan(const float* __restrict__ src, int tile_len, EdcShared& sh,
+                                                   double s[EDC_PER_THREAD]) {
+  const int t = threadIdx.x;
+  // coalesced staging (works for any alignment of src)
+#pragma unroll
+  for (int r = 0; r < EDC_PER_THREAD; ++r) {
+    const int i = t + r * EDC_THREADS;
+    sh.stage[i] = (i < tile_len) ? src[i] : 0.0f;
+  }
+  __syncthreads();
+  double e[EDC_PER_THREAD];
+#pragma unroll
+  for (int r = 0; r < EDC_PER_THREAD; ++r) {
+    const double v = (double)sh.stage[EDC_PER_THREAD * t + r];
+    e[r] = v * v;
+  }
+  s[3] = e[3];
+  s[2] = e[2] + s[3];
+  s[1] = e[1] + s[2];
+  s[0] = e[0] + s[1];
+  // inclusive suffix scan of thread totals across the wave (towards higher lanes)
+  const int lane = t & 63, wave = t >> 6;
+  double incl = s[0];
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double up = __shfl_down(incl, o, 64);
+    if (lane + o < 64) incl += up;
+  }
+  double excl = __shfl_down(incl, 1, 64);  // sum over the lanes after this one
+  if (lane == 63) excl = 0.0;
+  if (lane == 0) sh.wave_tot[wave] = incl;
+  __syncthreads();
+  double later_waves = 0.0;
+  for (int w = EDC_THREADS / IRA_WAVE - 1; w > wave; --w) later_waves += sh.wave_tot[w];
+  excl += later_waves;
+#pragma unroll
+  for (int r = 0; r < EDC_PER_THREAD; ++r) s[r] += excl;
+  if (t == 0) sh.total = s[0];
+  __syncthreads();
+  const double total = sh.total;
+  __syncthreads();  // stage / wave_tot / total are reused by the next tile
+  return total;
+}
+
+__global__ __launch_bounds__(EDC_THREADS) void edc_kernel(
+    const float* __restrict__ x, const int64_t* __restrict__ off, const int64_t* __restrict__ len, double eps,
+    double floor_db, float* __restrict__ out, double* __restrict__ out64, const int64_t* __restrict__ out_off,
+    double* __restrict__ scratch) {
+  __shared__ EdcShared sh;
+  const int seg = blockIdx.x;
+  const int64_t n = len[seg];
+  if (n <= 0) return;
+  const float* src = x + off[seg];
+  float* dst = out ? out + out_off[seg] : nullptr;
+  double* dst64 = out64 ? out64 + out_off[seg] : nullptr;
+  double* carry = scratch + (int64_t)seg * IRA_EDC_SCRATCH_DOUBLES;
+  const int64_t ntiles = (n + EDC_TILE - 1) / EDC_TILE;
+  // The first tile (at the START of the segment) is the ragged one, so tile boundaries are aligned to the
+  // end of the segment: tile j (counted from the end) covers [n-(j+1)*TILE, n-j*TILE) clipped at 0.
+  double run = 0.0;
+  double s[EDC_PER_THREAD];
+  for (int64_t j = 0; j < ntiles; ++j) {
+    const int64_t hi = n - j * EDC_TILE;
+    const int64_t lo = hi - EDC_TILE > 0 ? hi - EDC_TILE : 0;
+    if (threadIdx.x == 0) carry[j] = run;
+    const double tot = tile_suffix_scan(src + lo, (int)(hi - lo), sh, s);
+    run = tot + run;
+  }
+  // `run` is now edc[0] exactly as the emit pass will compute it: for the last tile the emit value at local
+  // index 0 is s[0] + carry with s[0] == tot bit-for-bit (same code path), and IEEE addition commutes.
+  const double norm = fmax(run, eps);
+  for (int64_t j = 0; j < ntiles; ++j) {
+    const int64_t hi = n - j * EDC_TILE;
+    const int64_t lo = hi - EDC_TILE > 0 ? hi - EDC_TILE : 0;
+    const int tl = (int)(hi - lo);
+    // carry[j] was written by this workgroup's thread 0 before a barrier inside tile_suffix_scan
+    const double c = carry[j];
+    (void)tile_suffix_scan(src + lo, tl, sh, s);
+#pragma unroll
+    for (int r = 0; r < EDC_PER_THREAD; ++r) {
+      const int i = EDC_PER_THREAD * threadIdx.x + r;
+      if (i < tl) {
+        double v = fmax(s[r] + c, eps);
+        v = v / norm;
+        double db = 10.0 * log10(v);
+        if (dst64) dst64[lo + i] = db;  // unfloored f64 (host-side optional smoothing, decay.py:161-164)
+        db = fmax(db, floor_db);
+        sh.stage[i] = (float)db;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < EDC_PER_THREAD; ++r) {
+      const int i = threadIdx.x + r * EDC_THREADS;
+      if (dst && i < tl) dst[lo + i] = sh.stage[i];
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a4/a5/a16: crossings + line fits on float32 dB curves.
+// ------------------------------------------------------------------------------------------------
+constexpr int FIT_MAX_RANGES = 4;
+constexpr int FIT_MAX_CROSS = 4;
+constexpr int FIT_MAX_TARGETS = 2 * FIT_MAX_RANGES + FIT_MAX_CROSS;
+
+struct FitParams {
+  double hi[FIT_MAX_RANGES];
+  double lo[FIT_MAX_RANGES];
+  double cross[FIT_MAX_CROSS];
+  int nranges, ncross, min_points, rel_to_peak;
+  double floor_db, min_peak_above_floor;
+  float t_mul, t_div;
+  const float* t_axis;
+};
+
+// Time axis: either an explicit float32 array (t_axis) or the analytic axis of the reference,
+// float32(i) * t_mul / t_div evaluated as two correctly rounded float32 operations.
+struct TimeAxis {
+  const float* axis;
+  float t_mul, t_div;
+  __device__ __forceinline__ float at(long long i) const {
+    return axis ? axis[i] : ((float)i * t_mul) / t_div;
+  }
+};
+
+struct FitShared {
+  double red[3][16];
+  long long idx[FIT_MAX_TARGETS];
+  double tgt[FIT_MAX_TARGETS];
+};
+
+__device__ __forceinline__ void block_sum3(double& a, double& b, double& c, FitShared& sh) {
+  a = ira::wave_sum(a); b = ira::wave_sum(b); c = ira::wave_sum(c);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) { sh.red[0][wave] = a; sh.red[1][wave] = b; sh.red[2][wave] = c; }
+  __syncthreads();
+  a = b = c = 0.0;
+  for (int w = 0; w < nw; ++w) { a += sh.red[0][w]; b += sh.red[1][w]; c += sh.red[2][w]; }
+}
+
+// first index i with y_rel[i] <= target  (float32 compare, like `curve <= target` under NEP 50)
+__device__ __forceinline__ double crossing_time_from_index(const float* y, float peak, long long idx, long long n,
+                                                           double target, const TimeAxis& ta) {
+  if (idx >= n) return __longlong_as_double(0x7ff8000000000000ll);  // NaN = "no crossing"
+  if (idx == 0) return (double)ta.at(0);
+  const double t0 = (double)ta.at(idx - 1);
+  const double t1 = (double)ta.at(idx);
+  const double y0 = (double)(y[idx - 1] - peak);
+  const double y1 = (double)(y[idx] - peak);
+  if (y1 == y0) return t1;
+  double frac = (target - y0) / (y1 - y0);
+  frac = fmin(fmax(frac, 0.0), 1.0);
+  return t0 + frac * (t1 - t0);
+}
+
+__global__ void curve_fit_kernel(const float* __restrict__ ybase, const int64_t* __restrict__ off,
+                                 const int64_t* __restrict__ len, FitParams P, double* __restrict__ fit_out,
+                                 double* __restrict__ cross_out) {
+  __shared__ FitShared sh;
+  const int c = blockIdx.x;
+  const long long n = len[c];
+  const float* y = ybase + off[c];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+  const TimeAxis ta{P.t_axis, P.t_mul, P.t_div};
+  double* fo = fit_out + (int64_t)c * P.nranges * IRA_FIT_DOUBLES;
+  double* co = cross_out ? cross_out + (int64_t)c * P.ncross : nullptr;
+
+  // ---- optional normalisation to the curve's own peak (modal cloud) -------------------------------------
+  float peak = 0.0f;
+  bool usable = n > 0;
+  if (P.rel_to_peak) {
+    float m = -INFINITY;
+    int bad = 0;
+    for (long long i = tid; i < n; i += nt) {
+      const float v = y[i];
+      if (!isfinite(v)) bad = 1;
+      m = fmaxf(m, v);
+    }
+    m = ira::wave_max(m);
+    bad = __any(bad) ? 1 : 0;
+    if ((tid & 63) == 0) { sh.red[0][tid >> 6] = (double)m; sh.red[1][tid >> 6] = (double)bad; }
+    __syncthreads();
+    float pk = -INFINITY;
+    int anybad = 0;
+    for (int w = 0; w < ((nt + 63) >> 6); ++w) {
+      pk = fmaxf(pk, (float)sh.red[0][w]);
+      anybad |= (sh.red[1][w] != 0.0);
+    }
+    __syncthreads();
+    peak = pk;
+    if (anybad) usable = false;
+    if (usable && ((double)peak - P.floor_db) < P.min_peak_above_floor) usable = false;
+  }
+  if (!usable) {
+    if (tid == 0) {
+      for (int r = 0; r < P.nranges; ++r)
+        for (int k = 0; k < IRA_FIT_DOUBLES; ++k) fo[r * IRA_FIT_DOUBLES + k] = (k == 0) ? 0.0 : qnan;
+      for (int j = 0; j < P.ncross && co; ++j) co[j] = qnan;
+    }
+    return;
+  }
+
+  // ---- first-crossing indices for every target, one sweep ----------------------------------------------
+  // Fixed-size, fully unrolled arrays so they stay in registers (runtime-indexed arrays go to scratch).
+  const int ntargets = 2 * P.nranges + P.ncross;
+  if (tid < FIT_MAX_TARGETS) {
+    double tv = 0.0;
+    if (tid < 2 * P.nranges) tv = (tid & 1) ? P.lo[tid >> 1] : P.hi[tid >> 1];
+    else if (tid < ntargets) tv = P.cross[tid - 2 * P.nranges];
+    sh.tgt[tid] = tv;
+    sh.idx[tid] = n;
+  }
+  __syncthreads();
+  float targets[FIT_MAX_TARGETS];
+  long long first[FIT_MAX_TARGETS];
+#pragma unroll
+  for (int k = 0; k < FIT_MAX_TARGETS; ++k) { targets[k] = (float)sh.tgt[k]; first[k] = n; }
+  for (long long i = tid; i < n; i += nt) {
+    const float v = y[i] - peak;
+#pragma unroll
+    for (int k = 0; k < FIT_MAX_TARGETS; ++k)
+      if (k < ntargets && v <= targets[k] && i < first[k]) first[k] = i;
+  }
+#pragma unroll
+  for (int k = 0; k < FIT_MAX_TARGETS; ++k) {
+    if (k < ntargets) {
+      long long f = first[k];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const long long other = __shfl_xor(f, o, 64);
+        f = other < f ? other : f;
+      }
+      if ((tid & 63) == 0) atomicMin(&sh.idx[k], f);
+    }
+  }
+  __syncthreads();
+  const double* targets_d = sh.tgt;
+
+  if (co && tid == 0) {
+    for (int j = 0; j < P.ncross; ++j) {
+      const int k = 2 * P.nranges + j;
+      co[j] = crossing_time_from_index(y, peak, sh.idx[k], n, targets_d[k], ta);
+    }
+  }
+
+  // ---- per range: crossing times -> float32 mask -> two-pass regression ----------------------------------
+  for (int r = 0; r < P.nranges; ++r) {
+    const long long i_hi = sh.idx[2 * r], i_lo = sh.idx[2 * r + 1];
+    const double ts = crossing_time_from_index(y, peak, i_hi, n, targets_d[2 * r], ta);
+    const double te = crossing_time_from_index(y, peak, i_lo, n, targets_d[2 * r + 1], ta);
+    double* o = fo + r * IRA_FIT_DOUBLES;
+    bool ok = !(isnan(ts) || isnan(te) || te <= ts);
+    if (!ok) {
+      if (tid == 0) { o[0] = 0.0; o[1] = ts; o[2] = te; for (int k = 3; k < IRA_FIT_DOUBLES; ++k) o[k] = qnan; }
+      continue;
+    }
+    const float ts32 = (float)ts, te32 = (float)te;
+    long long a0 = i_hi - 2; if (a0 < 0) a0 = 0;
+    long long a1 = i_lo + 2; if (a1 > n - 1) a1 = n - 1;
+    // pass 1: count, sum t, sum y
+    double cnt = 0.0, st = 0.0, sy = 0.0;
+    for (long long i = a0 + tid; i <= a1; i += nt) {
+      const float tf = ta.at(i);
+      if (tf >= ts32 && tf <= te32) { cnt += 1.0; st += (double)tf; sy += (double)(y[i] - peak); }
+    }
+    block_sum3(cnt, st, sy, sh);
+    const long long npts = (long long)cnt;
+    if (npts < P.min_points) {
+      if (tid == 0) { o[0] = 0.0; o[1] = ts; o[2] = te; for (int k = 3; k < 7; ++k) o[k] = qnan; o[7] = (double)npts; }
+      continue;
+    }
+    const double tm = st / cnt, ym = sy / cnt;
+    // pass 2: centred second moments
+    double stt = 0.0, sty = 0.0, syy = 0.0;
+    for (long long i = a0 + tid; i <= a1; i += nt) {
+      const float tf = ta.at(i);
+      if (tf >= ts32 && tf <= te32) {
+        const double dt = (double)tf - tm, dy = (double)(y[i] - peak) - ym;
+        stt += dt * dt; sty += dt * dy; syy += dy * dy;
+      }
+    }
+    block_sum3(stt, sty, syy, sh);
+    const double slope = sty / stt;
+    const double icpt = ym - slope * tm;
+    // pass 3: residual sum of squares against the fitted line (decay.py:244-247)
+    double sres = 0.0, d1 = 0.0, d2 = 0.0;
+    for (long long i = a0 + tid; i <= a1; i += nt) {
+      const float tf = ta.at(i);
+      if (tf >= ts32 && tf <= te32) {
+        const double e = (double)(y[i] - peak) - (slope * (double)tf + icpt);
+        sres += e * e;
+      }
+    }
+    block_sum3(sres, d1, d2, sh);
+    if (tid == 0) {
+      const bool neg = slope < 0.0;  // also false for NaN (stt == 0)
+      o[0] = neg ? 1.0 : 0.0;
+      o[1] = ts; o[2] = te; o[3] = slope; o[4] = icpt;
+      o[5] = syy > 0.0 ? 1.0 - sres / syy : 0.0;
+      o[6] = -60.0 / slope;
+      o[7] = (double)npts;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int32_t ira_peak_index(const float* x_dev, const int64_t* off_dev, const int64_t* len_dev, int32_t nseg,
+                                  int64_t* peak_dev, float* peak_abs_dev, void* stream) {
+  IRA_CHECK_PTR(x_dev); IRA_CHECK_PTR(off_dev); IRA_CHECK_PTR(len_dev); IRA_CHECK_PTR(peak_dev);
+  if (nseg <= 0) return nseg == 0 ? IRA_OK : IRA_E_SIZE;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(peak_dev, 0, sizeof(int64_t) * (size_t)nseg, st);
+  if (e != hipSuccess) return ira_hip_status(e);
+  // chunk count is sized for the longest supported segment (2^31 samples would be 131072 chunks); the host
+  // passes lengths on the device only, so launch a fixed generous grid and let empty chunks exit at once.
+  const int max_chunks = 2048;  // 33.5 M samples per segment
+  peak_partial_kernel<<<dim3(max_chunks, nseg), PEAK_THREADS, 0, st>>>(
+      x_dev, off_dev, len_dev, reinterpret_cast<unsigned long long*>(peak_dev));
+  peak_decode_kernel<<<(nseg + 255) / 256, 256, 0, st>>>(reinterpret_cast<unsigned long long*>(peak_dev),
+                                                           peak_abs_dev, nseg);
+  IRA_RETURN_LAUNCH();
+}
+
+extern "C" int32_t ira_edc_db(const float* x_dev, const int64_t* off_dev, const int64_t* len_dev, int32_t nseg,
+                              double eps, double floor_db, float* edc_db_dev, double* edc_db64_dev,
+                              const int64_t* edc_off_dev, double* scratch_dev, void* stream) {
+  IRA_CHECK_PTR(x_dev); IRA_CHECK_PTR(off_dev); IRA_CHECK_PTR(len_dev);
+  if (edc_db_dev == nullptr && edc_db64_dev == nullptr) return IRA_E_NULL;
+  IRA_CHECK_PTR(edc_off_dev); IRA_CHECK_PTR(scratch_dev);
+  if (nseg <= 0) return nseg == 0 ? IRA_OK : IRA_E_SIZE;
+  edc_kernel<<<nseg, EDC_THREADS, 0, (hipStream_t)stream>>>(x_dev, off_dev, len_dev, eps, floor_db, edc_db_dev,
+                                                            edc_db64_dev, edc_off_dev, scratch_dev);
+  IRA_RETURN_LAUNCH();
+}
+
+extern "C" int32_t ira_curve_fits(const float* y_dev, const int64_t* off_dev, const int64_t* len_dev,
+                                  int32_t ncurves, int32_t max_len, float t_mul, float t_div,
+                                  const float* t_axis_dev, const double* ranges_hi_lo, int32_t nranges, int32_t min_points,
+                                  const double* cross_targets, int32_t ncross, int32_t rel_to_peak, double floor_db,
+                                  double min_peak_above_floor, double* fit_out_dev, double* cross_out_dev,
+                                  void* stream) {
+  IRA_CHECK_PTR(y_dev); IRA_CHECK_PTR(off_dev); IRA_CHECK_PTR(len_dev);
+  if (nranges < 0 || nranges > FIT_MAX_RANGES || ncross < 0 || ncross > FIT_MAX_CROSS) return IRA_E_SIZE;
+  if (nranges > 0) { IRA_CHECK_PTR(ranges_hi_lo); IRA_CHECK_PTR(fit_out_dev); }
+  if (ncross > 0) { IRA_CHECK_PTR(cross_targets); IRA_CHECK_PTR(cross_out_dev); }
+  if (ncurves <= 0) return ncurves == 0 ? IRA_OK : IRA_E_SIZE;
+  FitParams P{};
+  for (int r = 0; r < nranges; ++r) { P.hi[r] = ranges_hi_lo[2 * r]; P.lo[r] = ranges_hi_lo[2 * r + 1]; }
+  for (int j = 0; j < ncross; ++j) P.cross[j] = cross_targets[j];
+  P.nranges = nranges; P.ncross = ncross; P.min_points = min_points; P.rel_to_peak = rel_to_peak;
+  P.floor_db = floor_db; P.min_peak_above_floor = min_peak_above_floor; P.t_mul = t_mul; P.t_div = t_div; P.t_axis = t_axis_dev;
+  const int threads = max_len <= 2048 ? 64 : (max_len <= 32768 ? 256 : 1024);
+  curve_fit_kernel<<<ncurves, threads, 0, (hipStream_t)stream>>>(y_dev, off_dev, len_dev, P, fit_out_dev,
+                                                                   ncross > 0 ? cross_out_dev : nullptr);
+  IRA_RETURN_LAUNCH();
+}

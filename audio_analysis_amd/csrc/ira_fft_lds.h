@@ -1,0 +1,135 @@
+// In-LDS power-of-two complex FFTs shared by the STFT and long-FFT kernels.
+//
+//  lds_fft_dif : decimation-in-frequency, natural-order input -> BIT-REVERSED output (forward, e^{-i...}).
+//  lds_fft_dit : decimation-in-time, BIT-REVERSED input -> natural-order output; with conj_tw it is the
+//                (unnormalised) inverse of lds_fft_dif, so a forward/inverse pair needs no reorder pass.
+// Radix-4 passes plus one radix-2 pass when log2(M) is odd; in place; `nbat` independent transforms laid out
+// `bstride` elements apart are processed together (all `nt` threads must call; the functions contain barriers).
+//
+// Twiddles come from a caller-provided table tw[k] = exp(-2*pi*i*k/TWN), k < TWN/2, TWN = M * tw_per_m;
+// angles in [pi, 2pi) use W^(k+TWN/2) = -W^k.
+#pragma once
+#include "ira_common.h"
+
+namespace ira {
+
+__device__ __forceinline__ unsigned lds_brev(unsigned k, int log2m) {
+  return log2m == 0 ? 0u : (__brev(k) >> (32 - log2m));
+}
+
+template <typename T>
+__device__ __forceinline__ cplx<T> tw_lookup(const cplx<T>* __restrict__ tw, unsigned idx, unsigned half) {
+  // idx in [0, 2*half)
+  if (idx >= half) {
+    const cplx<T> w = tw[idx - half];
+    return {-w.re, -w.im};
+  }
+  return tw[idx];
+}
+
+template <typename T>
+__device__ __forceinline__ void lds_fft_dif(cplx<T>* buf, int log2m, const cplx<T>* __restrict__ tw,
+                                            unsigned tw_per_m, int tid, int nt, int nbat = 1,
+                                            unsigned bstride = 0) {
+  const unsigned M = 1u << log2m;
+  const unsigned half = (M * tw_per_m) >> 1;
+  int s = log2m;  // log2 of the current block length S
+  while (s >= 2) {
+    const unsigned q = 1u << (s - 2);               // quarter block
+    const unsigned step = tw_per_m << (log2m - s);  // table steps per unit of j at block length S
+    const unsigned per = M >> 2;
+    for (unsigned g = tid; g < per * (unsigned)nbat; g += nt) {
+      const unsigned which = g >> (log2m - 2), b = g & (per - 1);
+      cplx<T>* p = buf + which * bstride;
+      const unsigned j = b & (q - 1);
+      const unsigned base = ((b >> (s - 2)) << s) + j;
+      const cplx<T> a0 = p[base], a1 = p[base + q], a2 = p[base + 2 * q], a3 = p[base + 3 * q];
+      const cplx<T> p02 = cadd(a0, a2), m02 = csub(a0, a2);
+      const cplx<T> p13 = cadd(a1, a3), m13 = cmul_mi(csub(a1, a3));  // -i (a1 - a3)
+      cplx<T> c0 = cadd(p02, p13);
+      cplx<T> c1 = csub(p02, p13);
+      cplx<T> c2 = cadd(m02, m13);
+      cplx<T> c3 = csub(m02, m13);
+      if (j != 0) {
+        const cplx<T> w1 = tw[j * step];                       // W_S^j      (j*step < half/2)
+        const cplx<T> w2 = tw[2 * j * step];                   // W_S^(2j)   (< half)
+        const cplx<T> w3 = tw_lookup(tw, 3 * j * step, half);  // W_S^(3j)   (< 3/2 half)
+        c1 = cmul(c1, w2);
+        c2 = cmul(c2, w1);
+        c3 = cmul(c3, w3);
+      }
+      p[base] = c0; p[base + q] = c1; p[base + 2 * q] = c2; p[base + 3 * q] = c3;
+    }
+    __syncthreads();
+    s -= 2;
+  }
+  if (s == 1) {  // final radix-2 pass, block length 2, twiddle 1
+    const unsigned per = M >> 1;
+    for (unsigned g = tid; g < per * (unsigned)nbat; g += nt) {
+      const unsigned which = g >> (log2m - 1), b = g & (per - 1);
+      cplx<T>* p = buf + which * bstride;
+      const cplx<T> a0 = p[2 * b], a1 = p[2 * b + 1];
+      p[2 * b] = cadd(a0, a1);
+      p[2 * b + 1] = csub(a0, a1);
+    }
+    __syncthreads();
+  }
+}
+
+// Bit-reversed input -> natural output.  conj_tw = true uses exp(+i...) twiddles (inverse transform,
+// unnormalised); false gives the forward transform of a bit-reversed-order input.
+template <typename T>
+__device__ __forceinline__ void lds_fft_dit(cplx<T>* buf, int log2m, const cplx<T>* __restrict__ tw,
+                                            unsigned tw_per_m, bool conj_tw, int tid, int nt, int nbat = 1,
+                                            unsigned bstride = 0) {
+  const unsigned M = 1u << log2m;
+  const unsigned half = (M * tw_per_m) >> 1;
+  int s = 0;  // log2 of the block length already combined
+  if (log2m & 1) {  // first radix-2 pass, block length 2
+    const unsigned per = M >> 1;
+    for (unsigned g = tid; g < per * (unsigned)nbat; g += nt) {
+      const unsigned which = g >> (log2m - 1), b = g & (per - 1);
+      cplx<T>* p = buf + which * bstride;
+      const cplx<T> a0 = p[2 * b], a1 = p[2 * b + 1];
+      p[2 * b] = cadd(a0, a1);
+      p[2 * b + 1] = csub(a0, a1);
+    }
+    __syncthreads();
+    s = 1;
+  }
+  while (s < log2m) {
+    // combine blocks of length q = 2^s into blocks of length S = 4q
+    const unsigned q = 1u << s;
+    const int sS = s + 2;
+    const unsigned step = tw_per_m << (log2m - sS);
+    const unsigned per = M >> 2;
+    for (unsigned g = tid; g < per * (unsigned)nbat; g += nt) {
+      const unsigned which = g >> (log2m - 2), b = g & (per - 1);
+      cplx<T>* p = buf + which * bstride;
+      const unsigned j = b & (q - 1);
+      const unsigned base = ((b >> s) << sS) + j;
+      const cplx<T> a0 = p[base];
+      cplx<T> t1 = p[base + q], t2 = p[base + 2 * q], t3 = p[base + 3 * q];
+      if (j != 0) {
+        cplx<T> w1 = tw[j * step];
+        cplx<T> w2 = tw[2 * j * step];
+        cplx<T> w3 = tw_lookup(tw, 3 * j * step, half);
+        if (conj_tw) { w1.im = -w1.im; w2.im = -w2.im; w3.im = -w3.im; }
+        t1 = cmul(t1, w2);
+        t2 = cmul(t2, w1);
+        t3 = cmul(t3, w3);
+      }
+      const cplx<T> s01 = cadd(a0, t1), d01 = csub(a0, t1);
+      const cplx<T> s23 = cadd(t2, t3);
+      const cplx<T> d23 = conj_tw ? cmul_pi(csub(t2, t3)) : cmul_mi(csub(t2, t3));  // (+-i)(t2 - t3)
+      p[base] = cadd(s01, s23);
+      p[base + q] = cadd(d01, d23);
+      p[base + 2 * q] = csub(s01, s23);
+      p[base + 3 * q] = csub(d01, d23);
+    }
+    __syncthreads();
+    s = sS;
+  }
+}
+
+}  // namespace ira

@@ -1,0 +1,109 @@
+/*
+ * ira.h -- C-ABI of libira.so: batched impulse-response analysis kernels for AMD MI355X (gfx950).
+ *
+ * The reference project (kianmcevoy/audio_analysis) is pure Python and has no FFI for this path
+ * (SURVEY.md section 8b); the boundary it exposes is its per-module Python API.  Each entry point
+ * below therefore cites the reference Python function whose numeric body it replaces, and
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no exceptions, no torch types.
+ *  - Every pointer named *_dev is DEVICE memory owned by the caller (the Python host allocates
+ *    torch-ROCm tensors and passes data_ptr()).  The library allocates nothing the caller sees and
+ *    keeps no state: all tables (windows, twiddles) are caller-provided device buffers.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls only enqueue work;
+ *    they never synchronise.  Re-entrant per stream.
+ *  - Ragged batches: a flat float32 sample buffer plus per-segment int64 offset/length arrays.
+ *  - Return value: 0 = ok; negative = argument error (IRA_E_*); <= -1000 = -(1000 + hipError_t).
+ */
+#ifndef IRA_H_
+#define IRA_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IRA_OK 0
+#define IRA_E_NULL (-1)       /* a required pointer was NULL */
+#define IRA_E_SIZE (-2)       /* a size/shape argument is out of the supported range */
+#define IRA_E_UNSUPPORTED (-3)
+#define IRA_E_HIP_BASE (-1000)
+
+#define IRA_ABI_VERSION 1
+
+int32_t ira_abi_version(void);
+const char* ira_error_string(int32_t code);
+
+/* ---- a2: peak pick ---------------------------------------------------------------------------
+ * peak_dev[s] = argmax_n |x[off[s]+n]|, n < len[s]; the FIRST maximum wins (bit-exact integer).
+ * Replaces np.argmax(np.abs(x)) at reference analyse/decay.py:136, spectrogram.py:181,
+ * waterfall.py:359, modalcloud.py:299, frequency_response.py:186, filterplot.py:125,
+ * zplane.py:197, rt60bands.py:335.  Also returns the peak magnitude (zplane.py:211). */
+int32_t ira_peak_index(const float* x_dev, const int64_t* off_dev, const int64_t* len_dev,
+                       int32_t nseg, int64_t* peak_dev, float* peak_abs_dev, void* stream);
+
+/* ---- a3: Schroeder energy-decay curve ----------------------------------------------------------
+ * For each segment: e = x^2 (f64) -> reverse cumulative sum -> max(.,eps) -> /edc[0] -> 10 log10
+ * -> max(.,floor_db) -> float32, written to edc_db_dev at the same offsets as the input segment
+ * (edc_off_dev).  Replaces compute_schroeder_edc_db, reference analyse/decay.py:115-170
+ * edc_db64_dev (optional, may be NULL): the same curve as float64 BEFORE the floor, for the optional
+ * host-side dB smoothing of decay.py:161-164.  edc_db_dev may be NULL if only that is wanted.
+ * scratch_dev: nseg * IRA_EDC_SCRATCH_DOUBLES doubles.  Segments up to 2048*4096 samples. */
+#define IRA_EDC_SCRATCH_DOUBLES 2048
+int32_t ira_edc_db(const float* x_dev, const int64_t* off_dev, const int64_t* len_dev, int32_t nseg,
+                   double eps, double floor_db, float* edc_db_dev, double* edc_db64_dev,
+                   const int64_t* edc_off_dev, double* scratch_dev, void* stream);
+
+/* ---- a4/a5/a16: threshold crossings + straight-line decay fits on a float32 dB curve -------------
+ * For each curve c (ncurves of them) and each of nranges (hi_db, lo_db_effective) pairs:
+ *   first index with y <= target (float32 compare), linear interpolation of the crossing time in
+ *   f64, mask t>=t_start & t<=t_end in float32, >= min_points, least-squares line, slope<0, r^2,
+ *   rt60 = -60/slope.
+ * Replaces _interpolated_crossing_time_seconds + fit_decay_slope_over_db_range, reference
+ * analyse/decay.py:173-260, and the per-bin copy analyse/modalcloud.py:215-281.
+ * Time axis: t[i] = float32(i) * t_mul / t_div evaluated in float32 exactly like the reference
+ * (decay.py:169: t_mul = 1, t_div = sr; spectrogram.py:158: t_mul = hop, t_div = sr).
+ * If t_axis_dev != NULL it is an explicit float32 time axis (>= max_len values, shared by all curves)
+ * used instead of the analytic one (the public fit_decay_slope_over_db_range takes any time array).
+ * If rel_to_peak != 0 the curve is first shifted by its own maximum in float32
+ * (modalcloud.py:356-361) and curves that are not finite or whose peak - floor_db <
+ * min_peak_above_floor are flagged invalid (status bit 2).
+ * ranges_hi_lo (2*nranges doubles) and cross_targets are HOST arrays; nranges <= 4, ncross <= 4;
+ * max_len (longest curve) only picks the workgroup size.
+ * cross_targets (ncross values) -> cross_out_dev[c*ncross + j] crossing time or NaN
+ * (used for the 0 / -10 dB early-decay time, decay.py:280-286).
+ * fit_out_dev: ncurves*nranges records of IRA_FIT_DOUBLES doubles:
+ *   [0] valid (1/0) [1] start_t [2] end_t [3] slope [4] intercept [5] r2 [6] rt60 [7] npts */
+#define IRA_FIT_DOUBLES 8
+int32_t ira_curve_fits(const float* y_dev, const int64_t* off_dev, const int64_t* len_dev,
+                       int32_t ncurves, int32_t max_len, float t_mul, float t_div,
+                       const float* t_axis_dev, const double* ranges_hi_lo,
+                       int32_t nranges, int32_t min_points, const double* cross_targets,
+                       int32_t ncross, int32_t rel_to_peak, double floor_db,
+                       double min_peak_above_floor, double* fit_out_dev, double* cross_out_dev,
+                       void* stream);
+
+/* ---- a11: STFT magnitude in dB -------------------------------------------------------------------
+ * Valid framing (no padding), frame f of segment s starts at off[s] + f*hop, nframes[s] frames.
+ * out[s] is a C-contiguous (n_fft/2+1, nframes[s]) float32 matrix at out_dev + out_off[s]:
+ *   20*log10(max(|rfft(frame*window)|, 10^(floor_db/20))).
+ * Replaces _compute_stft_magnitude_db, reference analyse/spectrogram.py:107-160 and its copies
+ * analyse/waterfall.py:188-230, analyse/modalcloud.py:121-158.
+ * precision: 32 = float32 butterflies (spectrogram), 64 = float64 butterflies.
+ * window_dev: n_fft values; twiddle_dev: n_fft/2 interleaved (cos, -sin) pairs of
+ * exp(-2*pi*i*k/n_fft); both float (precision 32) or double (precision 64).
+ * frame_sel_dev (optional): if not NULL, nframes[s] is the number of SELECTED frames and
+ * frame_sel_dev[sel_off[s] + j] gives the frame index of output column j (waterfall shortcut,
+ * reference analyse/waterfall.py:309). n_fft: power of two, 64..16384. */
+int32_t ira_stft_mag_db(const float* x_dev, const int64_t* off_dev, const int32_t* nframes_dev,
+                        int32_t nseg, int32_t max_frames, int32_t n_fft, int32_t hop,
+                        const void* window_dev, const void* twiddle_dev, int32_t precision,
+                        double floor_db, float* out_dev, const int64_t* out_off_dev,
+                        const int32_t* frame_sel_dev, const int64_t* sel_off_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IRA_H_ */

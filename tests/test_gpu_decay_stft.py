@@ -1,0 +1,155 @@
+"""GPU parity: decay (EDC + fits) and STFT/spectrogram vs the oracle and the golden vectors."""
+import numpy as np
+import pytest
+
+from oracle import ira_oracle as O
+
+pytestmark = pytest.mark.gpu
+SR = 48000
+
+
+def _rel(a, b):
+    return abs(a - b) / max(abs(b), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def amd():
+    from audio_analysis_amd.analyse import decay, spectrogram
+    return decay, spectrogram
+
+
+def test_peak_index_exact(golden):
+    g, c, _ = golden
+    from audio_analysis_amd.engine import get_engine
+    eng = get_engine()
+    chans = [g[f"in/{k}"] for k in ("xa", "xb", "xb16", "xc", "xd", "xe", "xs_l", "xs_r")]
+    rng = np.random.default_rng(3)
+    ties = np.zeros(70001, dtype=np.float32); ties[[17, 40000, 69999]] = [-0.5, 0.5, 0.5]   # first max wins
+    chans += [ties, np.zeros(100, np.float32), rng.standard_normal(1_000_003).astype(np.float32)]
+    b = eng.upload(chans)
+    pk = eng.peaks(b)
+    for i, x in enumerate(chans):
+        assert pk[i] == int(np.argmax(np.abs(x))), i
+        assert b.peak_abs[i] == np.abs(x).max()
+
+
+@pytest.mark.parametrize("tag,inp", [("xa", "xa"), ("xa_edt", "xa"), ("xa_ign", "xa"), ("xa_notrim", "xa"),
+                                     ("xa_smooth", "xa"), ("xb", "xb"), ("xb16", "xb16"), ("xc", "xc")])
+def test_decay_vs_golden(golden, amd, tag, inp):
+    decay, _ = amd
+    g, c, _ = golden
+    case = c[f"{tag}/decay"]
+    r = decay.analyse_decay_for_channel(g[f"in/{inp}"], SR, "mono", decay.DecayAnalysisSettings(**case["kw"]))
+    assert r.analysis_start_sample_index == case["start"]            # bit-exact index
+    ref = g[f"{tag}/decay/edc_db"]
+    assert r.edc_db.shape == ref.shape and r.edc_db.dtype == np.float32
+    if not case["kw"].get("edc_smoothing_window_samples"):
+        assert r.edc_db[0] == 0.0          # exact: the kernel normalises by its own value at index 0
+    # float64 scan order differs from numpy's sequential cumsum only in the last bits: <= 1 float32 ulp
+    np.testing.assert_allclose(r.edc_db, ref, rtol=3e-7, atol=1e-6)
+    assert (r.early_decay_10db_time_seconds is None) == (case["early"] is None)
+    if case["early"] is not None:
+        assert _rel(r.early_decay_10db_time_seconds, case["early"]) < 1e-6
+    assert set(r.fits) == set(case["fits"])
+    for k, f in r.fits.items():
+        gold = case["fits"][k]
+        assert _rel(f.rt60_seconds, gold[7]) < 1e-6, (k, f.rt60_seconds, gold[7])   # north_star bar is 1e-4
+        assert _rel(f.slope_db_per_second, gold[4]) < 1e-6
+        assert abs(f.r_squared - gold[6]) < 1e-9
+        assert abs(f.start_time_seconds - gold[2]) < 1e-7 and abs(f.end_time_seconds - gold[3]) < 1e-7
+    assert decay.summarise_decay_results_text([r]) == case["summary"]
+
+
+def test_public_fit_function(golden, amd):
+    decay, _ = amd
+    g, c, _ = golden
+    t, db, start = decay.compute_schroeder_edc_db(g["in/xb"], SR, decay.DecayAnalysisSettings())
+    assert start == c["xb/decay"]["start"]
+    f = decay.fit_decay_slope_over_db_range(t, db, (-5.0, -35.0), -80.0, "T30")
+    assert _rel(f.rt60_seconds, c["xb/decay"]["fits"]["T30"][7]) < 1e-6
+    assert decay.fit_decay_slope_over_db_range(t, db, (-5.0, -200.0), -300.0, "X") is None
+    with pytest.raises(ValueError):
+        decay.fit_decay_slope_over_db_range(t, db, (-25.0, -5.0), -80.0, "bad")
+    with pytest.raises(ValueError):
+        decay.compute_schroeder_edc_db(np.zeros((4, 2), np.float32), SR, decay.DecayAnalysisSettings())
+    with pytest.raises(ValueError):
+        decay.analyse_decay_for_channel(np.array([0, 0, 1.0], np.float32), SR, "m", decay.DecayAnalysisSettings())
+
+
+def _stft_check(got, ref, floor_db=-120.0):
+    """float32-FFT tolerance: 1e-3 dB for bins within 50 dB of the frame's peak and > floor + 20 dB;
+    linear error below 3e-6 of the frame's peak everywhere."""
+    assert got.shape == ref.shape and got.dtype == np.float32
+    peak = ref.max(axis=0, keepdims=True)
+    strong = (ref > peak - 50.0) & (ref > floor_db + 20.0)
+    assert np.max(np.abs(got - ref)[strong]) < 1e-3
+    lin_err = np.abs(10.0 ** (got.astype(np.float64) / 20) - 10.0 ** (ref.astype(np.float64) / 20))
+    assert np.max(lin_err / 10.0 ** (peak.astype(np.float64) / 20)) < 3e-6
+
+
+@pytest.mark.parametrize("precision", [32, 64])
+def test_stft_vs_golden(golden, precision):
+    g, c, _ = golden
+    from audio_analysis_amd.engine import get_engine
+    eng = get_engine()
+    for nfft in (4096, 8192):
+        cs = c[f"stft{nfft}"]
+        seg = g["in/xb"][cs["seg_start"] : cs["seg_start"] + cs["seg_len"]]
+        b = eng.upload([seg])
+        nfr = np.array([1 + (seg.size - nfft) // 512], dtype=np.int32)
+        out, off, cols = eng.stft_mag_db(b.x, b.off, nfr, nfft, 512, True, -120.0, precision)
+        got = out.cpu().numpy()[: (nfft // 2 + 1) * nfr[0]].reshape(nfft // 2 + 1, nfr[0])
+        ref = g[f"stft{nfft}/mag_db"]
+        if precision == 64:
+            np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5)     # f64 butterflies: float32 rounding only
+            assert np.mean(got == ref) > 0.99
+        else:
+            _stft_check(got, ref)
+    seg = g["in/xa"][240:6240]
+    b = eng.upload([seg])
+    nfr = np.array([1 + (seg.size - 1024) // 256], dtype=np.int32)
+    out, _, _ = eng.stft_mag_db(b.x, b.off, nfr, 1024, 256, False, -100.0, precision)
+    got = out.cpu().numpy()[: 513 * nfr[0]].reshape(513, nfr[0])
+    if precision == 64:
+        np.testing.assert_allclose(got, g["stft1024rect/mag_db"], rtol=0, atol=2e-5)
+    else:
+        _stft_check(got, g["stft1024rect/mag_db"], -100.0)
+
+
+def test_spectrogram_vs_golden(golden, amd):
+    _, spectrogram = amd
+    g, c, _ = golden
+    r = spectrogram.analyse_spectrogram_for_channel(g["in/xa"], SR, "mono", spectrogram.SpectrogramAnalysisSettings())
+    cs = c["xa/spectrogram"]
+    assert (r.analysis_start_sample_index, r.analysis_length_samples) == (cs["start"], cs["length"])
+    _stft_check(r.magnitude_db, g["xa/spectrogram/mag_db"])
+    assert spectrogram.summarise_spectrogram_results_text([r]) == cs["summary"]
+    np.testing.assert_array_equal(r.frequency_hz, np.fft.rfftfreq(4096, 1 / 48000.0).astype(np.float32))
+    r = spectrogram.analyse_spectrogram_for_channel(
+        g["in/xb"], SR, "mono",
+        spectrogram.SpectrogramAnalysisSettings(ignore_leading_seconds=0.01, analysis_duration_seconds=0.5))
+    cs = c["xb_sel/spectrogram"]
+    assert (r.analysis_start_sample_index, r.analysis_length_samples, list(r.magnitude_db.shape)) == (
+        cs["start"], cs["length"], cs["shape"])
+    assert spectrogram.summarise_spectrogram_results_text([r]) == cs["summary"]
+    with pytest.raises(ValueError):
+        spectrogram.analyse_spectrogram_for_channel(g["in/xa"][:3000], SR, "m", spectrogram.SpectrogramAnalysisSettings())
+
+
+def test_batch_matches_oracle_ragged():
+    """Ragged batch at a mid size, compared with the oracle run on the same seeded inputs."""
+    from audio_analysis_amd.analyse import decay, spectrogram
+    from audio_analysis_amd.synth import synth_ir
+    chans = [synth_ir(i, 0, 96000 - 1000 * i) for i in range(5)]
+    res = decay.analyse_decay_batch(chans, SR, [f"c{i}" for i in range(5)], decay.DecayAnalysisSettings(compute_edt=True))
+    spec = spectrogram.analyse_spectrogram_batch(chans, SR, [f"c{i}" for i in range(5)],
+                                                 spectrogram.SpectrogramAnalysisSettings())
+    for x, r, s in zip(chans, res, spec):
+        o = O.analyse_decay(x, SR, compute_edt=True)
+        assert r.analysis_start_sample_index == o["start"]
+        np.testing.assert_allclose(r.edc_db, o["edc_db"], rtol=3e-7, atol=1e-6)
+        assert set(r.fits) == set(o["fits"])
+        for k in r.fits:
+            assert _rel(r.fits[k].rt60_seconds, o["fits"][k]["rt60"]) < 1e-6
+        os_ = O.analyse_spectrogram(x, SR)
+        _stft_check(s.magnitude_db, os_["magnitude_db"])
