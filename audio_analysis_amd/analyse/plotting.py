@@ -94,3 +94,86 @@ def render_spectrogram(result, settings, plot_settings, title, path, show):
     ax.set_xlabel("Time (s)"); ax.set_ylabel("Frequency (Hz)"); _log_hz(ax, lo, hi, "y")
     fig.colorbar(mesh, ax=ax, label="Magnitude (dB)")
     finish(fig, path, show)
+
+
+def render_frequency_response(results, settings, plot_settings, title, path, show):
+    if path is None and not show:
+        return
+    fig, ax = new_axes(title)
+    nyq = 0.5 * results[0].sample_rate_hz
+    lo = float(np.clip(settings.f_min_hz, 1.0, nyq)); hi = float(np.clip(settings.f_max_hz, lo, nyq))
+    for i, r in enumerate(results):
+        sel = (r.frequency_hz >= lo) & (r.frequency_hz <= hi)
+        ax.plot(r.frequency_hz[sel], r.magnitude_db[sel], alpha=1.0 if i == 0 else plot_settings.secondary_channel_alpha,
+                label=f"{r.channel_name}  peak={r.peak_frequency_hz:.0f}Hz  centroid={r.spectral_centroid_hz:.0f}Hz")
+    _log_hz(ax, lo, hi, "x")
+    ax.set_xlabel("Frequency (Hz)"); ax.set_ylabel("Level (dB)")
+    if plot_settings.ylim_db is not None:
+        ax.set_ylim(*plot_settings.ylim_db)
+    ax.grid(True, which="both", linestyle=":"); ax.legend(loc="best")
+    finish(fig, path, show)
+
+
+def render_filter_response(results, settings, plot_settings, title, path, show):
+    if path is None and not show:
+        return
+    plt = _plt()
+    fig, (ax_m, ax_p) = plt.subplots(2, 1, figsize=(10, 8))
+    fig.suptitle(title, fontsize=12, fontweight="bold")
+    nyq = 0.5 * results[0].sample_rate_hz
+    lo = float(np.clip(settings.f_min_hz, 1.0, nyq)); hi = float(np.clip(settings.f_max_hz, lo, nyq))
+    for i, r in enumerate(results):
+        sel = (r.frequency_hz >= lo) & (r.frequency_hz <= hi)
+        a = 1.0 if i == 0 else plot_settings.secondary_channel_alpha
+        ax_m.plot(r.frequency_hz[sel], r.magnitude_db[sel], alpha=a,
+                  label=f"{r.channel_name}  peak={r.peak_frequency_hz:.0f}Hz  @1kHz={r.magnitude_at_1khz_db:.1f}dB")
+        ax_p.plot(r.frequency_hz[sel], r.phase_response[sel], alpha=a, label=r.channel_name)
+    for ax, lab in ((ax_m, "Magnitude (dB)"), (ax_p, f"Phase ({'degrees' if settings.phase_mode == 'degrees' else 'radians'})")):
+        ax.set_xscale("log"); ax.set_xlim(lo, hi); ax.set_xlabel("Frequency (Hz)"); ax.set_ylabel(lab)
+        ax.grid(True, which="both", linestyle=":"); ax.legend(loc="best", fontsize=9)
+    if plot_settings.magnitude_ylim_db is not None:
+        ax_m.set_ylim(plot_settings.magnitude_ylim_db)
+    if plot_settings.phase_ylim is not None:
+        ax_p.set_ylim(plot_settings.phase_ylim)
+    fig.tight_layout()
+    finish(fig, path, show)
+
+
+def render_rt60_bands(results, settings, plot_settings, title, path, show):
+    if path is None and not show:
+        return
+    fig, ax = new_axes(title)
+    bands = results[0].band_definitions
+    cols = [("T30", "rt60_t30_seconds", "-")]
+    if settings.include_t20:
+        cols.append(("T20", "rt60_t20_seconds", "--"))
+    if settings.include_edt:
+        cols.append(("EDT", "edt_seconds", ":"))
+    names = [b.name for b in bands]
+    centres = np.array([b.centre_hz for b in bands], dtype=np.float32)
+    as_bars = len(bands) <= 6
+    groups = len(cols) * len(results)
+    width = 0.8 / max(1, groups)
+    slot = 0
+    for i, ch in enumerate(results):
+        a = 1.0 if i == 0 else plot_settings.secondary_channel_alpha
+        for key, attr, ls in cols:
+            vals = [getattr(ch.band_metrics_by_name[n], attr) for n in names]
+            arr = np.array([np.nan if v is None else v for v in vals], dtype=np.float32)
+            label = f"{key} {ch.channel_name}"
+            if plot_settings.legend_values:
+                label += "  " + "  ".join(f"{n}={'NA' if v is None else f'{v:.2f}s'}" for n, v in zip(names, vals))
+            if as_bars:
+                ax.bar(np.arange(len(bands)) + (slot - groups / 2) * width + width / 2, arr, width=width, alpha=a, label=label)
+            else:
+                ax.plot(centres, arr, linestyle=ls, marker="o", alpha=a, label=label)
+            slot += 1
+    if as_bars:
+        ax.set_xticks(np.arange(len(bands))); ax.set_xticklabels(names); ax.set_xlabel("Band")
+    else:
+        ax.set_xscale("log"); ax.set_xlabel("Band centre frequency (Hz)")
+    ax.set_ylabel("RT60 (seconds)")
+    if plot_settings.ylim_seconds is not None:
+        ax.set_ylim(*plot_settings.ylim_seconds)
+    ax.grid(True, linestyle=":"); ax.legend(loc="best")
+    finish(fig, path, show)

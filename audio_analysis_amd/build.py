@@ -25,6 +25,8 @@ SOURCES = {
     "ira_api.hip": [],
     "ira_edc.hip": ["-ffp-contract=off"],
     "ira_stft.hip": [],
+    "ira_fftlong.hip": [],
+    "ira_spectrum.hip": ["-ffp-contract=off"],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 

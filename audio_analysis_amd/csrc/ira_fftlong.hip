@@ -1,0 +1,372 @@
+// Arbitrary-length float64 DFTs of whole impulse responses (lengths are data dependent and generally not
+// powers of two: N - argmax|x|), used by
+//   * frequency response / filter response: rfft(x * hanning(L))        (reference frequency_response.py:204-213,
+//                                                                         filterplot.py:145-152)
+//   * RT60 bands: rfft(x) once, then irfft(spectrum * mask, n) per band  (reference rt60bands.py:170-175)
+//
+// Method: Bluestein (chirp-z).  With w[n] = exp(-i*pi*n^2/L):
+//     X[k] = w[k] * sum_n (x[n] w[n]) * conj(w[k-n])
+// i.e. one circular convolution of length M = 2^m >= 2L-1, done with a four-step FFT M = N1 x N2 whose
+// sub-transforms run in LDS (ira_fft_lds.h):
+//   K1 cols_fwd : generate the input on the fly (samples*window*chirp | chirp filter | masked spectrum*chirp),
+//                 N1-point DIF down each column (stride N2), twiddle W_M^(n2*k1), store in place
+//   K2 rows     : N2-point DIF along each row, multiply by the filter spectrum B (same permuted layout), N2-point
+//                 inverse DIT, inverse twiddle -- the row never leaves LDS in between
+//   K3 cols_inv : N1-point inverse DIT down each column, fused epilogue (spectrum bins | two band signals)
+// The DIF leaves results bit-reversed and the DIT consumes bit-reversed input, so no transposes or reorder
+// passes exist; K1->K2->K3 each read and write the M*16-byte work array once.
+// All arithmetic is float64: the reference computes these FFTs in float64 (numpy pocketfft) and the unwrapped
+// phase / band RT60 values are discrete functions of them.
+#include <cmath>
+
+#include "ira_fft_lds.h"
+
+namespace {
+
+using ira::cplx;
+typedef cplx<double> cd;
+
+constexpr int FL_THREADS = 256;
+constexpr double kPi = 3.14159265358979323846;
+
+struct Geom {
+  int log2m, log2n1, log2n2;
+  const cd* t1;  // exp(-2 pi i k / N1), k < N1   (full circle; first half doubles as the N1 sub-FFT table)
+  const cd* t2;  // exp(-2 pi i k / N2), k < N2
+  const cd* tf;  // exp(-2 pi i k / M),  k < N2
+};
+
+// W_M^p for p < M as a product of a coarse (N1-entry) and a fine (N2-entry) table value.
+__device__ __forceinline__ cd twiddle_m(const Geom& g, unsigned p) {
+  const unsigned hi = p >> g.log2n2, lo = p & ((1u << g.log2n2) - 1u);
+  return ira::cmul(g.t1[hi], g.tf[lo]);
+}
+
+// exp(-i*pi*n^2/L) with the phase reduced exactly in integers (n < 2^31, L < 2^31).
+__device__ __forceinline__ cd chirp(long long n, long long L) {
+  const long long q = (n * n) % (2 * L);
+  double s, c;
+  sincospi((double)q / (double)L, &s, &c);
+  return {c, -s};
+}
+
+// numpy.hanning(L)[i] = 0.5 + 0.5*cos(pi*(2i + 1 - L)/(L - 1)); hanning(1) = 1
+__device__ __forceinline__ double hann_at(long long i, long long L) {
+  if (L <= 1) return 1.0;
+  return 0.5 + 0.5 * cospi((double)(2 * i + 1 - L) / (double)(L - 1));
+}
+
+// ---- band masks (reference rt60bands.py:116-167), float32 arithmetic on a float32 frequency axis ------------
+struct BandMask {
+  // kind: 0 zero mask, 1 low-pass, 2 high-pass, 3 band-pass (= hp * lp)
+  double kind, hp_x0, hp_x1, lp_x0, lp_x1, pad0, pad1, pad2;
+};
+
+__device__ __forceinline__ float ramp_f32(float f, double x0, double x1) {
+  if (x1 <= x0) return f >= (float)x1 ? 1.0f : 0.0f;
+  float t = (f - (float)x0) / (float)(x1 - x0);
+  t = fminf(fmaxf(t, 0.0f), 1.0f);
+  const float arg = (float)kPi * t;
+  const float cs = (float)cos((double)arg);  // correctly rounded float32 cosine
+  return 0.5f - 0.5f * cs;
+}
+__device__ __forceinline__ float lowpass_f32(float f, double pass, double stop) {
+  float m = 1.0f - ramp_f32(f, pass, stop);
+  if (f <= (float)pass) m = 1.0f;
+  if (f >= (float)stop) m = 0.0f;
+  return m;
+}
+__device__ __forceinline__ float highpass_f32(float f, double stop, double pass) {
+  float m = ramp_f32(f, stop, pass);
+  if (f <= (float)stop) m = 0.0f;
+  if (f >= (float)pass) m = 1.0f;
+  return m;
+}
+__device__ __forceinline__ float mask_at(const BandMask& b, float f) {
+  const int kind = (int)b.kind;
+  if (kind == 1) return lowpass_f32(f, b.lp_x0, b.lp_x1);
+  if (kind == 2) return highpass_f32(f, b.hp_x0, b.hp_x1);
+  if (kind == 3) return highpass_f32(f, b.hp_x0, b.hp_x1) * lowpass_f32(f, b.lp_x0, b.lp_x1);
+  return 0.0f;
+}
+
+// ---- per-element job description (device arrays, one entry per batch element) ----------------------------------
+struct Jobs {
+  const int32_t* L;         // transform length of element e
+  // signal input
+  const float* x;
+  const int64_t* xoff;
+  int use_hann;
+  // masked-spectrum input
+  const cd* spec;           // half spectra, complex f64
+  const int64_t* spec_off;  // element e reads spec + spec_off[e], (L/2+1) bins
+  const BandMask* bands;    // 2 per element
+  const double* freq_val;   // rfftfreq step of element e: bin k -> float32(k * freq_val[e])
+  // filter spectra
+  const cd* bfilt;          // [nfilt][M]
+  const int32_t* bidx;      // which filter element e uses
+  // outputs
+  cd* spec_out;
+  const int64_t* spec_out_off;
+  float* y;
+  const int64_t* y1_off;    // first band signal of element e (length L)
+  const int64_t* y2_off;    // second band signal or -1
+};
+
+enum InMode { IN_SIGNAL = 0, IN_FILTER = 1, IN_SPECTRUM = 2 };
+enum RowMode { ROW_FWD = 0, ROW_CONV = 1 };
+enum OutMode { OUT_SPECTRUM = 0, OUT_BANDS = 1 };
+
+template <int MODE>
+__device__ __forceinline__ cd gen_input(const Jobs& J, int e, long long n, long long L, long long M) {
+  if (MODE == IN_SIGNAL) {
+    if (n >= L) return {0.0, 0.0};
+    double v = (double)J.x[J.xoff[e] + n];
+    if (J.use_hann) v *= hann_at(n, L);
+    const cd w = chirp(n, L);
+    return {v * w.re, v * w.im};
+  } else if (MODE == IN_FILTER) {
+    long long m = n;
+    if (n >= L) {
+      m = M - n;
+      if (m >= L) return {0.0, 0.0};
+    }
+    const cd w = chirp(m, L);
+    return {w.re, -w.im};  // conj(w)
+  } else {
+    if (n >= L) return {0.0, 0.0};
+    // Hermitian extension of X * (m1 + i m2); the inverse DFT is conj(DFT(conj(.)))/L, so feed conj(W) * chirp
+    const bool upper = n > L / 2;
+    const long long k = upper ? L - n : n;
+    cd xk = J.spec[J.spec_off[e] + k];
+    if (upper) xk.im = -xk.im;
+    const float f = (float)((double)k * J.freq_val[e]);
+    const double m1 = (double)mask_at(J.bands[2 * e], f);
+    const double m2 = (double)mask_at(J.bands[2 * e + 1], f);
+    const cd wk = ira::cmul(xk, cd{m1, m2});
+    const cd cw = {wk.re, -wk.im};
+    return ira::cmul(cw, chirp(n, L));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K1: columns forward.  grid (N2 / C, nb); LDS C * (N1 + 1) complex.
+// ---------------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(FL_THREADS) void cols_fwd_kernel(Geom g, Jobs J, cd* __restrict__ work, int C) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  cd* lds = reinterpret_cast<cd*>(smem_raw);
+  const int e = blockIdx.y;
+  const long long L = J.L[e];
+  const unsigned N1 = 1u << g.log2n1, N2 = 1u << g.log2n2;
+  const long long M = 1ll << g.log2m;
+  const unsigned n2_0 = blockIdx.x * C;
+  const unsigned stride = N1 + 1;
+  const int tid = threadIdx.x;
+  for (unsigned i = tid; i < N1 * (unsigned)C; i += FL_THREADS) {
+    const unsigned c = i % C, n1 = i / C;
+    const long long n = (long long)n1 * N2 + n2_0 + c;
+    lds[c * stride + n1] = gen_input<MODE>(J, e, n, L, M);
+  }
+  __syncthreads();
+  ira::lds_fft_dif<double>(lds, g.log2n1, g.t1, 1u, tid, FL_THREADS, C, stride);
+  cd* w = work + (long long)e * M;
+  for (unsigned i = tid; i < N1 * (unsigned)C; i += FL_THREADS) {
+    const unsigned c = i % C, r = i / C;
+    const unsigned k1 = ira::lds_brev(r, g.log2n1);
+    const unsigned n2 = n2_0 + c;
+    const cd v = ira::cmul(lds[c * stride + r], twiddle_m(g, n2 * k1));
+    w[(long long)r * N2 + n2] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K2: rows.  grid (N1 / R, nb); LDS R * N2 complex.
+// ---------------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(FL_THREADS) void rows_kernel(Geom g, Jobs J, cd* __restrict__ work, int R) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  cd* lds = reinterpret_cast<cd*>(smem_raw);
+  const int e = blockIdx.y;
+  const unsigned N2 = 1u << g.log2n2;
+  const long long M = 1ll << g.log2m;
+  const unsigned r0 = blockIdx.x * R;
+  const int tid = threadIdx.x;
+  cd* w = work + (long long)e * M + (long long)r0 * N2;
+  for (unsigned i = tid; i < N2 * (unsigned)R; i += FL_THREADS) lds[i] = w[i];
+  __syncthreads();
+  ira::lds_fft_dif<double>(lds, g.log2n2, g.t2, 1u, tid, FL_THREADS, R, N2);
+  if (MODE == ROW_CONV) {
+    const cd* b = J.bfilt + (long long)J.bidx[e] * M + (long long)r0 * N2;
+    for (unsigned i = tid; i < N2 * (unsigned)R; i += FL_THREADS) lds[i] = ira::cmul(lds[i], b[i]);
+    __syncthreads();
+    ira::lds_fft_dit<double>(lds, g.log2n2, g.t2, 1u, true, tid, FL_THREADS, R, N2);
+    for (unsigned i = tid; i < N2 * (unsigned)R; i += FL_THREADS) {
+      const unsigned rr = i >> g.log2n2, n2 = i & (N2 - 1);
+      const unsigned k1 = ira::lds_brev(r0 + rr, g.log2n1);
+      cd t = twiddle_m(g, n2 * k1);
+      t.im = -t.im;
+      w[i] = ira::cmul(lds[i], t);
+    }
+  } else {
+    for (unsigned i = tid; i < N2 * (unsigned)R; i += FL_THREADS) w[i] = lds[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K3: columns inverse + epilogue.  grid (N2 / C, nb).
+// ---------------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(FL_THREADS) void cols_inv_kernel(Geom g, Jobs J, const cd* __restrict__ work, int C) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  cd* lds = reinterpret_cast<cd*>(smem_raw);
+  const int e = blockIdx.y;
+  const long long L = J.L[e];
+  const unsigned N1 = 1u << g.log2n1, N2 = 1u << g.log2n2;
+  const long long M = 1ll << g.log2m;
+  const unsigned n2_0 = blockIdx.x * C;
+  const unsigned stride = N1 + 1;
+  const int tid = threadIdx.x;
+  // outputs needed: n <= L/2 (spectrum) or n < L (bands); rows beyond that are computed but not stored
+  const long long n_need = (MODE == OUT_SPECTRUM) ? L / 2 + 1 : L;
+  const cd* w = work + (long long)e * M;
+  for (unsigned i = tid; i < N1 * (unsigned)C; i += FL_THREADS) {
+    const unsigned c = i % C, r = i / C;
+    lds[c * stride + r] = w[(long long)r * N2 + n2_0 + c];
+  }
+  __syncthreads();
+  ira::lds_fft_dit<double>(lds, g.log2n1, g.t1, 1u, true, tid, FL_THREADS, C, stride);
+  const double inv_m = 1.0 / (double)M;
+  for (unsigned i = tid; i < N1 * (unsigned)C; i += FL_THREADS) {
+    const unsigned c = i % C, n1 = i / C;
+    const long long n = (long long)n1 * N2 + n2_0 + c;
+    if (n >= n_need) continue;
+    cd v = lds[c * stride + n1];
+    v = ira::cmul(v, chirp(n, L));
+    if (MODE == OUT_SPECTRUM) {
+      v.re *= inv_m; v.im *= inv_m;
+      if (n == 0 || (2 * n == L)) v.im = 0.0;  // DC / Nyquist of a real signal
+      J.spec_out[J.spec_out_off[e] + n] = v;
+    } else {
+      const double sc = inv_m / (double)L;
+      // y1 + i y2 = conj(v) / L
+      J.y[J.y1_off[e] + n] = (float)(v.re * sc);
+      const long long o2 = J.y2_off[e];
+      if (o2 >= 0) J.y[o2 + n] = (float)(-v.im * sc);
+    }
+  }
+}
+
+struct Plan {
+  Geom g;
+  int C, R;
+  size_t lds_cols, lds_rows;
+};
+
+int32_t make_plan(int log2m, const void* t1, const void* t2, const void* tf, Plan* p) {
+  if (log2m < 4 || log2m > 22) return IRA_E_SIZE;
+  p->g.log2m = log2m;
+  p->g.log2n1 = (log2m + 1) / 2;
+  p->g.log2n2 = log2m / 2;
+  p->g.t1 = static_cast<const cd*>(t1);
+  p->g.t2 = static_cast<const cd*>(t2);
+  p->g.tf = static_cast<const cd*>(tf);
+  const int N1 = 1 << p->g.log2n1, N2 = 1 << p->g.log2n2;
+  int C = 8;
+  while (C > 1 && (size_t)C * (N1 + 1) * sizeof(cd) > 66 * 1024) C >>= 1;
+  if (C > N2) C = N2;
+  int R = 1;
+  while (R * 2 * N2 * (int)sizeof(cd) <= 64 * 1024 && R * 2 <= N1 && R < 16) R <<= 1;
+  p->C = C;
+  p->R = R;
+  p->lds_cols = (size_t)C * (N1 + 1) * sizeof(cd);
+  p->lds_rows = (size_t)R * N2 * sizeof(cd);
+  return IRA_OK;
+}
+
+template <typename K>
+hipError_t allow_lds(K kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)bytes);
+}
+
+#define IRA_TRY_HIP(expr)                          \
+  do {                                             \
+    hipError_t _e = (expr);                        \
+    if (_e != hipSuccess) return ira_hip_status(_e); \
+  } while (0)
+
+template <int IN, int OUT>
+int32_t run_convolution(const Plan& p, const Jobs& J, cd* work, int nb, hipStream_t st) {
+  const int N1 = 1 << p.g.log2n1, N2 = 1 << p.g.log2n2;
+  IRA_TRY_HIP(allow_lds(cols_fwd_kernel<IN>, p.lds_cols));
+  IRA_TRY_HIP(allow_lds(rows_kernel<ROW_CONV>, p.lds_rows));
+  IRA_TRY_HIP(allow_lds(cols_inv_kernel<OUT>, p.lds_cols));
+  cols_fwd_kernel<IN><<<dim3(N2 / p.C, nb), FL_THREADS, p.lds_cols, st>>>(p.g, J, work, p.C);
+  rows_kernel<ROW_CONV><<<dim3(N1 / p.R, nb), FL_THREADS, p.lds_rows, st>>>(p.g, J, work, p.R);
+  cols_inv_kernel<OUT><<<dim3(N2 / p.C, nb), FL_THREADS, p.lds_cols, st>>>(p.g, J, work, p.C);
+  IRA_RETURN_LAUNCH();
+}
+
+}  // namespace
+
+extern "C" int32_t ira_bluestein_filter(const int32_t* L_dev, int32_t nfilt, int32_t log2m, const void* t1_dev,
+                                        const void* t2_dev, const void* tf_dev, double* bfilt_dev, void* stream) {
+  IRA_CHECK_PTR(L_dev); IRA_CHECK_PTR(t1_dev); IRA_CHECK_PTR(t2_dev); IRA_CHECK_PTR(tf_dev); IRA_CHECK_PTR(bfilt_dev);
+  if (nfilt <= 0) return nfilt == 0 ? IRA_OK : IRA_E_SIZE;
+  Plan p;
+  int32_t rc = make_plan(log2m, t1_dev, t2_dev, tf_dev, &p);
+  if (rc != IRA_OK) return rc;
+  Jobs J{};
+  J.L = L_dev;
+  hipStream_t st = (hipStream_t)stream;
+  const int N1 = 1 << p.g.log2n1, N2 = 1 << p.g.log2n2;
+  IRA_TRY_HIP(allow_lds(cols_fwd_kernel<IN_FILTER>, p.lds_cols));
+  IRA_TRY_HIP(allow_lds(rows_kernel<ROW_FWD>, p.lds_rows));
+  cd* b = reinterpret_cast<cd*>(bfilt_dev);
+  cols_fwd_kernel<IN_FILTER><<<dim3(N2 / p.C, nfilt), FL_THREADS, p.lds_cols, st>>>(p.g, J, b, p.C);
+  rows_kernel<ROW_FWD><<<dim3(N1 / p.R, nfilt), FL_THREADS, p.lds_rows, st>>>(p.g, J, b, p.R);
+  IRA_RETURN_LAUNCH();
+}
+
+extern "C" int32_t ira_rfft_any(const float* x_dev, const int64_t* xoff_dev, const int32_t* L_dev, int32_t nb,
+                                int32_t use_hann, int32_t log2m, const void* t1_dev, const void* t2_dev,
+                                const void* tf_dev, const double* bfilt_dev, const int32_t* bidx_dev,
+                                double* work_dev, double* spec_out_dev, const int64_t* spec_off_dev, void* stream) {
+  IRA_CHECK_PTR(x_dev); IRA_CHECK_PTR(xoff_dev); IRA_CHECK_PTR(L_dev); IRA_CHECK_PTR(t1_dev); IRA_CHECK_PTR(t2_dev);
+  IRA_CHECK_PTR(tf_dev); IRA_CHECK_PTR(bfilt_dev); IRA_CHECK_PTR(bidx_dev); IRA_CHECK_PTR(work_dev);
+  IRA_CHECK_PTR(spec_out_dev); IRA_CHECK_PTR(spec_off_dev);
+  if (nb <= 0) return nb == 0 ? IRA_OK : IRA_E_SIZE;
+  Plan p;
+  int32_t rc = make_plan(log2m, t1_dev, t2_dev, tf_dev, &p);
+  if (rc != IRA_OK) return rc;
+  Jobs J{};
+  J.L = L_dev; J.x = x_dev; J.xoff = xoff_dev; J.use_hann = use_hann;
+  J.bfilt = reinterpret_cast<const cd*>(bfilt_dev); J.bidx = bidx_dev;
+  J.spec_out = reinterpret_cast<cd*>(spec_out_dev); J.spec_out_off = spec_off_dev;
+  return run_convolution<IN_SIGNAL, OUT_SPECTRUM>(p, J, reinterpret_cast<cd*>(work_dev), nb, (hipStream_t)stream);
+}
+
+extern "C" int32_t ira_band_irfft(const double* spec_dev, const int64_t* spec_off_dev, const int32_t* L_dev,
+                                  int32_t nb, const double* band_params_dev, const double* freq_val_dev,
+                                  int32_t log2m, const void* t1_dev, const void* t2_dev, const void* tf_dev,
+                                  const double* bfilt_dev, const int32_t* bidx_dev, double* work_dev, float* y_dev,
+                                  const int64_t* y1_off_dev, const int64_t* y2_off_dev, void* stream) {
+  IRA_CHECK_PTR(spec_dev); IRA_CHECK_PTR(spec_off_dev); IRA_CHECK_PTR(L_dev); IRA_CHECK_PTR(band_params_dev);
+  IRA_CHECK_PTR(freq_val_dev); IRA_CHECK_PTR(t1_dev); IRA_CHECK_PTR(t2_dev); IRA_CHECK_PTR(tf_dev);
+  IRA_CHECK_PTR(bfilt_dev); IRA_CHECK_PTR(bidx_dev); IRA_CHECK_PTR(work_dev); IRA_CHECK_PTR(y_dev);
+  IRA_CHECK_PTR(y1_off_dev); IRA_CHECK_PTR(y2_off_dev);
+  if (nb <= 0) return nb == 0 ? IRA_OK : IRA_E_SIZE;
+  Plan p;
+  int32_t rc = make_plan(log2m, t1_dev, t2_dev, tf_dev, &p);
+  if (rc != IRA_OK) return rc;
+  static_assert(sizeof(BandMask) == 8 * sizeof(double), "band parameter record is 8 doubles");
+  Jobs J{};
+  J.L = L_dev;
+  J.spec = reinterpret_cast<const cd*>(spec_dev); J.spec_off = spec_off_dev;
+  J.bands = reinterpret_cast<const BandMask*>(band_params_dev); J.freq_val = freq_val_dev;
+  J.bfilt = reinterpret_cast<const cd*>(bfilt_dev); J.bidx = bidx_dev;
+  J.y = y_dev; J.y1_off = y1_off_dev; J.y2_off = y2_off_dev;
+  return run_convolution<IN_SPECTRUM, OUT_BANDS>(p, J, reinterpret_cast<cd*>(work_dev), nb, (hipStream_t)stream);
+}

@@ -1,0 +1,222 @@
+// Post-processing of whole-segment spectra (complex float64 half spectra produced by ira_rfft_any):
+//   magnitude in dB (float32), phase (float64 angle), numpy.unwrap as a parallel scan, and the summary
+//   statistics of reference frequency_response.py:238-260 and filterplot.py:173-191.
+// Compiled with -ffp-contract=off (the unwrap correction arithmetic mirrors NumPy's operation by operation).
+#include <cmath>
+
+#include "ira_common.h"
+
+namespace {
+
+typedef ira::cplx<double> cd;
+constexpr double kPi = 3.14159265358979323846;
+
+// ---- |X| -> dB (float32) and angle(X) (float64) --------------------------------------------------------------
+__global__ void mag_phase_kernel(const cd* __restrict__ spec, const int64_t* __restrict__ spec_off,
+                                 const int32_t* __restrict__ L, double floor_lin, float* __restrict__ mag_db,
+                                 const int64_t* __restrict__ mag_off, double* __restrict__ phase,
+                                 const int64_t* __restrict__ phase_off) {
+  const int e = blockIdx.y;
+  const long long nb = (long long)L[e] / 2 + 1;
+  const cd* s = spec + spec_off[e];
+  for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nb; k += (long long)gridDim.x * blockDim.x) {
+    const cd v = s[k];
+    const double m = fmax(hypot(v.re, v.im), floor_lin);
+    mag_db[mag_off[e] + k] = (float)(20.0 * log10(m));
+    if (phase) phase[phase_off[e] + k] = atan2(v.im, v.re);
+  }
+}
+
+// ---- numpy.unwrap (period 2*pi) ------------------------------------------------------------------------------
+//   dd = diff(p); ddmod = mod(dd + pi, 2pi) - pi; ddmod[(ddmod == -pi) & (dd > 0)] = pi
+//   corr = ddmod - dd; corr[|dd| < pi] = 0; out[1:] = p[1:] + cumsum(corr)
+constexpr int UW_THREADS = 1024;
+constexpr int UW_PER = 4;
+constexpr int UW_TILE = UW_THREADS * UW_PER;
+
+__device__ __forceinline__ double unwrap_correction(double prev, double cur) {
+  const double dd = cur - prev;
+  const double period = 2.0 * kPi;
+  double a = dd + kPi;               // dd - interval_low
+  double md = fmod(a, period);       // numpy floor-mod for a positive divisor
+  if (md != 0.0) {
+    if (md < 0.0) md += period;
+  } else {
+    md = 0.0;
+  }
+  double ddmod = md + (-kPi);
+  if (ddmod == -kPi && dd > 0.0) ddmod = kPi;
+  double corr = ddmod - dd;
+  if (fabs(dd) < kPi) corr = 0.0;
+  return corr;
+}
+
+__global__ __launch_bounds__(UW_THREADS) void unwrap_kernel(const double* __restrict__ phase,
+                                                            const int64_t* __restrict__ phase_off,
+                                                            const int32_t* __restrict__ L, int do_unwrap,
+                                                            double out_scale, float* __restrict__ out,
+                                                            const int64_t* __restrict__ out_off) {
+  __shared__ double wave_tot[UW_THREADS / IRA_WAVE];
+  __shared__ double tile_total;
+  const int e = blockIdx.x;
+  const long long n = (long long)L[e] / 2 + 1;
+  const double* p = phase + phase_off[e];
+  float* o = out + out_off[e];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  double carry = 0.0;
+  for (long long base = 0; base < n; base += UW_TILE) {
+    double c[UW_PER], v[UW_PER];
+    const long long i0 = base + (long long)UW_PER * t;
+    double prev = (i0 >= 1 && i0 - 1 < n) ? p[i0 - 1] : 0.0;
+#pragma unroll
+    for (int r = 0; r < UW_PER; ++r) {
+      const long long i = i0 + r;
+      v[r] = (i < n) ? p[i] : 0.0;
+      c[r] = (do_unwrap && i >= 1 && i < n) ? unwrap_correction(prev, v[r]) : 0.0;
+      prev = v[r];
+    }
+    // inclusive prefix within the thread, then across the wave, then across waves
+    c[1] += c[0]; c[2] += c[1]; c[3] += c[2];
+    double incl = c[3];
+#pragma unroll
+    for (int o2 = 1; o2 < 64; o2 <<= 1) {
+      const double dn = __shfl_up(incl, o2, 64);
+      if (lane >= o2) incl += dn;
+    }
+    double excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 0.0;
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    double before = 0.0;
+    for (int w = 0; w < wave; ++w) before += wave_tot[w];
+    const double add = carry + (before + excl);
+#pragma unroll
+    for (int r = 0; r < UW_PER; ++r) {
+      const long long i = i0 + r;
+      if (i < n) o[i] = (float)((v[r] + (c[r] + add)) * out_scale);
+    }
+    if (t == UW_THREADS - 1) tile_total = c[3] + add;
+    __syncthreads();
+    carry = tile_total;
+    __syncthreads();
+  }
+}
+
+// ---- summary statistics ------------------------------------------------------------------------------------------
+// out record (8 doubles): [0] bins in range [1] peak bin (absolute index) [2] peak frequency (float32 value)
+// [3] sum(f*lin) [4] sum(lin) [5] first in-range frequency [6] index nearest 1 kHz [7] magnitude_db there
+constexpr int ST_THREADS = 1024;
+
+__global__ __launch_bounds__(ST_THREADS) void stats_kernel(const float* __restrict__ mag_db,
+                                                           const int64_t* __restrict__ mag_off,
+                                                           const int32_t* __restrict__ L,
+                                                           const double* __restrict__ freq_val, float f_min, float f_max,
+                                                           float probe_hz, double* __restrict__ out) {
+  __shared__ double red[4][ST_THREADS / IRA_WAVE];
+  __shared__ unsigned long long kred[2][ST_THREADS / IRA_WAVE];
+  __shared__ long long lred[ST_THREADS / IRA_WAVE];
+  const int e = blockIdx.x;
+  const long long n = (long long)L[e] / 2 + 1;
+  const float* m = mag_db + mag_off[e];
+  const double val = freq_val[e];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  double cnt = 0.0, sfl = 0.0, sl = 0.0;
+  // argmax of float32 dB with first-max-wins: order-preserving key of the float, then smallest index
+  unsigned long long best = 0ull;
+  // argmin |f - probe| first-min-wins: key = (bits(|d|) << 32 | idx) minimised
+  unsigned long long near = ~0ull;
+  long long first_in = n;
+  for (long long k = t; k < n; k += ST_THREADS) {
+    const float f = (float)((double)k * val);
+    const float d = fabsf(f - probe_hz);
+    const unsigned long long nk = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(uint32_t)k;
+    near = nk < near ? nk : near;
+    if (f >= f_min && f <= f_max) {
+      const float db = m[k];
+      uint32_t u = __float_as_uint(db);
+      u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone map float -> uint
+      const unsigned long long key = ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)k);
+      best = key > best ? key : best;
+      const double lin = pow(10.0, (double)db / 20.0);
+      cnt += 1.0; sfl += (double)f * lin; sl += lin;
+      first_in = k < first_in ? k : first_in;
+    }
+  }
+  cnt = ira::wave_sum(cnt); sfl = ira::wave_sum(sfl); sl = ira::wave_sum(sl);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long ob = __shfl_xor(best, o, 64);
+    best = ob > best ? ob : best;
+    const unsigned long long on = __shfl_xor(near, o, 64);
+    near = on < near ? on : near;
+    const long long of = __shfl_xor(first_in, o, 64);
+    first_in = of < first_in ? of : first_in;
+  }
+  if (lane == 0) {
+    red[0][wave] = cnt; red[1][wave] = sfl; red[2][wave] = sl;
+    kred[0][wave] = best; kred[1][wave] = near; lred[wave] = first_in;
+  }
+  __syncthreads();
+  if (t == 0) {
+    cnt = sfl = sl = 0.0;
+    for (int w = 0; w < ST_THREADS / IRA_WAVE; ++w) {
+      cnt += red[0][w]; sfl += red[1][w]; sl += red[2][w];
+      best = kred[0][w] > best ? kred[0][w] : best;
+      near = kred[1][w] < near ? kred[1][w] : near;
+      first_in = lred[w] < first_in ? lred[w] : first_in;
+    }
+    double* o = out + (int64_t)e * 8;
+    const long long pk = (cnt > 0.0) ? (long long)(0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFull)) : 0;
+    const long long i1k = (long long)(near & 0xFFFFFFFFull);
+    o[0] = cnt;
+    o[1] = (double)pk;
+    o[2] = (double)(float)((double)pk * val);
+    o[3] = sfl; o[4] = sl;
+    o[5] = first_in < n ? (double)(float)((double)first_in * val) : 0.0;
+    o[6] = (double)i1k;
+    o[7] = (double)m[i1k];
+  }
+}
+
+}  // namespace
+
+extern "C" int32_t ira_spectrum_mag_phase(const double* spec_dev, const int64_t* spec_off_dev, const int32_t* L_dev,
+                                          int32_t nb, int32_t max_len, double floor_db, float* mag_db_dev,
+                                          const int64_t* mag_off_dev, double* phase_dev,
+                                          const int64_t* phase_off_dev, void* stream) {
+  IRA_CHECK_PTR(spec_dev); IRA_CHECK_PTR(spec_off_dev); IRA_CHECK_PTR(L_dev); IRA_CHECK_PTR(mag_db_dev);
+  IRA_CHECK_PTR(mag_off_dev);
+  if (phase_dev != nullptr && phase_off_dev == nullptr) return IRA_E_NULL;
+  if (nb <= 0) return nb == 0 ? IRA_OK : IRA_E_SIZE;
+  const double floor_lin = std::pow(10.0, floor_db / 20.0);
+  int blocks = (max_len / 2 + 1 + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  mag_phase_kernel<<<dim3(blocks, nb), 256, 0, (hipStream_t)stream>>>(
+      reinterpret_cast<const cd*>(spec_dev), spec_off_dev, L_dev, floor_lin, mag_db_dev, mag_off_dev, phase_dev,
+      phase_off_dev);
+  IRA_RETURN_LAUNCH();
+}
+
+extern "C" int32_t ira_phase_unwrap(const double* phase_dev, const int64_t* phase_off_dev, const int32_t* L_dev,
+                                    int32_t nb, int32_t do_unwrap, int32_t to_degrees, float* out_dev,
+                                    const int64_t* out_off_dev, void* stream) {
+  IRA_CHECK_PTR(phase_dev); IRA_CHECK_PTR(phase_off_dev); IRA_CHECK_PTR(L_dev); IRA_CHECK_PTR(out_dev);
+  IRA_CHECK_PTR(out_off_dev);
+  if (nb <= 0) return nb == 0 ? IRA_OK : IRA_E_SIZE;
+  const double scale = to_degrees ? (180.0 / kPi) : 1.0;
+  unwrap_kernel<<<nb, UW_THREADS, 0, (hipStream_t)stream>>>(phase_dev, phase_off_dev, L_dev, do_unwrap, scale,
+                                                            out_dev, out_off_dev);
+  IRA_RETURN_LAUNCH();
+}
+
+extern "C" int32_t ira_spectrum_stats(const float* mag_db_dev, const int64_t* mag_off_dev, const int32_t* L_dev,
+                                      int32_t nb, const double* freq_val_dev, double f_min_hz, double f_max_hz,
+                                      double probe_hz, double* out_dev, void* stream) {
+  IRA_CHECK_PTR(mag_db_dev); IRA_CHECK_PTR(mag_off_dev); IRA_CHECK_PTR(L_dev); IRA_CHECK_PTR(freq_val_dev);
+  IRA_CHECK_PTR(out_dev);
+  if (nb <= 0) return nb == 0 ? IRA_OK : IRA_E_SIZE;
+  stats_kernel<<<nb, ST_THREADS, 0, (hipStream_t)stream>>>(mag_db_dev, mag_off_dev, L_dev, freq_val_dev,
+                                                           (float)f_min_hz, (float)f_max_hz, (float)probe_hz, out_dev);
+  IRA_RETURN_LAUNCH();
+}

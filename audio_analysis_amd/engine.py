@@ -208,3 +208,122 @@ class Engine:
                                        _ptr(out), _ptr(d_ooff), _ptr(sel), _ptr(sel_off_dev),
                                        self.stream), "ira_stft_mag_db")
         return out, out_off, cols
+
+    # ------------------------------------------------------------------ a9/a17: arbitrary-length f64 DFTs
+    workspace_budget_bytes = 48 << 30   # cap for the Bluestein work + filter arrays of one chunk
+
+    @staticmethod
+    def log2m_for(length: int) -> int:
+        need = max(2 * int(length) - 1, 16)
+        return max(4, int(need - 1).bit_length())
+
+    def long_tables(self, log2m: int):
+        key = ("long", log2m)
+        if key not in self._tables:
+            n1, n2, m = 1 << ((log2m + 1) // 2), 1 << (log2m // 2), 1 << log2m
+
+            def tab(count, period):
+                ang = -2.0 * np.pi * np.arange(count, dtype=np.float64) / float(period)
+                return self.to_dev(np.stack([np.cos(ang), np.sin(ang)], axis=1))
+
+            self._tables[key] = (tab(n1, n1), tab(n2, n2), tab(n2, m))
+        return self._tables[key]
+
+    def _chunks_by_log2m(self, lengths: np.ndarray):
+        """Group element indices by the FFT size they need, then cut each group to the workspace budget."""
+        l2 = np.array([self.log2m_for(int(v)) for v in lengths], dtype=np.int64)
+        for lm in sorted(set(l2.tolist())):
+            idx = np.nonzero(l2 == lm)[0]
+            per = (16 << lm) * 2                       # work + (worst case) one filter per element
+            step = max(1, int(self.workspace_budget_bytes // per))
+            for i in range(0, idx.size, step):
+                yield int(lm), idx[i : i + step]
+
+    def _filters(self, lengths: np.ndarray, log2m: int):
+        """Chirp-filter spectra for the distinct lengths in `lengths`; returns (bfilt device, bidx int32 host)."""
+        t = self.torch
+        uniq, inv = np.unique(lengths.astype(np.int32), return_inverse=True)
+        t1, t2, tf = self.long_tables(log2m)
+        bf = self.empty(int(uniq.size) * (2 << log2m), t.float64)
+        d_l = self.to_dev(uniq.astype(np.int32))
+        check(self.lib.ira_bluestein_filter(_ptr(d_l), int(uniq.size), log2m, _ptr(t1), _ptr(t2), _ptr(tf), _ptr(bf),
+                                            self.stream), "ira_bluestein_filter")
+        return bf, inv.astype(np.int32)
+
+    def rfft_any(self, x_dev, xoff: np.ndarray, lengths: np.ndarray, use_hann: bool):
+        """
+        Half spectra (complex f64) of x[xoff[e] : xoff[e]+L[e]] (* hanning) for every element.
+        Returns (spec float64 device viewed as (total_bins, 2), spec_off int64 host in complex elements).
+        """
+        t = self.torch
+        n = int(xoff.size)
+        lengths = np.ascontiguousarray(lengths, dtype=np.int32)
+        bins = lengths.astype(np.int64) // 2 + 1
+        spec_off = np.zeros(n, dtype=np.int64)
+        if n > 1:
+            spec_off[1:] = np.cumsum(bins[:-1])
+        spec = self.empty(int(bins.sum()) * 2, t.float64)
+        for lm, idx in self._chunks_by_log2m(lengths):
+            t1, t2, tf = self.long_tables(lm)
+            bf, bidx = self._filters(lengths[idx], lm)
+            work = self.empty(int(idx.size) * (2 << lm), t.float64)
+            d_xo, d_l = self.to_dev(np.ascontiguousarray(xoff[idx], dtype=np.int64)), self.to_dev(lengths[idx])
+            d_bi, d_so = self.to_dev(bidx), self.to_dev(spec_off[idx])
+            check(self.lib.ira_rfft_any(_ptr(x_dev), _ptr(d_xo), _ptr(d_l), int(idx.size), 1 if use_hann else 0, lm,
+                                        _ptr(t1), _ptr(t2), _ptr(tf), _ptr(bf), _ptr(d_bi), _ptr(work), _ptr(spec),
+                                        _ptr(d_so), self.stream), "ira_rfft_any")
+        return spec, spec_off
+
+    def band_irfft(self, spec_dev, spec_off: np.ndarray, lengths: np.ndarray, band_params: np.ndarray,
+                   freq_val: np.ndarray, y_dev, y1_off: np.ndarray, y2_off: np.ndarray):
+        """Masked inverse transforms, two bands per element (see ira_band_irfft in include/ira.h)."""
+        t = self.torch
+        lengths = np.ascontiguousarray(lengths, dtype=np.int32)
+        for lm, idx in self._chunks_by_log2m(lengths):
+            t1, t2, tf = self.long_tables(lm)
+            bf, bidx = self._filters(lengths[idx], lm)
+            work = self.empty(int(idx.size) * (2 << lm), t.float64)
+            d_so, d_l = self.to_dev(np.ascontiguousarray(spec_off[idx], np.int64)), self.to_dev(lengths[idx])
+            d_bp = self.to_dev(np.ascontiguousarray(band_params[idx], dtype=np.float64))
+            d_fv = self.to_dev(np.ascontiguousarray(freq_val[idx], dtype=np.float64))
+            d_bi = self.to_dev(bidx)
+            d_y1 = self.to_dev(np.ascontiguousarray(y1_off[idx], np.int64))
+            d_y2 = self.to_dev(np.ascontiguousarray(y2_off[idx], np.int64))
+            check(self.lib.ira_band_irfft(_ptr(spec_dev), _ptr(d_so), _ptr(d_l), int(idx.size), _ptr(d_bp), _ptr(d_fv),
+                                          lm, _ptr(t1), _ptr(t2), _ptr(tf), _ptr(bf), _ptr(d_bi), _ptr(work),
+                                          _ptr(y_dev), _ptr(d_y1), _ptr(d_y2), self.stream), "ira_band_irfft")
+
+    def spectrum_mag_phase(self, spec_dev, spec_off: np.ndarray, lengths: np.ndarray, floor_db: float,
+                           want_phase: bool):
+        """mag_db (f32) [+ wrapped phase f64] laid out at the same per-element bin offsets as the spectra."""
+        t = self.torch
+        n = int(spec_off.size)
+        lengths = np.ascontiguousarray(lengths, dtype=np.int32)
+        total = int((lengths.astype(np.int64) // 2 + 1).sum())
+        mag = self.empty(total, t.float32)
+        ph = self.empty(total, t.float64) if want_phase else None
+        d_so, d_l = self.to_dev(spec_off), self.to_dev(lengths)
+        check(self.lib.ira_spectrum_mag_phase(_ptr(spec_dev), _ptr(d_so), _ptr(d_l), n, int(lengths.max()),
+                                              float(floor_db), _ptr(mag), _ptr(d_so), _ptr(ph), _ptr(d_so),
+                                              self.stream), "ira_spectrum_mag_phase")
+        return mag, ph
+
+    def phase_unwrap(self, phase_dev, off: np.ndarray, lengths: np.ndarray, unwrap: bool, degrees: bool):
+        t = self.torch
+        lengths = np.ascontiguousarray(lengths, dtype=np.int32)
+        out = self.empty(int((lengths.astype(np.int64) // 2 + 1).sum()), t.float32)
+        d_o, d_l = self.to_dev(off), self.to_dev(lengths)
+        check(self.lib.ira_phase_unwrap(_ptr(phase_dev), _ptr(d_o), _ptr(d_l), int(off.size), 1 if unwrap else 0,
+                                        1 if degrees else 0, _ptr(out), _ptr(d_o), self.stream), "ira_phase_unwrap")
+        return out
+
+    def spectrum_stats(self, mag_dev, off: np.ndarray, lengths: np.ndarray, freq_val: np.ndarray, f_min: float,
+                       f_max: float, probe_hz: float = 1000.0):
+        t = self.torch
+        n = int(off.size)
+        lengths = np.ascontiguousarray(lengths, dtype=np.int32)
+        out = self.empty(n * 8, t.float64)
+        d_o, d_l, d_fv = self.to_dev(off), self.to_dev(lengths), self.to_dev(np.ascontiguousarray(freq_val, np.float64))
+        check(self.lib.ira_spectrum_stats(_ptr(mag_dev), _ptr(d_o), _ptr(d_l), n, _ptr(d_fv), float(f_min),
+                                          float(f_max), float(probe_hz), _ptr(out), self.stream), "ira_spectrum_stats")
+        return out[: n * 8].view(n, 8)

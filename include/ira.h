@@ -103,6 +103,62 @@ int32_t ira_stft_mag_db(const float* x_dev, const int64_t* off_dev, const int32_
                         double floor_db, float* out_dev, const int64_t* out_off_dev,
                         const int32_t* frame_sel_dev, const int64_t* sel_off_dev, void* stream);
 
+/* ---- a9/a17: arbitrary-length float64 DFTs (Bluestein over a four-step power-of-two FFT) ---------------
+ * Common arguments: log2m with M = 2^log2m >= 2*max(L) - 1 (4 <= log2m <= 22); three caller-provided
+ * complex-f64 tables for M = N1*N2, N1 = 2^ceil(log2m/2), N2 = 2^floor(log2m/2):
+ *   t1_dev[k] = exp(-2 pi i k/N1), k < N1;  t2_dev[k] = exp(-2 pi i k/N2), k < N2;
+ *   tf_dev[k] = exp(-2 pi i k/M),  k < N2.
+ * work_dev: nb * M complex f64 of scratch.  bfilt_dev: chirp-filter spectra built by ira_bluestein_filter,
+ * M complex f64 each; bidx_dev[e] selects the filter (the one built for length L[e]) of element e. */
+
+/* bfilt_dev[j] = FFT_M of the Bluestein chirp filter for length L_dev[j], j < nfilt. */
+int32_t ira_bluestein_filter(const int32_t* L_dev, int32_t nfilt, int32_t log2m, const void* t1_dev,
+                             const void* t2_dev, const void* tf_dev, double* bfilt_dev, void* stream);
+
+/* spec_out[e][k] = sum_n x[xoff[e]+n] * (hanning(L[e])[n] | 1) * exp(-2 pi i n k / L[e]),  k = 0..L[e]/2,
+ * complex f64 at spec_out_dev + 2*spec_off_dev[e] doubles.  Replaces np.fft.rfft(x * w) of arbitrary
+ * length at reference analyse/frequency_response.py:204-213, analyse/filterplot.py:145-152 and the
+ * forward transform of analyse/rt60bands.py:172. */
+int32_t ira_rfft_any(const float* x_dev, const int64_t* xoff_dev, const int32_t* L_dev, int32_t nb,
+                     int32_t use_hann, int32_t log2m, const void* t1_dev, const void* t2_dev,
+                     const void* tf_dev, const double* bfilt_dev, const int32_t* bidx_dev,
+                     double* work_dev, double* spec_out_dev, const int64_t* spec_off_dev, void* stream);
+
+/* Band filter bank: element e takes the half spectrum at spec_dev + 2*spec_off_dev[e] (length L[e]/2+1),
+ * multiplies it by TWO real masks (band_params_dev: 2 records of IRA_BAND_DOUBLES doubles per element:
+ * [0] kind 0 none/1 low-pass/2 high-pass/3 band-pass, [1] hp ramp start, [2] hp ramp end (pass edge),
+ * [3] lp ramp start (pass edge), [4] lp ramp end; masks are evaluated in float32 on the float32 axis
+ * float32(k*freq_val[e]) exactly as reference analyse/rt60bands.py:116-167) and inverse-transforms both
+ * at once (y1 + i*y2), writing float32 signals of length L[e] at y_dev + y1_off[e] and y_dev + y2_off[e]
+ * (y2_off[e] < 0: no second band).  Replaces _apply_fft_mask, reference analyse/rt60bands.py:170-175. */
+#define IRA_BAND_DOUBLES 8
+int32_t ira_band_irfft(const double* spec_dev, const int64_t* spec_off_dev, const int32_t* L_dev,
+                       int32_t nb, const double* band_params_dev, const double* freq_val_dev,
+                       int32_t log2m, const void* t1_dev, const void* t2_dev, const void* tf_dev,
+                       const double* bfilt_dev, const int32_t* bidx_dev, double* work_dev, float* y_dev,
+                       const int64_t* y1_off_dev, const int64_t* y2_off_dev, void* stream);
+
+/* ---- a17/a18: spectrum post-processing -------------------------------------------------------------------
+ * mag_db[e][k] = float32(20 log10(max(|X|, 10^(floor_db/20)))), optional phase[e][k] = atan2(im, re) (f64).
+ * Reference analyse/frequency_response.py:213-218, analyse/filterplot.py:152-160. */
+int32_t ira_spectrum_mag_phase(const double* spec_dev, const int64_t* spec_off_dev, const int32_t* L_dev,
+                               int32_t nb, int32_t max_len, double floor_db, float* mag_db_dev,
+                               const int64_t* mag_off_dev, double* phase_dev,
+                               const int64_t* phase_off_dev, void* stream);
+
+/* numpy.unwrap (optional) + rad2deg (optional) -> float32.  Reference analyse/filterplot.py:162-168. */
+int32_t ira_phase_unwrap(const double* phase_dev, const int64_t* phase_off_dev, const int32_t* L_dev,
+                         int32_t nb, int32_t do_unwrap, int32_t to_degrees, float* out_dev,
+                         const int64_t* out_off_dev, void* stream);
+
+/* Statistics over bins with f_min <= float32(k*freq_val[e]) <= f_max (float32 compares): out_dev[e*8..]:
+ * [0] bin count [1] argmax bin of mag_db (first max) [2] its frequency [3] sum f*10^(dB/20) [4] sum 10^(dB/20)
+ * [5] first in-range frequency [6] argmin |f - probe_hz| over ALL bins (first min) [7] mag_db there.
+ * Reference analyse/frequency_response.py:238-260, analyse/filterplot.py:173-191. */
+int32_t ira_spectrum_stats(const float* mag_db_dev, const int64_t* mag_off_dev, const int32_t* L_dev,
+                           int32_t nb, const double* freq_val_dev, double f_min_hz, double f_max_hz,
+                           double probe_hz, double* out_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,134 @@
+"""GPU parity: arbitrary-length float64 rFFT (Bluestein), fr / filter modules, RT60 band filter bank."""
+import numpy as np
+import pytest
+
+from oracle import ira_oracle as O
+
+pytestmark = pytest.mark.gpu
+SR = 48000
+
+
+def _rel(a, b):
+    return abs(a - b) / max(abs(b), 1e-300)
+
+
+def _spec(eng, x, L_list, hann):
+    b = eng.upload([x])
+    offs = np.zeros(len(L_list), dtype=np.int64)
+    spec, off = eng.rfft_any(b.x, offs, np.array(L_list, np.int32), hann)
+    h = spec.cpu().numpy()
+    return [h[2 * o : 2 * (o + L // 2 + 1)].reshape(-1, 2) for o, L in zip(off, L_list)]
+
+
+def test_rfft_any_lengths():
+    """Awkward lengths (prime, 2*prime, power of two, 2^a 3^b 5^c, tiny) against numpy.fft.rfft in float64."""
+    from audio_analysis_amd.engine import get_engine
+    eng = get_engine()
+    rng = np.random.default_rng(11)
+    x = (rng.standard_normal(70000) * np.exp(-np.arange(70000) / 9000.0)).astype(np.float32)
+    lengths = [32, 33, 97, 1000, 1024, 4099, 23003, 2 * 37 * 311, 65536, 69997, 48000]
+    for hann in (False, True):
+        got = _spec(eng, x, lengths, hann)
+        for L, g in zip(lengths, got):
+            seg = x[:L].astype(np.float64)
+            if hann:
+                seg = seg * np.hanning(L)
+            ref = np.fft.rfft(seg)
+            err = np.max(np.abs(g[:, 0] + 1j * g[:, 1] - ref)) / np.max(np.abs(ref))
+            assert err < 5e-14, (L, hann, err)
+            assert g[0, 1] == 0.0
+
+
+@pytest.mark.parametrize("tag,inp", [("xa", "xa"), ("xc", "xc"), ("xd", "xd"), ("xa_sel", "xa"), ("xa_rect", "xa")])
+def test_fr_and_filter_vs_golden(golden, tag, inp):
+    from audio_analysis_amd.analyse import filterplot, frequency_response as fr
+    g, c, _ = golden
+    x = g[f"in/{inp}"]
+    cs = c[f"{tag}/fr"]
+    r = fr.analyse_frequency_response_for_channel(x, SR, "mono", fr.FrequencyResponseAnalysisSettings(**cs["kw"]))
+    assert (r.analysis_start_sample_index, r.analysis_length_samples) == (cs["start"], cs["length"])
+    ref = g[f"{tag}/fr/mag_db"]
+    assert r.magnitude_db.shape == ref.shape and r.magnitude_db.dtype == np.float32
+    np.testing.assert_allclose(r.magnitude_db, ref, rtol=0, atol=2e-5)      # float64 FFT: float32 rounding only
+    assert r.peak_frequency_hz == cs["peak"]                                  # argmax bin: exact
+    assert _rel(r.spectral_centroid_hz, cs["centroid"]) < 1e-9
+    assert fr.summarise_frequency_response_results_text([r]) == cs["summary"]
+    np.testing.assert_array_equal(r.frequency_hz, np.fft.rfftfreq(cs["length"], 1 / 48000.0).astype(np.float32))
+
+    cs = c[f"{tag}/filter"]
+    r = filterplot.analyse_filter_response_for_channel(x, SR, "mono", filterplot.FilterAnalysisSettings(**cs["kw"]))
+    assert (r.analysis_start_sample_index, r.analysis_length_samples) == (cs["start"], cs["length"])
+    np.testing.assert_allclose(r.magnitude_db, g[f"{tag}/filter/mag_db"], rtol=0, atol=2e-5)
+    assert r.peak_frequency_hz == cs["peak"]
+    assert abs(r.magnitude_at_1khz_db - cs["mag1k"]) < 2e-5
+    ph_ref = g[f"{tag}/filter/phase"]
+    # unwrapped phase in degrees (float32, values up to ~1e6 deg): any flipped 2*pi decision would show as 360
+    assert np.max(np.abs(r.phase_response - ph_ref) / np.maximum(1.0, np.abs(ph_ref))) < 1e-6
+    assert filterplot.summarise_filter_response_results_text([r]) == cs["summary"]
+
+
+def test_fr_smoothing_and_radians(golden):
+    from audio_analysis_amd.analyse import filterplot, frequency_response as fr
+    g, c, _ = golden
+    r = fr.analyse_frequency_response_for_channel(g["in/xa"], SR, "m",
+                                                  fr.FrequencyResponseAnalysisSettings(smoothing_log_bins=9))
+    np.testing.assert_allclose(r.magnitude_db, g["xa_smooth/fr/mag_db"], rtol=0, atol=2e-5)
+    assert r.peak_frequency_hz == c["xa_smooth/fr"]["peak"]
+    assert _rel(r.spectral_centroid_hz, c["xa_smooth/fr"]["centroid"]) < 1e-7
+    r = filterplot.analyse_filter_response_for_channel(
+        g["in/xa"], SR, "m", filterplot.FilterAnalysisSettings(phase_mode="radians", unwrap_phase=False))
+    ref = g["xa_rad/filter/phase"]
+    d = np.abs(r.phase_response - ref)
+    d = np.minimum(d, np.abs(d - 2 * np.pi))          # +pi / -pi are the same angle
+    assert np.max(d) < 1e-5
+    with pytest.raises(ValueError):
+        fr.analyse_frequency_response_for_channel(g["in/xa"][:260], SR, "m",
+                                                  fr.FrequencyResponseAnalysisSettings(trim_to_peak=True))
+
+
+def test_band_tables_exact(golden):
+    from audio_analysis_amd.analyse import rt60bands as rb
+    _, c, _ = golden
+    for mode in ("three", "octave", "third"):
+        got = rb._build_band_definitions(rb.Rt60BandsAnalysisSettings(band_mode=mode), SR)
+        want = c[f"xb/rt60bands/{mode}"]["bands"]
+        assert [[b.name, b.centre_hz, b.kind, b.low_edge_hz, b.high_edge_hz] for b in got] == want
+    with pytest.raises(ValueError):
+        rb._build_band_definitions(rb.Rt60BandsAnalysisSettings(band_mode="nope"), SR)
+
+
+@pytest.mark.parametrize("key", ["xb/rt60bands/three", "xb/rt60bands/octave", "xb/rt60bands/third",
+                                 "xd/rt60bands/three", "xd/rt60bands/octave", "xd/rt60bands/third",
+                                 "xb16/rt60bands/third", "xc/rt60bands/octave", "xb_ign/rt60bands/three"])
+def test_rt60_bands_vs_golden(golden, key):
+    from audio_analysis_amd.analyse import decay, rt60bands as rb
+    g, c, _ = golden
+    case = c[key]
+    tag, _, mode = key.split("/")
+    kw = dict(case["kw"])
+    ign = kw.pop("ignore_leading_seconds", 0.0)
+    s = rb.Rt60BandsAnalysisSettings(band_mode=mode, decay_settings=decay.DecayAnalysisSettings(ignore_leading_seconds=ign), **kw)
+    r = rb.analyse_rt60_bands_for_channel(g[f"in/{tag.split('_')[0]}"], SR, "mono", s)
+    worst = 0.0
+    for name, m in r.band_metrics_by_name.items():
+        want = case["metrics"][name]
+        for got_v, want_v in zip((m.rt60_t30_seconds, m.rt60_t20_seconds, m.edt_seconds), want):
+            assert (got_v is None) == (want_v is None), (name, got_v, want_v)
+            if want_v is not None:
+                worst = max(worst, _rel(got_v, want_v))
+    assert worst < 1e-4, worst            # north_star tolerance for RT60 values
+    assert rb.summarise_rt60_bands_results_text([r], s.include_t20, s.include_edt) == case["summary"]
+
+
+def test_rt60_bands_batch_vs_oracle():
+    from audio_analysis_amd.analyse import rt60bands as rb
+    from audio_analysis_amd.synth import synth_ir
+    chans = [synth_ir(i, 0, 60000 + 7 * i) for i in range(3)]
+    res = rb.analyse_rt60_bands_batch(chans, SR, ["a", "b", "c"], rb.Rt60BandsAnalysisSettings(band_mode="octave"))
+    for x, r in zip(chans, res):
+        o = O.analyse_rt60_bands(x, SR, band_mode="octave")
+        for name, m in r.band_metrics_by_name.items():
+            w = o["metrics"][name]["t30"]
+            assert (m.rt60_t30_seconds is None) == (w is None)
+            if w is not None:
+                assert _rel(m.rt60_t30_seconds, w) < 1e-4, (name, m.rt60_t30_seconds, w)
