@@ -177,3 +177,57 @@ def render_rt60_bands(results, settings, plot_settings, title, path, show):
         ax.set_ylim(*plot_settings.ylim_seconds)
     ax.grid(True, linestyle=":"); ax.legend(loc="best")
     finish(fig, path, show)
+
+
+def render_waterfall(result, settings, plot_settings, title, path, show):
+    if path is None and not show:
+        return
+    plt = _plt()
+    f, t, z = result.frequency_hz, result.slice_times_seconds, result.slice_magnitude_rel_db
+    if str(plot_settings.style).lower() == "2d":
+        fig, ax = new_axes(title)
+        for i in range(z.shape[0]):
+            ax.plot(f, z[i] - i * plot_settings.ridge_offset_db, linewidth=0.8)
+        _log_hz(ax, float(f[0]), float(f[-1]), "x")
+        ax.set_xlabel("Frequency (Hz)"); ax.set_ylabel("Relative level (dB, offset per slice)")
+    else:
+        from mpl_toolkits.mplot3d import Axes3D  # noqa: F401
+        fig = plt.figure(figsize=DEFAULT_FIGURE_SIZE, dpi=DEFAULT_DPI)
+        ax = fig.add_subplot(111, projection="3d")
+        ax.set_title(title)
+        lf = np.log10(f.astype(np.float64))
+        for i in range(z.shape[0] - 1, -1, -1):
+            ax.plot(lf, np.full_like(lf, t[i]), z[i], linewidth=0.7)
+        ticks = [v for v in (20, 50, 100, 200, 500, 1000, 2000, 5000, 10000, 20000) if f[0] <= v <= f[-1]]
+        ax.set_xticks(np.log10(ticks)); ax.set_xticklabels([f"{int(v/1000)}k" if v >= 1000 else str(v) for v in ticks])
+        ax.set_xlabel("Frequency (Hz)"); ax.set_ylabel("Time (s)"); ax.set_zlabel("Relative level (dB)")
+        ax.view_init(elev=plot_settings.elev_deg, azim=plot_settings.azim_deg)
+        if plot_settings.zlim_db is not None:
+            ax.set_zlim(*plot_settings.zlim_db)
+    finish(fig, path, show)
+
+
+def render_modal_cloud(result, settings, plot_settings, title, path, show):
+    if path is None and not show:
+        return
+    fig, ax = new_axes(title)
+    nyq = 0.5 * result.sample_rate_hz
+    lo = float(np.clip(settings.f_min_hz, 1.0, nyq)); hi = float(np.clip(settings.f_max_hz, lo, nyq))
+    _log_hz(ax, lo, hi, "x")
+    ax.set_xlabel("Frequency (Hz)"); ax.set_ylabel(f"RT60 estimate (s) [{result.metric.upper()}]")
+    if not result.points:
+        ax.text(0.5, 0.5, "No valid points (insufficient decay range).", transform=ax.transAxes, ha="center")
+    else:
+        fr = np.array([p.centre_hz for p in result.points]); rt = np.array([p.rt60_seconds for p in result.points])
+        ax.scatter(fr, rt, s=12, alpha=0.85, label=f"{result.channel_name} ({len(result.points)} pts)")
+        if plot_settings.show_median_curve and fr.size >= 8:
+            lf = np.log2(fr); half = 0.5 * max(0.01, plot_settings.median_octave_window)
+            keep = [(fr[i], float(np.median(rt[(lf >= lf[i] - half) & (lf <= lf[i] + half)])))
+                    for i in range(fr.size) if int(np.sum((lf >= lf[i] - half) & (lf <= lf[i] + half))) >= 3]
+            if len(keep) >= 4:
+                ax.plot([k[0] for k in keep], [k[1] for k in keep], alpha=0.9, label=f"{result.channel_name} median")
+        ax.legend(loc="best")
+    if plot_settings.ylim_seconds is not None:
+        ax.set_ylim(*plot_settings.ylim_seconds)
+    ax.grid(True, which="both", linestyle=":")
+    finish(fig, path, show)

@@ -27,6 +27,7 @@ SOURCES = {
     "ira_stft.hip": [],
     "ira_fftlong.hip": [],
     "ira_spectrum.hip": ["-ffp-contract=off"],
+    "ira_modal.hip": ["-ffp-contract=off"],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 

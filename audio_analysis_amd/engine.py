@@ -327,3 +327,40 @@ class Engine:
         check(self.lib.ira_spectrum_stats(_ptr(mag_dev), _ptr(d_o), _ptr(d_l), n, _ptr(d_fv), float(f_min),
                                           float(f_max), float(probe_hz), _ptr(out), self.stream), "ira_spectrum_stats")
         return out[: n * 8].view(n, 8)
+
+    # ------------------------------------------------------------------ a14 / a15
+    def waterfall_rel(self, mag_dev, mag_off: np.ndarray, nslices: np.ndarray, k_lo: int, nsel: int,
+                      slice_max: bool, dyn_db: float):
+        """(S_e, nsel) relative-dB slices per element; returns (out f32 device, out_off host)."""
+        t = self.torch
+        n = int(mag_off.size)
+        nslices = np.ascontiguousarray(nslices, dtype=np.int32)
+        sizes = nslices.astype(np.int64) * int(nsel)
+        out_off = np.zeros(n, dtype=np.int64)
+        if n > 1:
+            out_off[1:] = np.cumsum(sizes[:-1])
+        out = self.empty(int(sizes.sum()), t.float32)
+        d_mo, d_ns, d_oo = self.to_dev(mag_off), self.to_dev(nslices), self.to_dev(out_off)
+        check(self.lib.ira_waterfall_rel(_ptr(mag_dev), _ptr(d_mo), _ptr(d_ns), n, int(k_lo), int(nsel),
+                                         1 if slice_max else 0, float(dyn_db), _ptr(out), _ptr(d_oo), self.stream),
+              "ira_waterfall_rel")
+        return out, out_off
+
+    def logbin_aggregate(self, mag_dev, mag_off: np.ndarray, nframes: np.ndarray, k_base: int, first: np.ndarray,
+                         count: np.ndarray):
+        """(nbins, T_e) float32 log-bin curves per element; returns (out device, out_off host)."""
+        t = self.torch
+        n = int(mag_off.size)
+        nbins = int(first.size)
+        nframes = np.ascontiguousarray(nframes, dtype=np.int32)
+        sizes = nframes.astype(np.int64) * nbins
+        out_off = np.zeros(n, dtype=np.int64)
+        if n > 1:
+            out_off[1:] = np.cumsum(sizes[:-1])
+        out = self.empty(int(sizes.sum()), t.float32)
+        d_mo, d_nf, d_oo = self.to_dev(mag_off), self.to_dev(nframes), self.to_dev(out_off)
+        d_f, d_c = self.to_dev(first.astype(np.int32)), self.to_dev(count.astype(np.int32))
+        check(self.lib.ira_logbin_aggregate(_ptr(mag_dev), _ptr(d_mo), _ptr(d_nf), n, int(nframes.max()), int(k_base),
+                                            _ptr(d_f), _ptr(d_c), nbins, _ptr(out), _ptr(d_oo), self.stream),
+              "ira_logbin_aggregate")
+        return out, out_off

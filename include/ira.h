@@ -159,6 +159,25 @@ int32_t ira_spectrum_stats(const float* mag_db_dev, const int64_t* mag_off_dev, 
                            int32_t nb, const double* freq_val_dev, double f_min_hz, double f_max_hz,
                            double probe_hz, double* out_dev, void* stream);
 
+/* ---- a14: waterfall slice normalisation ----------------------------------------------------------------
+ * mag[e] is the (F, S_e) STFT dB matrix of the S_e selected frames (ira_stft_mag_db with frame_sel_dev);
+ * out[e] is (S_e, nsel) float32: clip(mag[k_lo+k, s] - ref, -dyn_db, 0), ref = max over the selected block
+ * (slice_max = 0) or over each slice (slice_max = 1), float32 arithmetic.
+ * Replaces _build_rel_db_slices, reference analyse/waterfall.py:289-341 (smoothing off). */
+int32_t ira_waterfall_rel(const float* mag_dev, const int64_t* mag_off_dev, const int32_t* nslices_dev,
+                          int32_t nb, int32_t k_lo, int32_t nsel, int32_t slice_max, double dyn_db,
+                          float* out_dev, const int64_t* out_off_dev, void* stream);
+
+/* ---- a15: modal-cloud log-frequency aggregation -----------------------------------------------------------
+ * mag[e] is the (F, T_e) STFT dB matrix; for log bin b rows k_base+first[b] .. +count[b]-1 are averaged as
+ * linear magnitude 10^(dB/20) in float64 (rows added in order), then 20 log10(max(mean, 1e-30)) -> float32;
+ * count[b] == 0 gives a NaN row.  out[e] is (nbins, T_e).
+ * Replaces _aggregate_to_log_bins, reference analyse/modalcloud.py:176-207. */
+int32_t ira_logbin_aggregate(const float* mag_dev, const int64_t* mag_off_dev, const int32_t* nframes_dev,
+                             int32_t nb, int32_t max_frames, int32_t k_base, const int32_t* first_dev,
+                             const int32_t* count_dev, int32_t nbins, float* out_dev,
+                             const int64_t* out_off_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
