@@ -231,3 +231,31 @@ def render_modal_cloud(result, settings, plot_settings, title, path, show):
         ax.set_ylim(*plot_settings.ylim_seconds)
     ax.grid(True, which="both", linestyle=":")
     finish(fig, path, show)
+
+
+def render_zplane(result, settings, plot_settings, title, path, show, rt60_of_radius):
+    if path is None and not show:
+        return
+    fig, ax = new_axes(title, size=(7.5, 7.5))
+    if plot_settings.show_axes:
+        ax.axhline(0.0, linewidth=1.0); ax.axvline(0.0, linewidth=1.0)
+    if plot_settings.show_unit_circle:
+        th = np.linspace(0.0, 2.0 * np.pi, 512)
+        ax.plot(np.cos(th), np.sin(th), linestyle="--", linewidth=1.0)
+    if result.poles.size:
+        ax.scatter(result.poles.real, result.poles.imag, marker="x", s=30, label="Poles")
+    if result.zeros is not None and result.zeros.size:
+        ax.scatter(result.zeros.real, result.zeros.imag, marker="o", s=18, facecolors="none", label="Zeros")
+    lim = float(plot_settings.limit_radius)
+    ax.set_aspect("equal", adjustable="box"); ax.set_xlim(-lim, lim); ax.set_ylim(-lim, lim)
+    ax.set_xlabel("Re{z}"); ax.set_ylabel("Im{z}"); ax.legend(loc="upper right")
+    if plot_settings.annotate_stats and result.poles.size:
+        rad = np.abs(result.poles)
+        mx, md = float(np.max(rad)), float(np.median(rad))
+        ax.text(0.02, 0.02,
+                f"AR order: {int(settings.ar_order)}\npoles: {result.poles.size}\n"
+                f"unstable (|p|>=1): {int(np.sum(rad >= 1.0))}\nradius median: {md:.6f}\nradius max: {mx:.6f}\n"
+                f"RT60~ (median r): {rt60_of_radius(min(md, 0.999999), result.sample_rate_hz):.3f} s\n"
+                f"RT60~ (max r): {rt60_of_radius(min(mx, 0.999999), result.sample_rate_hz):.3f} s",
+                transform=ax.transAxes, fontsize=9, va="bottom", ha="left")
+    finish(fig, path, show)

@@ -28,6 +28,7 @@ SOURCES = {
     "ira_fftlong.hip": [],
     "ira_spectrum.hip": ["-ffp-contract=off"],
     "ira_modal.hip": ["-ffp-contract=off"],
+    "ira_ar.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 

@@ -1,0 +1,430 @@
+// a19-a21: z-plane AR pole fit (reference analyse/zplane.py:83-158).
+//
+// The reference solves the covariance-method least squares  min || A a + x ||,  A[n,k] = x[n-k] (n = p..N-1,
+// k = 1..p) with an SVD (numpy.linalg.lstsq) over an (N-p) x p matrix -- 4 s of LAPACK per 10 s channel.
+// Here:
+//   1. ar_gram_kernel   G = A^T A and r = A^T y as a dense float64 contraction on the matrix cores
+//                       (v_mfma_f64_16x16x4_f64).  A is an implicit Hankel view of the signal: every operand
+//                       fragment is a shifted window of the LDS-staged samples, nothing is materialised.
+//   2. ar_solve_kernel  deterministic reduction of the per-chunk partial Grams, optional ridge, Cholesky,
+//                       two triangular solves -> a[0..p] (a[0] = 1).
+//   3. poly_roots_kernel  all roots of the monic polynomial by Aberth-Ehrlich iteration in float64
+//                       (numpy.roots uses companion-matrix eigenvalues; root ORDER is unspecified there, so
+//                       parity is on the sorted set and on the radius statistics).
+//   4. fir_numerator_kernel  b[n] = sum_k a[k] h[n-k], n <= Q   (zplane.py:123-142, --zeros option).
+// Float32 is not an option for G: on coloured IRs a float32 Gram loses the poles entirely (SURVEY.md
+// section 7, hard part 1).
+#include <cmath>
+
+#include "ira_common.h"
+
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int GR_KC = 1024;       // rows (samples n) staged in LDS per tile
+constexpr int GR_CHUNK = 16384;   // rows per workgroup (one wave)
+constexpr int GR_GROUP = 64;      // a workgroup accumulates one 64 x 64 block of G
+constexpr int GR_PART = GR_GROUP * GR_GROUP + GR_GROUP;   // doubles per partial record (block + rhs slice)
+constexpr int GR_MAX_P = 1024;
+
+__host__ __device__ inline int groups_side(int p) { return (p + GR_GROUP - 1) / GR_GROUP; }
+__host__ __device__ inline int groups_total(int p) { const int g = groups_side(p); return g * (g + 1) / 2; }
+
+// lower-triangular enumeration: id -> (gi >= gj)
+__device__ __forceinline__ void group_from_id(int id, int& gi, int& gj) {
+  gi = 0;
+  while ((gi + 1) * (gi + 2) / 2 <= id) ++gi;
+  gj = id - gi * (gi + 1) / 2;
+}
+
+template <bool DIAG>
+__device__ __forceinline__ void gram_tile_loop(const double* __restrict__ lds, long long t0, long long origin,
+                                               long long n_end, int kc, int gi, int gj, d4 (&acc)[4][4],
+                                               double& rhs) {
+  const int lane = threadIdx.x;
+  const int i = lane & 15, kk = lane >> 4;
+  for (int ks = 0; ks < kc; ks += 4) {
+    const long long n = t0 + ks + kk;          // row of this lane's operand element
+    const bool valid = n < n_end;
+    const long long base = (n - 1 - i) - origin;   // LDS index of s[n-1-i]
+    double fa[4], fb[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const double v = lds[base - (GR_GROUP * gi + 16 * a)];
+      fa[a] = valid ? v : 0.0;
+    }
+    if (DIAG) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) fb[b] = fa[b];
+    } else {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const double v = lds[base - (GR_GROUP * gj + 16 * b)];
+        fb[b] = valid ? v : 0.0;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        if (DIAG && b > a) continue;
+        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+      }
+    }
+    if (DIAG) {
+      // rhs slice r[64 gi + lane] = - sum_n s[n - 1 - j'] s[n]
+      const long long jb = (long long)GR_GROUP * gi + lane;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const long long nn = t0 + ks + q;
+        if (nn < n_end) {
+          const double sn = lds[nn - origin];
+          rhs -= lds[nn - 1 - jb - origin] * sn;
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void ar_gram_kernel(const float* __restrict__ x, const double* __restrict__ x64,
+                                                     const int64_t* __restrict__ xoff,
+                                                     const int32_t* __restrict__ nlen,
+                                                     const double* __restrict__ divisor, int p, int nchunks_max,
+                                                     double* __restrict__ part) {
+  __shared__ double lds[GR_KC + GR_MAX_P + 8];
+  const int e = blockIdx.z;
+  const int chunk = blockIdx.x;
+  const long long N = nlen[e];
+  const long long row0 = (long long)p + (long long)chunk * GR_CHUNK;
+  if (row0 >= N) return;
+  const long long n_end = (row0 + GR_CHUNK < N) ? row0 + GR_CHUNK : N;
+  int gi, gj;
+  group_from_id(blockIdx.y, gi, gj);
+  const int halo = GR_GROUP * groups_side(p) + 1;   // largest lag touched (padded) + 1
+  const float* xs = x ? x + xoff[e] : nullptr;
+  const double* xd = x64 ? x64 + xoff[e] : nullptr;
+  const double div = divisor ? divisor[e] : 1.0;
+  const int lane = threadIdx.x;
+
+  d4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+  double rhs = 0.0;
+
+  for (long long t0 = row0; t0 < n_end; t0 += GR_KC) {
+    const long long origin = t0 - halo;
+    const int kc = (int)((n_end - t0 < GR_KC) ? n_end - t0 : GR_KC);
+    const int kc4 = (kc + 3) & ~3;
+    __syncthreads();
+    for (int m = lane; m < halo + kc4; m += 64) {
+      const long long idx = origin + m;
+      lds[m] = (idx >= 0 && idx < N) ? (xd ? xd[idx] : (double)xs[idx]) / div : 0.0;
+    }
+    __syncthreads();
+    if (gi == gj) gram_tile_loop<true>(lds, t0, origin, n_end, kc4, gi, gj, acc, rhs);
+    else gram_tile_loop<false>(lds, t0, origin, n_end, kc4, gi, gj, acc, rhs);
+  }
+
+  // D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+  double* out = part + (((long long)e * nchunks_max + chunk) * groups_total(p) + blockIdx.y) * GR_PART;
+  const int col = lane & 15, rq = lane >> 4;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if (gi == gj && b > a) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rq + 4 * r;
+        out[(16 * a + row) * GR_GROUP + 16 * b + col] = acc[a][b][r];
+      }
+    }
+  }
+  if (gi == gj) out[GR_GROUP * GR_GROUP + lane] = rhs;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Reduction of partials + Cholesky + solves.  One 256-thread workgroup per element.
+// The p x p matrix lives in LDS when it fits (p <= 128), otherwise in caller-provided global scratch.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int SV_THREADS = 256;
+constexpr int SV_LDS_P = 128;
+
+__global__ __launch_bounds__(SV_THREADS) void ar_solve_kernel(const double* __restrict__ part,
+                                                              const int32_t* __restrict__ nlen, int p,
+                                                              int nchunks_max, double ridge,
+                                                              double* __restrict__ gscratch,
+                                                              double* __restrict__ coeffs,
+                                                              double* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __shared__ double piv;
+  __shared__ int fail;
+  const int e = blockIdx.x;
+  const int tid = threadIdx.x;
+  const long long N = nlen[e];
+  const int nchunks = (int)((N - p + GR_CHUNK - 1) / GR_CHUNK);
+  const int ng = groups_total(p);
+  double* vec = reinterpret_cast<double*>(smem_raw);            // rhs / solution, p doubles
+  double* G = (p <= SV_LDS_P) ? vec + p : gscratch + (long long)e * p * p;
+  const double* pe = part + (long long)e * nchunks_max * ng * GR_PART;
+
+  // ---- deterministic reduction over chunks (fixed order), lower triangle + mirror -------------------------
+  for (int idx = tid; idx < p * p; idx += SV_THREADS) {
+    const int r = idx / p, c = idx - r * p;
+    if (c > r) continue;
+    const int gi = r / GR_GROUP, gj = c / GR_GROUP;
+    const int gid = gi * (gi + 1) / 2 + gj;
+    const int lr = r - gi * GR_GROUP, lc = c - gj * GR_GROUP;
+    double s = 0.0;
+    for (int ch = 0; ch < nchunks; ++ch) s += pe[((long long)ch * ng + gid) * GR_PART + lr * GR_GROUP + lc];
+    if (r == c) s += ridge;
+    G[r * p + c] = s;
+    G[c * p + r] = s;
+  }
+  for (int j = tid; j < p; j += SV_THREADS) {
+    const int gi = j / GR_GROUP;
+    const int gid = gi * (gi + 1) / 2 + gi;
+    double s = 0.0;
+    for (int ch = 0; ch < nchunks; ++ch)
+      s += pe[((long long)ch * ng + gid) * GR_PART + GR_GROUP * GR_GROUP + (j - gi * GR_GROUP)];
+    vec[j] = s;
+  }
+  if (tid == 0) fail = 0;
+  __syncthreads();
+  double dmax = 0.0, dmin = INFINITY;
+
+  // ---- Cholesky, right-looking, lower triangle in place ---------------------------------------------------
+  for (int k = 0; k < p; ++k) {
+    if (tid == 0) {
+      const double d = G[k * p + k];
+      if (!(d > 0.0)) { fail = 1; piv = 1.0; }
+      else piv = sqrt(d);
+    }
+    __syncthreads();
+    const double d = piv;
+    dmax = fmax(dmax, d); dmin = fmin(dmin, d);
+    for (int i = k + tid; i < p; i += SV_THREADS) G[i * p + k] = (i == k) ? d : G[i * p + k] / d;
+    __syncthreads();
+    // trailing update: G[i][j] -= L[i][k] L[j][k] for k < j <= i
+    const int m = p - k - 1;
+    for (int idx = tid; idx < m * m; idx += SV_THREADS) {
+      const int ii = idx / m, jj = idx - ii * m;
+      if (jj > ii) continue;
+      const int i = k + 1 + ii, j = k + 1 + jj;
+      G[i * p + j] -= G[i * p + k] * G[j * p + k];
+    }
+    __syncthreads();
+  }
+  // ---- L y = r (forward), L^T a = y (backward), column oriented ----------------------------------------------
+  for (int k = 0; k < p; ++k) {
+    if (tid == 0) vec[k] = vec[k] / G[k * p + k];
+    __syncthreads();
+    const double yk = vec[k];
+    for (int i = k + 1 + tid; i < p; i += SV_THREADS) vec[i] -= G[i * p + k] * yk;
+    __syncthreads();
+  }
+  for (int k = p - 1; k >= 0; --k) {
+    if (tid == 0) vec[k] = vec[k] / G[k * p + k];
+    __syncthreads();
+    const double ak = vec[k];
+    for (int i = tid; i < k; i += SV_THREADS) vec[i] -= G[k * p + i] * ak;
+    __syncthreads();
+  }
+  double* co = coeffs + (long long)e * (p + 1);
+  if (tid == 0) co[0] = 1.0;
+  for (int j = tid; j < p; j += SV_THREADS) co[j + 1] = vec[j];
+  if (tid == 0 && info) {
+    info[3 * e + 0] = (double)fail;
+    info[3 * e + 1] = dmax;   // largest / smallest Cholesky pivot: (dmax/dmin)^2 ~ cond(G) lower bound
+    info[3 * e + 2] = dmin;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Aberth-Ehrlich: all roots of c[0] z^n + ... + c[n] (descending powers), float64 complex.
+// One workgroup per polynomial, one thread per root (n <= 1024).  Jacobi-style sweeps (all corrections from
+// the previous iterate) keep it deterministic.  Leading/trailing handling follows the reference: trailing
+// |c| < trail_eps coefficients are dropped first (zplane.py:153-155), then numpy.roots semantics (leading
+// zeros stripped; exact trailing zeros become roots at 0).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int RT_MAX_DEG = 1024;
+constexpr int RT_MAX_ITERS = 200;
+
+struct cdbl { double re, im; };
+__device__ __forceinline__ cdbl c_mul(cdbl a, cdbl b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ cdbl c_div(cdbl a, cdbl b) {
+  // Smith's algorithm
+  if (fabs(b.re) >= fabs(b.im)) {
+    const double r = b.im / b.re, d = b.re + b.im * r;
+    return {(a.re + a.im * r) / d, (a.im - a.re * r) / d};
+  }
+  const double r = b.re / b.im, d = b.re * r + b.im;
+  return {(a.re * r + a.im) / d, (a.im * r - a.re) / d};
+}
+
+__global__ void poly_roots_kernel(const double* __restrict__ coeffs, int stride, int ncoef, double trail_eps,
+                                  double* __restrict__ roots, int32_t* __restrict__ nroots_out) {
+  __shared__ double c[RT_MAX_DEG + 1];
+  __shared__ cdbl z[2][RT_MAX_DEG];
+  __shared__ int sh_lo, sh_hi, sh_changed;
+  const int e = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const double* ce = coeffs + (long long)e * stride;
+  double* re = roots + (long long)e * 2 * (ncoef - 1);
+  if (tid == 0) {
+    int hi = ncoef;   // exclusive end after trimming tiny trailing coefficients
+    while (hi > 1 && fabs(ce[hi - 1]) < trail_eps) --hi;
+    int lo = 0;       // strip leading exact zeros (numpy.roots)
+    while (lo < hi && ce[lo] == 0.0) ++lo;
+    sh_lo = lo; sh_hi = hi;
+  }
+  __syncthreads();
+  int lo = sh_lo, hi = sh_hi;
+  if (hi - lo <= 1 || hi <= 1) {
+    if (tid == 0) nroots_out[e] = 0;
+    return;
+  }
+  // exact trailing zeros -> roots at the origin
+  int tz = 0;
+  while (hi - 1 - tz > lo && ce[hi - 1 - tz] == 0.0) ++tz;
+  const int n = hi - lo - 1 - tz;   // degree of the deflated polynomial
+  const double lead = ce[lo];
+  for (int k = tid; k <= n; k += nt) c[k] = ce[lo + k] / lead;   // monic
+  __syncthreads();
+  if (n >= 1) {
+    // initial radius: geometric mean of the root moduli, |c_n|^(1/n), kept in a sane range
+    double r0 = pow(fabs(c[n]), 1.0 / (double)n);
+    if (!(r0 > 1e-3)) r0 = 1e-3;
+    if (r0 > 1e3) r0 = 1e3;
+    for (int k = tid; k < n; k += nt) {
+      double s, co;
+      sincos(2.0 * 3.14159265358979323846 * (double)k / (double)n + 0.4, &s, &co);
+      z[0][k] = {r0 * co, r0 * s};
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int it = 0; it < RT_MAX_ITERS; ++it) {
+      if (tid == 0) sh_changed = 0;
+      __syncthreads();
+      int changed = 0;
+      for (int k = tid; k < n; k += nt) {
+        const cdbl zk = z[cur][k];
+        // Horner for p and p'
+        cdbl pv = {1.0, 0.0}, dv = {0.0, 0.0};
+        for (int m = 1; m <= n; ++m) {
+          dv = c_mul(dv, zk); dv.re += pv.re; dv.im += pv.im;
+          pv = c_mul(pv, zk); pv.re += c[m];
+        }
+        cdbl w = {0.0, 0.0};
+        if (pv.re != 0.0 || pv.im != 0.0) {
+          const cdbl ratio = c_div(pv, dv);
+          cdbl sum = {0.0, 0.0};
+          for (int j = 0; j < n; ++j) {
+            if (j == k) continue;
+            const cdbl zj = z[cur][j];
+            const double dr = zk.re - zj.re, di = zk.im - zj.im;
+            const double inv = 1.0 / (dr * dr + di * di);   // 1/(zk - zj) = conj(d)/|d|^2
+            sum.re += dr * inv; sum.im -= di * inv;
+          }
+          const cdbl rs = c_mul(ratio, sum);
+          w = c_div(ratio, cdbl{1.0 - rs.re, -rs.im});
+        }
+        z[cur ^ 1][k] = {zk.re - w.re, zk.im - w.im};
+        const double wm = fabs(w.re) + fabs(w.im), zm = fabs(zk.re) + fabs(zk.im);
+        if (wm > 2e-13 * zm) changed = 1;
+      }
+      if (changed) sh_changed = 1;   // benign race: every writer stores 1
+      __syncthreads();
+      cur ^= 1;
+      const int any = sh_changed;
+      __syncthreads();
+      if (!any) break;
+    }
+    for (int k = tid; k < n; k += nt) { re[2 * k] = z[cur][k].re; re[2 * k + 1] = z[cur][k].im; }
+  }
+  for (int k = n + tid; k < n + tz; k += nt) { re[2 * k] = 0.0; re[2 * k + 1] = 0.0; }
+  if (tid == 0) nroots_out[e] = n + tz;
+}
+
+// b[n] = sum_{k=0..p} a[k] h[n-k], 0 <= n-k < N; h = x / divisor (float64)
+__global__ void fir_numerator_kernel(const double* __restrict__ coeffs, int p, const float* __restrict__ x,
+                                     const int64_t* __restrict__ xoff, const int32_t* __restrict__ nlen,
+                                     const double* __restrict__ divisor, int q, double* __restrict__ b) {
+  const int e = blockIdx.x;
+  const double* a = coeffs + (long long)e * (p + 1);
+  const float* xs = x + xoff[e];
+  const double div = divisor ? divisor[e] : 1.0;
+  const long long N = nlen[e];
+  for (int n = threadIdx.x; n <= q; n += blockDim.x) {
+    double acc = 0.0;
+    for (int k = 0; k <= p; ++k) {
+      const long long m = (long long)n - k;
+      if (m < 0 || m >= N) continue;
+      acc += a[k] * ((double)xs[m] / div);
+    }
+    b[(long long)e * (q + 1) + n] = acc;
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t ira_ar_partial_doubles(int32_t p, int32_t max_len) {
+  if (p < 1 || p > GR_MAX_P || max_len <= p) return 0;
+  const int64_t nchunks = ((int64_t)max_len - p + GR_CHUNK - 1) / GR_CHUNK;
+  return nchunks * groups_total(p) * (int64_t)GR_PART;
+}
+
+extern "C" int32_t ira_ar_fit(const float* x_dev, const double* x64_dev, const int64_t* xoff_dev,
+                              const int32_t* len_dev,
+                              const double* divisor_dev, int32_t nb, int32_t max_len, int32_t order, double ridge,
+                              double* partial_dev, double* gscratch_dev, double* coeffs_dev, double* info_dev,
+                              void* stream) {
+  if (x_dev == nullptr && x64_dev == nullptr) return IRA_E_NULL;
+  IRA_CHECK_PTR(xoff_dev); IRA_CHECK_PTR(len_dev); IRA_CHECK_PTR(partial_dev);
+  IRA_CHECK_PTR(coeffs_dev);
+  if (nb <= 0) return nb == 0 ? IRA_OK : IRA_E_SIZE;
+  if (order < 1 || order > GR_MAX_P || max_len <= order) return IRA_E_SIZE;
+  if (order > SV_LDS_P && gscratch_dev == nullptr) return IRA_E_NULL;
+  hipStream_t st = (hipStream_t)stream;
+  const int nchunks = (int)(((int64_t)max_len - order + GR_CHUNK - 1) / GR_CHUNK);
+  if (nb > 65535 || groups_total(order) > 65535) return IRA_E_SIZE;
+  ar_gram_kernel<<<dim3(nchunks, groups_total(order), nb), 64, 0, st>>>(x64_dev ? nullptr : x_dev, x64_dev, xoff_dev, len_dev,
+                                                                       divisor_dev, order,
+                                                                       nchunks, partial_dev);
+  size_t lds = sizeof(double) * (size_t)order;
+  if (order <= SV_LDS_P) lds += sizeof(double) * (size_t)order * order;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ar_solve_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return ira_hip_status(e);
+  }
+  ar_solve_kernel<<<nb, SV_THREADS, lds, st>>>(partial_dev, len_dev, order, nchunks, ridge, gscratch_dev, coeffs_dev,
+                                               info_dev);
+  IRA_RETURN_LAUNCH();
+}
+
+extern "C" int32_t ira_poly_roots(const double* coeffs_dev, int32_t npoly, int32_t ncoef, double trail_eps,
+                                  double* roots_dev, int32_t* nroots_dev, void* stream) {
+  IRA_CHECK_PTR(coeffs_dev); IRA_CHECK_PTR(roots_dev); IRA_CHECK_PTR(nroots_dev);
+  if (npoly <= 0) return npoly == 0 ? IRA_OK : IRA_E_SIZE;
+  if (ncoef < 2 || ncoef - 1 > RT_MAX_DEG) return IRA_E_SIZE;
+  int threads = 64;
+  while (threads < ncoef - 1 && threads < 1024) threads <<= 1;
+  poly_roots_kernel<<<npoly, threads, 0, (hipStream_t)stream>>>(coeffs_dev, ncoef, ncoef, trail_eps, roots_dev,
+                                                               nroots_dev);
+  IRA_RETURN_LAUNCH();
+}
+
+extern "C" int32_t ira_fir_numerator(const double* coeffs_dev, int32_t order, const float* x_dev,
+                                     const int64_t* xoff_dev, const int32_t* len_dev, const double* divisor_dev,
+                                     int32_t nb, int32_t zero_order, double* b_dev, void* stream) {
+  IRA_CHECK_PTR(coeffs_dev); IRA_CHECK_PTR(x_dev); IRA_CHECK_PTR(xoff_dev); IRA_CHECK_PTR(len_dev);
+  IRA_CHECK_PTR(b_dev);
+  if (nb <= 0) return nb == 0 ? IRA_OK : IRA_E_SIZE;
+  if (order < 0 || zero_order < 0) return IRA_E_SIZE;
+  fir_numerator_kernel<<<nb, 128, 0, (hipStream_t)stream>>>(coeffs_dev, order, x_dev, xoff_dev, len_dev,
+                                                            divisor_dev, zero_order, b_dev);
+  IRA_RETURN_LAUNCH();
+}

@@ -364,3 +364,57 @@ class Engine:
                                             _ptr(d_f), _ptr(d_c), nbins, _ptr(out), _ptr(d_oo), self.stream),
               "ira_logbin_aggregate")
         return out, out_off
+
+    # ------------------------------------------------------------------ a19-a21: AR pole fit
+    def ar_fit(self, x_dev, xoff: np.ndarray, lengths: np.ndarray, divisor: Optional[np.ndarray], order: int,
+               ridge: float = 0.0, x_is_f64: bool = False):
+        """AR coefficients (nb, order+1) float64 device + info (nb, 3) for segments of x_dev."""
+        t = self.torch
+        n = int(xoff.size)
+        lengths = np.ascontiguousarray(lengths, dtype=np.int32)
+        max_len = int(lengths.max())
+        per = int(self.lib.ira_ar_partial_doubles(int(order), max_len))
+        if per <= 0:
+            raise ValueError("AR order must satisfy 1 <= order <= 1024 < segment length")
+        part = self.empty(n * per, t.float64)
+        gs = self.empty(n * order * order, t.float64) if order > 128 else None
+        coeffs = self.empty(n * (order + 1), t.float64)
+        info = self.empty(n * 3, t.float64)
+        d_xo, d_l = self.to_dev(np.ascontiguousarray(xoff, np.int64)), self.to_dev(lengths)
+        d_div = self.to_dev(np.ascontiguousarray(divisor, np.float64)) if divisor is not None else None
+        check(self.lib.ira_ar_fit(0 if x_is_f64 else _ptr(x_dev), _ptr(x_dev) if x_is_f64 else 0, _ptr(d_xo), _ptr(d_l),
+                                  _ptr(d_div), n, max_len, int(order), float(ridge),
+                                  _ptr(part), _ptr(gs), _ptr(coeffs), _ptr(info), self.stream), "ira_ar_fit")
+        return coeffs[: n * (order + 1)].view(n, order + 1), info[: n * 3].view(n, 3)
+
+    def poly_roots(self, coeffs_dev, npoly: int, ncoef: int, trail_eps: float = 1e-14):
+        """Roots (npoly, ncoef-1, 2) float64 device + counts int32 device."""
+        t = self.torch
+        roots = self.empty(npoly * (ncoef - 1) * 2, t.float64)
+        cnt = self.empty(npoly, t.int32)
+        check(self.lib.ira_poly_roots(_ptr(coeffs_dev), int(npoly), int(ncoef), float(trail_eps), _ptr(roots),
+                                      _ptr(cnt), self.stream), "ira_poly_roots")
+        return roots[: npoly * (ncoef - 1) * 2].view(npoly, ncoef - 1, 2), cnt[:npoly]
+
+    def fir_numerator(self, coeffs_dev, order: int, x_dev, xoff: np.ndarray, lengths: np.ndarray,
+                      divisor: Optional[np.ndarray], zero_order: int):
+        t = self.torch
+        n = int(xoff.size)
+        b = self.empty(n * (zero_order + 1), t.float64)
+        d_xo = self.to_dev(np.ascontiguousarray(xoff, np.int64))
+        d_l = self.to_dev(np.ascontiguousarray(lengths, np.int32))
+        d_div = self.to_dev(np.ascontiguousarray(divisor, np.float64)) if divisor is not None else None
+        check(self.lib.ira_fir_numerator(_ptr(coeffs_dev), int(order), _ptr(x_dev), _ptr(d_xo), _ptr(d_l), _ptr(d_div),
+                                         n, int(zero_order), _ptr(b), self.stream), "ira_fir_numerator")
+        return b[: n * (zero_order + 1)].view(n, zero_order + 1)
+
+    def segment_peaks(self, x_dev, off: np.ndarray, lens: np.ndarray):
+        """max|x| (float32 values as float64) of arbitrary segments."""
+        t = self.torch
+        n = int(off.size)
+        pk = self.empty(n, t.int64)
+        pa = self.empty(n, t.float32)
+        d_o, d_l = self.to_dev(np.ascontiguousarray(off, np.int64)), self.to_dev(np.ascontiguousarray(lens, np.int64))
+        check(self.lib.ira_peak_index(_ptr(x_dev), _ptr(d_o), _ptr(d_l), n, _ptr(pk), _ptr(pa), self.stream),
+              "ira_peak_index")
+        return pa.cpu().numpy()[:n].astype(np.float64)

@@ -178,6 +178,35 @@ int32_t ira_logbin_aggregate(const float* mag_dev, const int64_t* mag_off_dev, c
                              const int32_t* count_dev, int32_t nbins, float* out_dev,
                              const int64_t* out_off_dev, void* stream);
 
+/* ---- a19-a21: z-plane AR pole fit ----------------------------------------------------------------------------
+ * Covariance-method AR least squares of order `order` on segments x[xoff[e] .. +len[e]) / divisor[e]
+ * (divisor_dev may be NULL = 1; if x64_dev != NULL the samples are read from it as float64 instead): normal equations G = A^T A, r = A^T y with A[n,k] = s[n-k], y = -s[n],
+ * n = order..len-1, contracted in float64 on the matrix cores, optional ridge added to the diagonal, Cholesky
+ * solve.  coeffs_dev[e*(order+1) ..] = [1, a_1 .. a_order].  Replaces _fit_ar_least_squares, reference
+ * analyse/zplane.py:83-120 (which uses an SVD-based lstsq; results agree to ~cond(A)^2 * 1e-16).
+ * partial_dev: nb * ira_ar_partial_doubles(order, max_len) doubles of scratch; gscratch_dev: nb*order*order
+ * doubles, only needed when order > 128; info_dev (optional): 3 doubles per element
+ * [0] 1 if a Cholesky pivot was not positive, [1] largest, [2] smallest pivot.  1 <= order <= 1024 < len. */
+int64_t ira_ar_partial_doubles(int32_t order, int32_t max_len);
+int32_t ira_ar_fit(const float* x_dev, const double* x64_dev, const int64_t* xoff_dev,
+                   const int32_t* len_dev, const double* divisor_dev, int32_t nb, int32_t max_len, int32_t order, double ridge,
+                   double* partial_dev, double* gscratch_dev, double* coeffs_dev, double* info_dev,
+                   void* stream);
+
+/* All complex roots of npoly real polynomials given in DESCENDING powers, ncoef coefficients each
+ * (Aberth-Ehrlich, float64).  Trailing coefficients with |c| < trail_eps are dropped first (reference
+ * analyse/zplane.py:153-155), then numpy.roots conventions apply (leading zeros stripped, exact trailing
+ * zeros are roots at 0).  roots_dev: npoly * (ncoef-1) interleaved (re, im); nroots_dev[e] = count found.
+ * Replaces _roots_from_poly_descending, reference analyse/zplane.py:145-158.  Root order is unspecified. */
+int32_t ira_poly_roots(const double* coeffs_dev, int32_t npoly, int32_t ncoef, double trail_eps,
+                       double* roots_dev, int32_t* nroots_dev, void* stream);
+
+/* b[e][n] = sum_k a[e][k] * s[n-k], n = 0..zero_order.  Replaces _derive_fir_numerator_from_ar, reference
+ * analyse/zplane.py:123-142. */
+int32_t ira_fir_numerator(const double* coeffs_dev, int32_t order, const float* x_dev,
+                          const int64_t* xoff_dev, const int32_t* len_dev, const double* divisor_dev,
+                          int32_t nb, int32_t zero_order, double* b_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

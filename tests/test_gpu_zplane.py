@@ -1,0 +1,94 @@
+"""GPU parity: AR least squares (MFMA Gram + Cholesky), Aberth roots, FIR numerator vs golden vectors."""
+import numpy as np
+import pytest
+
+from oracle import ira_oracle as O
+
+pytestmark = pytest.mark.gpu
+SR = 48000
+
+
+def _sorted(z):
+    z = np.asarray(z)
+    return z[np.lexsort((np.round(z.imag, 9), np.round(z.real, 9)))]
+
+
+def _match_roots(got, ref):
+    """Greedy nearest matching (root order is unspecified in numpy.roots); returns max |difference|."""
+    assert got.size == ref.size
+    ref = list(ref)
+    worst = 0.0
+    for g in got:
+        d = [abs(g - r) for r in ref]
+        j = int(np.argmin(d))
+        worst = max(worst, d[j])
+        ref.pop(j)
+    return worst
+
+
+def test_poly_roots_known():
+    from audio_analysis_amd.analyse import zplane as zp
+    rts = np.array([0.5, -0.25, 0.9 * np.exp(1j * 0.7), 0.9 * np.exp(-1j * 0.7), 1.1j, -1.1j, 0.99, -0.98])
+    c = np.real(np.poly(rts))
+    got = zp._roots_from_poly_descending(c)
+    assert _match_roots(got, rts) < 1e-12
+    # trailing tiny coefficient is dropped (degree falls), trailing exact zeros become roots at 0, leading zeros strip
+    got = zp._roots_from_poly_descending(np.array([1.0, -1.5, 0.5, 1e-15]))
+    assert _match_roots(got, np.array([1.0, 0.5])) < 1e-12
+    got = zp._roots_from_poly_descending(np.array([0.0, 2.0, -3.0, 1.0, 0.0]))
+    assert _match_roots(got, O.poly_roots(np.array([0.0, 2.0, -3.0, 1.0, 0.0]))) < 1e-12
+    assert zp._roots_from_poly_descending(np.array([3.0])).size == 0
+
+
+@pytest.mark.parametrize("tag,inp", [("xa_p8", "xa"), ("xa_p64", "xa"), ("xa_p256", "xa"), ("xa_p64_ridge", "xa"),
+                                     ("xe_p64", "xe"), ("xb16_p64", "xb16"), ("xc_p32", "xc")])
+def test_zplane_vs_golden(golden, tag, inp):
+    from audio_analysis_amd.analyse import zplane as zp
+    g, c, _ = golden
+    cs = c["zplane"][tag]
+    s = zp.ZPlaneAnalysisSettings(ar_order=cs["order"], ridge_lambda=cs["ridge"], derive_zeros=True)
+    r = zp.analyse_zplane_batch([g[f"in/{inp}"]], SR, ["mono"], s)[0]
+    ref_poles = g[f"{tag}/zplane/poles"]
+    assert r.poles.size == ref_poles.size
+    rad, rad_ref = np.sort(np.abs(r.poles)), np.sort(np.abs(ref_poles))
+    assert np.max(np.abs(rad - rad_ref) / rad_ref) < 1e-4            # north_star: pole radii within 1e-4
+    assert _match_roots(r.poles, ref_poles) < 1e-6
+    assert abs(np.max(rad) - cs["max_r"]) < 1e-8 and abs(np.median(rad) - cs["med_r"]) < 1e-8
+    assert int(np.sum(rad >= 1.0)) == cs["unstable"]                  # integer: exact
+    assert zp.summarise_zplane_results_text([r]) == cs["summary"]
+    ref_zeros = g[f"{tag}/zplane/zeros"]
+    assert r.zeros.size == ref_zeros.size
+    assert _match_roots(r.zeros, ref_zeros) < 1e-6 * max(1.0, np.max(np.abs(ref_zeros)))
+
+
+def test_ar_helpers_vs_golden(golden):
+    from audio_analysis_amd.analyse import zplane as zp
+    g, c, _ = golden
+    x = g["in/xa"]
+    st = c["zplane"]["xa_p64"]["start"]
+    seg = x[st:].astype(np.float64)
+    seg = seg / np.max(np.abs(seg))
+    a = zp._fit_ar_least_squares(seg, 64)
+    ref = g["xa_p64/zplane/a"]
+    assert np.max(np.abs(a - ref)) / np.max(np.abs(ref)) < 1e-10
+    a = zp._fit_ar_least_squares(seg, 64, 1e-6)
+    assert np.max(np.abs(a - g["xa_p64_ridge/zplane/a"])) / np.max(np.abs(ref)) < 1e-10
+    b = zp._derive_fir_numerator_from_ar(ref, seg, 64)
+    np.testing.assert_allclose(b, g["xa_p64/zplane/b"], rtol=1e-12, atol=1e-14)
+    assert zp._fit_ar_least_squares(seg, 0).tolist() == [1.0]
+    assert zp._fit_ar_least_squares(seg[:5], 64).size == 5           # order reduced to N-1
+    assert zp._rt60_from_pole_radius(1.0, SR) == float("inf")
+    assert abs(zp._rt60_from_pole_radius(0.999, SR) - O.rt60_from_radius(0.999, SR)) < 1e-15
+
+
+def test_zplane_batch_vs_oracle():
+    from audio_analysis_amd.analyse import zplane as zp
+    from audio_analysis_amd.synth import synth_ir
+    chans = [synth_ir(i, 0, 40000 + 333 * i, rt60_seconds=0.2 + 0.1 * i) for i in range(3)]
+    chans.append(synth_ir(9, 0, 30000, rt60_seconds=0.3, lowpass_pole=0.9))       # strongly coloured
+    res = zp.analyse_zplane_batch(chans, SR, list("abcd"), zp.ZPlaneAnalysisSettings(ar_order=48))
+    for x, r in zip(chans, res):
+        o = O.analyse_zplane(x, SR, ar_order=48)
+        rad, rad_ref = np.sort(np.abs(r.poles)), np.sort(np.abs(o["poles"]))
+        assert np.max(np.abs(rad - rad_ref) / rad_ref) < 1e-4
+        assert int(np.sum(rad >= 1.0)) == o["unstable"]
