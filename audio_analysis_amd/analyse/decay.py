@@ -161,6 +161,47 @@ def fit_decay_slope_over_db_range(
 # ---------------------------------------------------------------------------------------------------
 
 
+def decay_fit_specs(settings: DecayAnalysisSettings):
+    """[(name, range_db)] in the order the fits are computed, plus the effective (hi, lo) pairs."""
+    specs = ([("EDT", settings.edt_range_db)] if settings.compute_edt else []) + [
+        ("T20", settings.t20_range_db), ("T30", settings.t30_range_db)]
+    ranges = []
+    for _, rng in specs:
+        hi, lo = _check_range(rng)
+        ranges.append((hi, max(lo, float(settings.fit_lower_limit_db))))
+    return specs, ranges
+
+
+def decay_device(eng, batch, sample_rate_hz: int, settings: DecayAnalysisSettings):
+    """Device-resident decay analysis of a batch: EDC curves + fit/crossing records stay in HBM."""
+    specs, ranges = decay_fit_specs(settings)
+    edc, edc_off, starts, lens = _edc_on_device(eng, batch, sample_rate_hz, settings)
+    fits_dev, cross_dev = eng.curve_fits(edc, edc_off, lens, 1.0, float(sample_rate_hz), ranges, 8,
+                                         cross=(0.0, -10.0))
+    return dict(edc=edc, edc_off=edc_off, starts=starts, lens=lens, fits=fits_dev, cross=cross_dev, specs=specs)
+
+
+def decay_records_to_results(dev, fits: np.ndarray, cross: np.ndarray, edc_host, sample_rate_hz, channel_names):
+    out: List[ChannelDecayAnalysis] = []
+    for i, name in enumerate(channel_names):
+        t0, t10 = cross[i, 0], cross[i, 1]
+        early = float(t10 - t0) if (not np.isnan(t0) and not np.isnan(t10) and t10 >= t0) else None
+        fd: Dict[str, LinearDecayFit] = {}
+        for j, (fname, rng) in enumerate(dev["specs"]):
+            f = _fit_from_record(fits[i, j], fname, rng)
+            if f is not None:
+                fd[fname] = f
+        ln = int(dev["lens"][i])
+        o = int(dev["edc_off"][i])
+        out.append(ChannelDecayAnalysis(
+            channel_name=name, sample_rate_hz=sample_rate_hz, analysis_start_sample_index=int(dev["starts"][i]),
+            time_seconds=_time_axis(ln, sample_rate_hz),
+            edc_db=edc_host[o : o + ln].copy() if edc_host is not None else None,
+            early_decay_10db_time_seconds=early, fits=fd,
+        ))
+    return out
+
+
 def analyse_decay_batch(
     channels: Sequence[np.ndarray],
     sample_rate_hz: int,
@@ -171,36 +212,12 @@ def analyse_decay_batch(
     for c in channels:
         if c.ndim != 1:
             raise ValueError("compute_schroeder_edc_db expects a 1D mono array.")
-    specs = ([("EDT", settings.edt_range_db)] if settings.compute_edt else []) + [
-        ("T20", settings.t20_range_db), ("T30", settings.t30_range_db)]
-    ranges = []
-    for _, rng in specs:
-        hi, lo = _check_range(rng)
-        ranges.append((hi, max(lo, float(settings.fit_lower_limit_db))))
+    decay_fit_specs(settings)          # validates the ranges before any device work
     eng = get_engine()
     batch = eng.upload(list(channels))
-    edc, edc_off, starts, lens = _edc_on_device(eng, batch, sample_rate_hz, settings)
-    fits_dev, cross_dev = eng.curve_fits(edc, edc_off, lens, 1.0, float(sample_rate_hz), ranges, 8,
-                                         cross=(0.0, -10.0))
-    fits = fits_dev.cpu().numpy()
-    cross = cross_dev.cpu().numpy()
-    edc_host = edc.cpu().numpy()
-    out: List[ChannelDecayAnalysis] = []
-    for i, name in enumerate(channel_names):
-        t0, t10 = cross[i, 0], cross[i, 1]
-        early = float(t10 - t0) if (not np.isnan(t0) and not np.isnan(t10) and t10 >= t0) else None
-        fd: Dict[str, LinearDecayFit] = {}
-        for j, (fname, rng) in enumerate(specs):
-            f = _fit_from_record(fits[i, j], fname, rng)
-            if f is not None:
-                fd[fname] = f
-        ln = int(lens[i])
-        out.append(ChannelDecayAnalysis(
-            channel_name=name, sample_rate_hz=sample_rate_hz, analysis_start_sample_index=int(starts[i]),
-            time_seconds=_time_axis(ln, sample_rate_hz), edc_db=edc_host[edc_off[i] : edc_off[i] + ln].copy(),
-            early_decay_10db_time_seconds=early, fits=fd,
-        ))
-    return out
+    dev = decay_device(eng, batch, sample_rate_hz, settings)
+    return decay_records_to_results(dev, dev["fits"].cpu().numpy(), dev["cross"].cpu().numpy(),
+                                    dev["edc"].cpu().numpy(), sample_rate_hz, channel_names)
 
 
 def analyse_decay_for_channel(

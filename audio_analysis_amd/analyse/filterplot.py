@@ -15,7 +15,7 @@ import numpy as np
 
 from ..engine import get_engine
 from ._common import wav_channels
-from .frequency_response import rfft_bin_step, spectrum_segments
+from .frequency_response import spectrum_device
 from .io import get_analysis_channels, load_wav_file
 
 
@@ -64,16 +64,11 @@ def analyse_filter_response_batch(
             raise ValueError("analyse_filter_response_for_channel expects a 1D mono array.")
     eng = get_engine()
     batch = eng.upload(list(channels))
-    starts, lens = spectrum_segments(eng, batch, sample_rate_hz, settings, "filter response")
-    spec, off = eng.rfft_any(batch.x, batch.off + starts, lens, bool(settings.use_hann_window))
-    mag, ph = eng.spectrum_mag_phase(spec, off, lens, float(settings.magnitude_floor_db), want_phase=True)
-    phase = eng.phase_unwrap(ph, off, lens, bool(settings.unwrap_phase), settings.phase_mode == "degrees")
-    nyq = 0.5 * float(sample_rate_hz)
-    f_lo = float(np.clip(settings.f_min_hz, 0.0, nyq))
-    f_hi = float(np.clip(settings.f_max_hz, f_lo, nyq))
-    steps = np.array([rfft_bin_step(int(n), sample_rate_hz) for n in lens], dtype=np.float64)
-    stats = eng.spectrum_stats(mag, off, lens, steps, f_lo, f_hi, 1000.0).cpu().numpy()
-    mag_host, ph_host = mag.cpu().numpy(), phase.cpu().numpy()
+    dev = spectrum_device(eng, batch, sample_rate_hz, settings, "filter response", want_phase=True,
+                          unwrap=bool(settings.unwrap_phase), degrees=settings.phase_mode == "degrees")
+    starts, lens, off = dev["starts"], dev["lens"], dev["off"]
+    stats = dev["stats"].cpu().numpy()
+    mag_host, ph_host = dev["mag"].cpu().numpy(), dev["phase"].cpu().numpy()
     out = []
     for i, name in enumerate(channel_names):
         n = int(lens[i])

@@ -102,6 +102,24 @@ def spectrum_segments(eng, batch, sample_rate_hz: int, settings, what: str):
     return starts, lens
 
 
+def spectrum_device(eng, batch, sample_rate_hz: int, settings, what: str, want_phase: bool = False,
+                    unwrap: bool = True, degrees: bool = True):
+    """
+    Device-resident whole-segment spectra: complex f64 half spectra, float32 dB magnitudes, optional
+    (unwrapped) phase and the (n, 8) statistics records of ira_spectrum_stats, all left in HBM.
+    """
+    starts, lens = spectrum_segments(eng, batch, sample_rate_hz, settings, what)
+    spec, off = eng.rfft_any(batch.x, batch.off + starts, lens, bool(settings.use_hann_window))
+    mag, ph = eng.spectrum_mag_phase(spec, off, lens, float(settings.magnitude_floor_db), want_phase=want_phase)
+    phase = eng.phase_unwrap(ph, off, lens, unwrap, degrees) if want_phase else None
+    nyq = 0.5 * float(sample_rate_hz)
+    f_lo = float(np.clip(settings.f_min_hz, 0.0, nyq))
+    f_hi = float(np.clip(settings.f_max_hz, f_lo, nyq))
+    steps = np.array([rfft_bin_step(int(n), sample_rate_hz) for n in lens], dtype=np.float64)
+    stats = eng.spectrum_stats(mag, off, lens, steps, f_lo, f_hi, 1000.0)
+    return dict(spec=spec, off=off, starts=starts, lens=lens, mag=mag, phase=phase, stats=stats, f_lo=f_lo, f_hi=f_hi)
+
+
 def analyse_frequency_response_batch(
     channels: Sequence[np.ndarray],
     sample_rate_hz: int,
@@ -113,15 +131,11 @@ def analyse_frequency_response_batch(
             raise ValueError("analyse_frequency_response_for_channel expects a 1D mono array.")
     eng = get_engine()
     batch = eng.upload(list(channels))
-    starts, lens = spectrum_segments(eng, batch, sample_rate_hz, settings, "spectrum")
-    spec, off = eng.rfft_any(batch.x, batch.off + starts, lens, bool(settings.use_hann_window))
-    mag, _ = eng.spectrum_mag_phase(spec, off, lens, float(settings.magnitude_floor_db), want_phase=False)
+    dev = spectrum_device(eng, batch, sample_rate_hz, settings, "spectrum")
+    starts, lens, off, mag, f_lo, f_hi = dev["starts"], dev["lens"], dev["off"], dev["mag"], dev["f_lo"], dev["f_hi"]
     nyq = 0.5 * float(sample_rate_hz)
-    f_lo = float(np.clip(settings.f_min_hz, 0.0, nyq))
-    f_hi = float(np.clip(settings.f_max_hz, f_lo, nyq))
-    steps = np.array([rfft_bin_step(int(n), sample_rate_hz) for n in lens], dtype=np.float64)
     smoothing = bool(settings.smoothing_log_bins and int(settings.smoothing_log_bins) > 1)
-    stats = None if smoothing else eng.spectrum_stats(mag, off, lens, steps, f_lo, f_hi).cpu().numpy()
+    stats = None if smoothing else dev["stats"].cpu().numpy()
     mag_host = mag.cpu().numpy()
     out = []
     for i, name in enumerate(channel_names):

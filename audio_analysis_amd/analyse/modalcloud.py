@@ -101,6 +101,28 @@ def analyse_modal_cloud_batch(
 ) -> List[ChannelModalCloudResult]:
     eng = get_engine()
     batch = eng.upload(list(channels))
+    dev = modal_cloud_device(eng, batch, sample_rate_hz, settings)
+    return modal_records_to_results(dev, dev["fits"].cpu().numpy(), sample_rate_hz, channel_names)
+
+
+def modal_records_to_results(dev, rec: np.ndarray, sample_rate_hz: int, channel_names):
+    centres, nbins = dev["centres"], dev["nbins"]
+    rec = rec.reshape(len(channel_names), nbins, 8)
+    out = []
+    for i, name in enumerate(channel_names):
+        pts = [ModalPoint(centre_hz=float(centres[b]), rt60_seconds=float(rec[i, b, 6]), r_squared=float(rec[i, b, 5]))
+               for b in range(nbins) if rec[i, b, 0] == 1.0]
+        pts.sort(key=lambda p: p.centre_hz)
+        out.append(ChannelModalCloudResult(
+            channel_name=str(name), sample_rate_hz=int(sample_rate_hz),
+            analysis_start_sample_index=int(dev["starts"][i]), analysis_length_samples=int(dev["lens"][i]),
+            metric=dev["metric"], points=pts,
+        ))
+    return out
+
+
+def modal_cloud_device(eng, batch, sample_rate_hz: int, settings: ModalCloudAnalysisSettings):
+    """Device-resident modal cloud: per-(channel, log bin) fit records stay in HBM."""
     starts, lens, nframes = select_stft_segments(eng, batch, sample_rate_hz, settings, "modal cloud")
     n_fft, hop = int(settings.n_fft), int(settings.hop_length)
     metric = str(settings.metric).lower()
@@ -133,17 +155,8 @@ def analyse_modal_cloud_batch(
                              [(hi_db, max(lo_db, float(settings.fit_lower_limit_db)))], int(settings.min_fit_points),
                              rel_to_peak=True, floor_db=float(settings.floor_db),
                              min_peak_above_floor=float(settings.min_peak_db_above_floor))
-    rec = fits.cpu().numpy().reshape(batch.count, nbins, 8)
-    out = []
-    for i, name in enumerate(channel_names):
-        pts = [ModalPoint(centre_hz=float(centres[b]), rt60_seconds=float(rec[i, b, 6]), r_squared=float(rec[i, b, 5]))
-               for b in range(nbins) if rec[i, b, 0] == 1.0]
-        pts.sort(key=lambda p: p.centre_hz)
-        out.append(ChannelModalCloudResult(
-            channel_name=str(name), sample_rate_hz=int(sample_rate_hz), analysis_start_sample_index=int(starts[i]),
-            analysis_length_samples=int(lens[i]), metric=metric, points=pts,
-        ))
-    return out
+    return dict(fits=fits, centres=centres, nbins=nbins, starts=starts, lens=lens, metric=metric, curves=curves,
+                cols=cols)
 
 
 def analyse_modal_cloud_for_channel(

@@ -173,10 +173,35 @@ def analyse_rt60_bands_batch(
     settings: Rt60BandsAnalysisSettings,
 ) -> List[Rt60BandsChannelResult]:
     eng = get_engine()
-    t = eng.torch
-    dec = settings.decay_settings
     chans = [c.astype(np.float32, copy=False) for c in channels]
     batch = eng.upload(chans)
+    bands, values, have = rt60_bands_device(eng, batch, sample_rate_hz, settings)
+
+    def opt(v):
+        return None if np.isnan(v) else float(v)
+
+    out = []
+    for c, name in enumerate(channel_names):
+        metrics: Dict[str, Rt60BandMetrics] = {}
+        for b, band in enumerate(bands):
+            if not have[c, b]:
+                metrics[band.name] = Rt60BandMetrics(None, None, None)
+            else:
+                metrics[band.name] = Rt60BandMetrics(opt(values[c, b, 0]), opt(values[c, b, 1]), opt(values[c, b, 2]))
+        out.append(Rt60BandsChannelResult(channel_name=name, sample_rate_hz=sample_rate_hz,
+                                          band_definitions=list(bands), band_metrics_by_name=metrics))
+    return out
+
+
+def rt60_bands_device(eng, batch, sample_rate_hz: int, settings: Rt60BandsAnalysisSettings):
+    """
+    Filter bank + per-band decay fits for a device-resident batch.
+    Returns (bands, values (nch, nbands, 3) float64 [t30, t20, edt; NaN = no fit], have (nch, nbands) bool).
+    """
+    t = eng.torch
+    dec = settings.decay_settings
+    if dec.edc_smoothing_window_samples and dec.edc_smoothing_window_samples > 1:
+        raise NotImplementedError("edc_smoothing_window_samples > 1 is not supported in the band filter bank")
     nch = batch.count
     n_all = batch.length
     if np.any(n_all < 8):
@@ -245,8 +270,6 @@ def analyse_rt60_bands_batch(
         if np.any(seg_len_a < 4):
             raise ValueError("Not enough samples after trimming/ignoring to compute EDC.")
         edc, edc_off = eng.edc_db(y, seg_off_a, seg_len_a, dec.edc_epsilon, dec.edc_floor_db)
-        if dec.edc_smoothing_window_samples and dec.edc_smoothing_window_samples > 1:
-            raise NotImplementedError("edc_smoothing_window_samples > 1 is not supported in the band filter bank")
         fit_dev, _ = eng.curve_fits(edc, edc_off, seg_len_a, 1.0, float(sample_rate_hz), ranges, 8)
         fit = fit_dev.cpu().numpy()
         for s, (c, b) in enumerate(zip(seg_c, seg_b)):
@@ -255,20 +278,7 @@ def analyse_rt60_bands_batch(
                 if fit[s, j, 0] == 1.0:
                     values[c, b, {"t30": 0, "t20": 1, "edt": 2}[key]] = fit[s, j, 6]
 
-    def opt(v):
-        return None if np.isnan(v) else float(v)
-
-    out = []
-    for c, name in enumerate(channel_names):
-        metrics: Dict[str, Rt60BandMetrics] = {}
-        for b, band in enumerate(bands):
-            if not have[c, b]:
-                metrics[band.name] = Rt60BandMetrics(None, None, None)
-            else:
-                metrics[band.name] = Rt60BandMetrics(opt(values[c, b, 0]), opt(values[c, b, 1]), opt(values[c, b, 2]))
-        out.append(Rt60BandsChannelResult(channel_name=name, sample_rate_hz=sample_rate_hz,
-                                          band_definitions=list(bands), band_metrics_by_name=metrics))
-    return out
+    return bands, values, have
 
 
 def analyse_rt60_bands_for_channel(

@@ -74,6 +74,15 @@ def select_stft_segments(eng, batch, sample_rate_hz: int, settings, what: str):
     return starts, lens, nframes
 
 
+def spectrogram_device(eng, batch, sample_rate_hz: int, settings: "SpectrogramAnalysisSettings"):
+    """Device-resident spectrograms: flat float32 buffer of C-contiguous (F, T_i) matrices."""
+    starts, lens, nframes = select_stft_segments(eng, batch, sample_rate_hz, settings, "spectrogram")
+    mag, mag_off, cols = eng.stft_mag_db(batch.x, batch.off + starts, nframes, int(settings.n_fft),
+                                         int(settings.hop_length), bool(settings.use_hann_window),
+                                         float(settings.floor_db), stft_precision())
+    return dict(mag=mag, mag_off=mag_off, cols=cols, starts=starts, lens=lens)
+
+
 def analyse_spectrogram_batch(
     channels: Sequence[np.ndarray],
     sample_rate_hz: int,
@@ -85,10 +94,9 @@ def analyse_spectrogram_batch(
             raise ValueError("analyse_spectrogram_for_channel expects a 1D mono array.")
     eng = get_engine()
     batch = eng.upload(list(channels))
-    starts, lens, nframes = select_stft_segments(eng, batch, sample_rate_hz, settings, "spectrogram")
+    dev = spectrogram_device(eng, batch, sample_rate_hz, settings)
+    out, out_off, cols, starts, lens = dev["mag"], dev["mag_off"], dev["cols"], dev["starts"], dev["lens"]
     n_fft, hop = int(settings.n_fft), int(settings.hop_length)
-    out, out_off, cols = eng.stft_mag_db(batch.x, batch.off + starts, nframes, n_fft, hop,
-                                         bool(settings.use_hann_window), float(settings.floor_db), stft_precision())
     host = out.cpu().numpy()
     f = n_fft // 2 + 1
     freq = np.fft.rfftfreq(n_fft, d=1.0 / float(sample_rate_hz)).astype(np.float32)

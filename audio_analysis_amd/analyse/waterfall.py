@@ -101,6 +101,24 @@ def analyse_waterfall_batch(
 ) -> List[ChannelWaterfallResult]:
     eng = get_engine()
     batch = eng.upload(list(channels))
+    dev = waterfall_device(eng, batch, sample_rate_hz, settings)
+    rel_host = dev["rel"].cpu().numpy()
+    out = []
+    for i, name in enumerate(channel_names):
+        s, nsel = int(dev["cols"][i]), dev["nsel"]
+        ft = frame_time_axis(int(dev["nframes"][i]), int(settings.hop_length), sample_rate_hz)
+        o = int(dev["rel_off"][i])
+        out.append(ChannelWaterfallResult(
+            channel_name=str(name), sample_rate_hz=int(sample_rate_hz),
+            analysis_start_sample_index=int(dev["starts"][i]), analysis_length_samples=int(dev["lens"][i]),
+            slice_times_seconds=ft[dev["picks"][i]].astype(np.float32), frequency_hz=dev["f_sel"],
+            slice_magnitude_rel_db=rel_host[o : o + s * nsel].reshape(s, nsel).copy(),
+        ))
+    return out
+
+
+def waterfall_device(eng, batch, sample_rate_hz: int, settings: WaterfallAnalysisSettings):
+    """Device-resident waterfall: (S_i, nsel) relative-dB slice blocks in one flat float32 buffer."""
     starts, lens, nframes = select_stft_segments(eng, batch, sample_rate_hz, settings, "waterfall")
     n_fft, hop = int(settings.n_fft), int(settings.hop_length)
     picks = []
@@ -137,17 +155,8 @@ def analyse_waterfall_batch(
     dyn = float(max(10.0, settings.dynamic_range_db))
     rel, rel_off = eng.waterfall_rel(mag, mag_off, cols, k_lo, nsel,
                                      str(settings.db_reference).lower() == "slice_max", dyn)
-    rel_host = rel.cpu().numpy()
-    out = []
-    for i, name in enumerate(channel_names):
-        s = int(cols[i])
-        ft = frame_time_axis(int(nframes[i]), hop, sample_rate_hz)
-        out.append(ChannelWaterfallResult(
-            channel_name=str(name), sample_rate_hz=int(sample_rate_hz), analysis_start_sample_index=int(starts[i]),
-            analysis_length_samples=int(lens[i]), slice_times_seconds=ft[picks[i]].astype(np.float32),
-            frequency_hz=f_sel, slice_magnitude_rel_db=rel_host[rel_off[i] : rel_off[i] + s * nsel].reshape(s, nsel).copy(),
-        ))
-    return out
+    return dict(rel=rel, rel_off=rel_off, cols=cols, picks=picks, starts=starts, lens=lens, nframes=nframes,
+                f_sel=f_sel, nsel=nsel)
 
 
 def analyse_waterfall_for_channel(

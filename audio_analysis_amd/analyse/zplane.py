@@ -116,6 +116,14 @@ def analyse_zplane_batch(
     """Numeric body of the reference's plot function for a whole batch of channels."""
     eng = get_engine()
     batch = eng.upload(list(channels))
+    poles, zeros = zplane_device(eng, batch, sample_rate_hz, settings)
+    return [ChannelZPlaneResult(channel_name=name, sample_rate_hz=sample_rate_hz, poles=poles[i],
+                                zeros=zeros[i] if settings.derive_zeros else None)
+            for i, name in enumerate(channel_names)]
+
+
+def zplane_device(eng, batch, sample_rate_hz: int, settings: ZPlaneAnalysisSettings):
+    """AR fit + roots for a device-resident batch; returns host lists (poles, zeros) of complex128 arrays."""
     nch = batch.count
     peaks = eng.peaks(batch) if settings.trim_to_peak else np.zeros(nch, dtype=np.int64)
     skip = int(round(float(settings.ignore_leading_seconds) * sample_rate_hz))
@@ -158,9 +166,7 @@ def analyse_zplane_batch(
             zr, zc = eng.poly_roots(b, int(idx.size), q + 1, 1e-14)
             for k, r in zip(idx, _to_complex(zr, zc)):
                 zeros[k] = r
-    return [ChannelZPlaneResult(channel_name=name, sample_rate_hz=sample_rate_hz, poles=poles[i],
-                                zeros=zeros[i] if settings.derive_zeros else None)
-            for i, name in enumerate(channel_names)]
+    return poles, zeros
 
 
 def plot_zplane_from_wav_file(
