@@ -39,6 +39,8 @@ PROTOTYPES = {
     "ira_waterfall_rel": (i32, [vp, vp, vp, i32, i32, i32, i32, f64, vp, vp, vp]),
     "ira_logbin_aggregate": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp]),
     "ira_ar_partial_doubles": (C.c_int64, [i32, i32]),
+    "ira_ar_gram": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
+    "ira_ar_solve": (i32, [vp, vp, i32, i32, i32, f64, vp, vp, vp, vp]),
     "ira_ar_fit": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f64, vp, vp, vp, vp, vp]),
     "ira_poly_roots": (i32, [vp, i32, i32, f64, vp, vp, vp]),
     "ira_fir_numerator": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, vp, vp]),
@@ -63,6 +65,10 @@ def load():
             f"{_LIB_PATH} not found. The HIP library is the product path and has no fallback; "
             "build it with `python -m audio_analysis_amd.build`."
         )
+    # torch bundles its own libamdhip64; load it FIRST so libira.so resolves to the same HIP runtime instance
+    # (two runtimes in one process do not share devices, streams or allocations).
+    import torch  # noqa: F401
+
     lib = C.CDLL(str(_LIB_PATH))
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing

@@ -376,23 +376,34 @@ extern "C" int64_t ira_ar_partial_doubles(int32_t p, int32_t max_len) {
   return nchunks * groups_total(p) * (int64_t)GR_PART;
 }
 
-extern "C" int32_t ira_ar_fit(const float* x_dev, const double* x64_dev, const int64_t* xoff_dev,
-                              const int32_t* len_dev,
-                              const double* divisor_dev, int32_t nb, int32_t max_len, int32_t order, double ridge,
-                              double* partial_dev, double* gscratch_dev, double* coeffs_dev, double* info_dev,
-                              void* stream) {
+static int32_t ar_check(int32_t nb, int32_t max_len, int32_t order) {
+  if (nb < 0) return IRA_E_SIZE;
+  if (order < 1 || order > GR_MAX_P || max_len <= order) return IRA_E_SIZE;
+  if (nb > 65535 || groups_total(order) > 65535) return IRA_E_SIZE;
+  return IRA_OK;
+}
+
+extern "C" int32_t ira_ar_gram(const float* x_dev, const double* x64_dev, const int64_t* xoff_dev,
+                               const int32_t* len_dev, const double* divisor_dev, int32_t nb, int32_t max_len,
+                               int32_t order, double* partial_dev, void* stream) {
   if (x_dev == nullptr && x64_dev == nullptr) return IRA_E_NULL;
   IRA_CHECK_PTR(xoff_dev); IRA_CHECK_PTR(len_dev); IRA_CHECK_PTR(partial_dev);
-  IRA_CHECK_PTR(coeffs_dev);
-  if (nb <= 0) return nb == 0 ? IRA_OK : IRA_E_SIZE;
-  if (order < 1 || order > GR_MAX_P || max_len <= order) return IRA_E_SIZE;
-  if (order > SV_LDS_P && gscratch_dev == nullptr) return IRA_E_NULL;
-  hipStream_t st = (hipStream_t)stream;
+  const int32_t rc = ar_check(nb, max_len, order);
+  if (rc != IRA_OK || nb == 0) return rc;
   const int nchunks = (int)(((int64_t)max_len - order + GR_CHUNK - 1) / GR_CHUNK);
-  if (nb > 65535 || groups_total(order) > 65535) return IRA_E_SIZE;
-  ar_gram_kernel<<<dim3(nchunks, groups_total(order), nb), 64, 0, st>>>(x64_dev ? nullptr : x_dev, x64_dev, xoff_dev, len_dev,
-                                                                       divisor_dev, order,
-                                                                       nchunks, partial_dev);
+  ar_gram_kernel<<<dim3(nchunks, groups_total(order), nb), 64, 0, (hipStream_t)stream>>>(
+      x64_dev ? nullptr : x_dev, x64_dev, xoff_dev, len_dev, divisor_dev, order, nchunks, partial_dev);
+  IRA_RETURN_LAUNCH();
+}
+
+extern "C" int32_t ira_ar_solve(const double* partial_dev, const int32_t* len_dev, int32_t nb, int32_t max_len,
+                                int32_t order, double ridge, double* gscratch_dev, double* coeffs_dev,
+                                double* info_dev, void* stream) {
+  IRA_CHECK_PTR(partial_dev); IRA_CHECK_PTR(len_dev); IRA_CHECK_PTR(coeffs_dev);
+  const int32_t rc = ar_check(nb, max_len, order);
+  if (rc != IRA_OK || nb == 0) return rc;
+  if (order > SV_LDS_P && gscratch_dev == nullptr) return IRA_E_NULL;
+  const int nchunks = (int)(((int64_t)max_len - order + GR_CHUNK - 1) / GR_CHUNK);
   size_t lds = sizeof(double) * (size_t)order;
   if (order <= SV_LDS_P) lds += sizeof(double) * (size_t)order * order;
   if (lds > 64 * 1024) {
@@ -400,9 +411,18 @@ extern "C" int32_t ira_ar_fit(const float* x_dev, const double* x64_dev, const i
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return ira_hip_status(e);
   }
-  ar_solve_kernel<<<nb, SV_THREADS, lds, st>>>(partial_dev, len_dev, order, nchunks, ridge, gscratch_dev, coeffs_dev,
-                                               info_dev);
+  ar_solve_kernel<<<nb, SV_THREADS, lds, (hipStream_t)stream>>>(partial_dev, len_dev, order, nchunks, ridge,
+                                                                 gscratch_dev, coeffs_dev, info_dev);
   IRA_RETURN_LAUNCH();
+}
+
+extern "C" int32_t ira_ar_fit(const float* x_dev, const double* x64_dev, const int64_t* xoff_dev,
+                              const int32_t* len_dev, const double* divisor_dev, int32_t nb, int32_t max_len,
+                              int32_t order, double ridge, double* partial_dev, double* gscratch_dev,
+                              double* coeffs_dev, double* info_dev, void* stream) {
+  int32_t rc = ira_ar_gram(x_dev, x64_dev, xoff_dev, len_dev, divisor_dev, nb, max_len, order, partial_dev, stream);
+  if (rc != IRA_OK) return rc;
+  return ira_ar_solve(partial_dev, len_dev, nb, max_len, order, ridge, gscratch_dev, coeffs_dev, info_dev, stream);
 }
 
 extern "C" int32_t ira_poly_roots(const double* coeffs_dev, int32_t npoly, int32_t ncoef, double trail_eps,

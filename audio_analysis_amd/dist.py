@@ -1,0 +1,96 @@
+"""
+Multi-GPU: per-file data parallelism + ONE gather of the fixed-width metrics records.
+
+IRs are independent, so the bundle shards embarrassingly: rank r analyses a contiguous block of FILES (both
+channels of a file stay on one GPU) and no collective touches the data path.  The only exchange is a single
+gather of (channels x METRICS_WIDTH) float64 records to rank 0 at the end -- over RCCL/xGMI when the ranks
+hold GPUs (backend "nccl" is RCCL on ROCm), over gloo in the CPU tests.  Large arrays (spectrograms, EDCs)
+are never gathered.  Because there are no cross-IR reductions the gathered records are bit-identical for any
+world size.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+
+def env_world() -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torchrun environment (1 process = 1 GPU)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_process_group(backend: Optional[str] = None):
+    """Initialise torch.distributed when WORLD_SIZE > 1.  Returns (rank, local_rank, world_size)."""
+    import torch
+    import torch.distributed as dist
+
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_files(num_files: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block [lo, hi) of file indices for `rank`: ceil(F/W) files per rank, last ranks may be short."""
+    per = -(-int(num_files) // int(world)) if world > 0 else int(num_files)
+    lo = min(num_files, rank * per)
+    hi = min(num_files, lo + per)
+    return lo, hi
+
+
+def gather_metrics(local: np.ndarray, device=None) -> Optional[np.ndarray]:
+    """
+    Gather per-channel records (n_local, width) float64 from every rank to rank 0, in rank order (= file order
+    under shard_files).  Returns the concatenated array on rank 0 and None elsewhere.  Single process: identity.
+    """
+    import torch
+    import torch.distributed as dist
+
+    local = np.ascontiguousarray(local, dtype=np.float64)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    on_gpu = dist.get_backend() == "nccl"
+    dev = (device or torch.device("cuda", torch.cuda.current_device())) if on_gpu else torch.device("cpu")
+    width = int(local.shape[1])
+    # 1) row counts (so ragged shards are handled), 2) one padded gather of the records
+    counts = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
+    all_counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(all_counts, counts)
+    all_counts = [int(c.item()) for c in all_counts]
+    cap = max(all_counts) if all_counts else 0
+    send = torch.zeros((cap, width), dtype=torch.float64, device=dev)
+    if local.shape[0]:
+        send[: local.shape[0]] = torch.from_numpy(local).to(dev)
+    recv = [torch.empty((cap, width), dtype=torch.float64, device=dev) for _ in range(world)] if rank == 0 else None
+    dist.gather(send, recv, dst=0)
+    if rank != 0:
+        return None
+    return np.concatenate([r[:c].cpu().numpy() for r, c in zip(recv, all_counts)], axis=0)
+
+
+def barrier() -> None:
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    on_gpu = dist.get_backend() == "nccl"
+    dev = (device or torch.device("cuda", torch.cuda.current_device())) if on_gpu else torch.device("cpu")
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -42,6 +42,41 @@ class ChannelBatch:
         return int(self.off.size)
 
 
+class _TimedLib:
+    """
+    Transparent proxy over the ctypes library: when the engine's `events` list is set, every ira_* launch is
+    bracketed by two HIP events recorded on the SAME stream the kernels are enqueued on, so per-call device
+    time can be read back after a synchronise (bench.py's roofline uses this).
+    """
+    _PLAIN = {"ira_error_string", "ira_abi_version", "ira_ar_partial_doubles"}
+
+    def __init__(self, lib, eng):
+        self._lib, self._eng, self._cache = lib, eng, {}
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if name in self._PLAIN or not name.startswith("ira_"):
+            return fn
+        if name not in self._cache:
+            eng = self._eng
+
+            def timed(*args, _fn=fn, _name=name):
+                rec = eng.events
+                if rec is None:
+                    return _fn(*args)
+                t = eng.torch
+                stream = t.cuda.current_stream(eng.device)
+                e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                rc = _fn(*args)
+                e1.record(stream)
+                rec.append((_name + eng.event_tag, e0, e1))
+                return rc
+
+            self._cache[name] = timed
+        return self._cache[name]
+
+
 _ENGINE = None
 
 
@@ -57,7 +92,9 @@ class Engine:
     def __init__(self, device: Optional[str] = None):
         import torch
 
-        self.lib = _lib.load()
+        self.lib = _TimedLib(_lib.load(), self)
+        self.events = None          # list of (name, start_event, end_event) while timing is on
+        self.event_tag = ""
         if not torch.cuda.is_available():
             raise IraError("audio_analysis_amd needs an AMD GPU (torch.cuda.is_available() is False); "
                            "there is no CPU fallback for the product path.")
@@ -69,6 +106,16 @@ class Engine:
     @property
     def stream(self) -> int:
         return int(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def collect_events(self):
+        """Synchronise and return {call name: [milliseconds, ...]} for the launches recorded so far."""
+        self.sync()
+        out = {}
+        for name, e0, e1 in (self.events or []):
+            out.setdefault(name, []).append(float(e0.elapsed_time(e1)))
+        if self.events is not None:
+            self.events = []
+        return out
 
     def sync(self) -> None:
         self.torch.cuda.current_stream(self.device).synchronize()
@@ -201,12 +248,14 @@ class Engine:
             out_off[1:] = np.cumsum(sizes[:-1])
         out = self.empty(int(sizes.sum()), t.float32)
         d_off, d_cols, d_ooff = self.to_dev(seg_off), self.to_dev(cols), self.to_dev(out_off)
+        self.event_tag = f"[f{precision},n{n_fft}{',sel' if frame_sel is not None else ''}]"
         check(self.lib.ira_stft_mag_db(_ptr(x_dev), _ptr(d_off), _ptr(d_cols), n,
                                        int(cols.max()) if n else 0, int(n_fft), int(hop),
                                        _ptr(self.window(n_fft, use_hann, precision)),
                                        _ptr(self.twiddle(n_fft, precision)), int(precision), float(floor_db),
                                        _ptr(out), _ptr(d_ooff), _ptr(sel), _ptr(sel_off_dev),
                                        self.stream), "ira_stft_mag_db")
+        self.event_tag = ""
         return out, out_off, cols
 
     # ------------------------------------------------------------------ a9/a17: arbitrary-length f64 DFTs
@@ -382,9 +431,11 @@ class Engine:
         info = self.empty(n * 3, t.float64)
         d_xo, d_l = self.to_dev(np.ascontiguousarray(xoff, np.int64)), self.to_dev(lengths)
         d_div = self.to_dev(np.ascontiguousarray(divisor, np.float64)) if divisor is not None else None
-        check(self.lib.ira_ar_fit(0 if x_is_f64 else _ptr(x_dev), _ptr(x_dev) if x_is_f64 else 0, _ptr(d_xo), _ptr(d_l),
-                                  _ptr(d_div), n, max_len, int(order), float(ridge),
-                                  _ptr(part), _ptr(gs), _ptr(coeffs), _ptr(info), self.stream), "ira_ar_fit")
+        check(self.lib.ira_ar_gram(0 if x_is_f64 else _ptr(x_dev), _ptr(x_dev) if x_is_f64 else 0, _ptr(d_xo),
+                                   _ptr(d_l), _ptr(d_div), n, max_len, int(order), _ptr(part), self.stream),
+              "ira_ar_gram")
+        check(self.lib.ira_ar_solve(_ptr(part), _ptr(d_l), n, max_len, int(order), float(ridge), _ptr(gs),
+                                    _ptr(coeffs), _ptr(info), self.stream), "ira_ar_solve")
         return coeffs[: n * (order + 1)].view(n, order + 1), info[: n * 3].view(n, 3)
 
     def poly_roots(self, coeffs_dev, npoly: int, ncoef: int, trail_eps: float = 1e-14):

@@ -1,0 +1,176 @@
+"""
+Batched, metrics-only "full report" over a device-resident batch of channels.
+
+One step = every enabled block of the reference's `report` (decay, rt60bands, frequency response,
+spectrogram, waterfall, modal cloud; report.py:252-386) PLUS the separate `filter` and `zplane` commands
+(cli.py:1362-1393, :1562-1593) that BASELINE.json's metric adds, for every channel of the batch.  Large result
+arrays (EDC curves, spectrograms, waterfall slices, log-bin curves, spectra, band signals) are produced in
+HBM and stay there; only the fixed-width per-channel metrics record comes back to the host, which is also
+what is gathered across ranks (audio_analysis_amd.dist).  PNG rendering is excluded (78 % of the reference's
+report time is matplotlib).  Group delay and diffusion
+are not part of the step.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field, replace
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from .analyse import decay as _decay
+from .analyse import filterplot as _filter
+from .analyse import frequency_response as _fr
+from .analyse import modalcloud as _modal
+from .analyse import rt60bands as _bands
+from .analyse import spectrogram as _spec
+from .analyse import waterfall as _wf
+from .analyse import zplane as _zp
+from .engine import ChannelBatch, Engine
+
+# ---- metrics record layout (float64 per channel) ----------------------------------------------------------
+MAX_BANDS = 26
+M_STATUS, M_NSAMPLES, M_START, M_EARLY10 = 0, 1, 2, 3
+M_FIT_EDT, M_FIT_T20, M_FIT_T30 = 4, 12, 20                 # 8 doubles each (ira_curve_fits record)
+M_BANDS = 28                                                # MAX_BANDS x (t30, t20, edt)
+M_FR_PEAK, M_FR_CENTROID, M_FILT_PEAK, M_FILT_1K = 106, 107, 108, 109
+M_SPEC_FRAMES, M_WF_SLICES, M_WF_BINS = 110, 111, 112
+M_MODAL_POINTS, M_MODAL_MEDIAN, M_MODAL_P90, M_MODAL_MAX = 113, 114, 115, 116
+M_AR_POLES, M_AR_MAX_R, M_AR_MEDIAN_R, M_AR_UNSTABLE = 117, 118, 119, 120
+M_NBANDS = 121
+METRICS_WIDTH = 128
+
+
+@dataclass(frozen=True)
+class FullReportSettings:
+    sample_rate_hz: int = 48_000
+    run_decay: bool = True
+    run_rt60_bands: bool = True
+    run_frequency_response: bool = True
+    run_filter: bool = True
+    run_spectrogram: bool = True
+    run_waterfall: bool = True
+    run_modal_cloud: bool = True
+    run_zplane: bool = True
+    decay: _decay.DecayAnalysisSettings = _decay.DecayAnalysisSettings()
+    rt60_bands: _bands.Rt60BandsAnalysisSettings = _bands.Rt60BandsAnalysisSettings()
+    frequency_response: _fr.FrequencyResponseAnalysisSettings = _fr.FrequencyResponseAnalysisSettings()
+    filter: _filter.FilterAnalysisSettings = _filter.FilterAnalysisSettings()
+    spectrogram: _spec.SpectrogramAnalysisSettings = _spec.SpectrogramAnalysisSettings()
+    waterfall: _wf.WaterfallAnalysisSettings = _wf.WaterfallAnalysisSettings()
+    modal_cloud: _modal.ModalCloudAnalysisSettings = _modal.ModalCloudAnalysisSettings()
+    zplane: _zp.ZPlaneAnalysisSettings = _zp.ZPlaneAnalysisSettings(ar_order=64)
+
+    def blocks(self) -> List[str]:
+        names = []
+        for flag, label in (("run_decay", "decay"), ("run_rt60_bands", f"rt60bands[{self.rt60_bands.band_mode}]"),
+                            ("run_frequency_response", "fr"), ("run_filter", "filter"),
+                            ("run_spectrogram", f"spectrogram[{self.spectrogram.n_fft}/{self.spectrogram.hop_length}]"),
+                            ("run_waterfall", "waterfall"),
+                            ("run_modal_cloud", f"modalcloud[{self.modal_cloud.n_fft}/{self.modal_cloud.hop_length}]"),
+                            ("run_zplane", f"zplane[ar{self.zplane.ar_order}]")):
+            if getattr(self, flag):
+                names.append(label)
+        return names
+
+
+def _same_spectrum(a, b) -> bool:
+    """fr and filter analyse the identical windowed segment when these fields agree -> share one rFFT."""
+    keys = ("trim_to_peak", "ignore_leading_seconds", "analysis_duration_seconds", "use_hann_window",
+            "magnitude_floor_db", "f_min_hz", "f_max_hz")
+    return all(getattr(a, k) == getattr(b, k) for k in keys)
+
+
+class FullReport:
+    """Runs the metrics-only report over a ChannelBatch; keeps the big arrays of the last step on the device."""
+
+    def __init__(self, engine: Engine, settings: Optional[FullReportSettings] = None):
+        self.eng = engine
+        self.s = settings or FullReportSettings()
+        self.device_results: Dict[str, dict] = {}
+
+    def run(self, batch: ChannelBatch) -> np.ndarray:
+        eng, s, sr = self.eng, self.s, self.s.sample_rate_hz
+        n = batch.count
+        m = np.full((n, METRICS_WIDTH), np.nan, dtype=np.float64)
+        m[:, M_STATUS] = 0.0
+        m[:, M_NSAMPLES] = batch.length
+        eng.peaks(batch)                                   # the one host round trip every block's geometry needs
+        res: Dict[str, dict] = {}
+
+        if s.run_decay:
+            d = _decay.decay_device(eng, batch, sr, s.decay)
+            res["decay"] = d
+        if s.run_rt60_bands:
+            bands, values, have = _bands.rt60_bands_device(eng, batch, sr, s.rt60_bands)
+            nb = min(len(bands), MAX_BANDS)
+            m[:, M_NBANDS] = nb
+            if nb:
+                m[:, M_BANDS : M_BANDS + 3 * nb] = values[:, :nb, :].reshape(n, 3 * nb)
+        spectrum = None
+        if s.run_frequency_response:
+            share = s.run_filter and _same_spectrum(s.frequency_response, s.filter)
+            spectrum = _fr.spectrum_device(eng, batch, sr, s.frequency_response, "spectrum", want_phase=share,
+                                           unwrap=bool(s.filter.unwrap_phase), degrees=s.filter.phase_mode == "degrees")
+            res["spectrum"] = spectrum
+        filt = None
+        if s.run_filter:
+            if spectrum is not None and spectrum["phase"] is not None:
+                filt = spectrum
+            else:
+                filt = _fr.spectrum_device(eng, batch, sr, s.filter, "filter response", want_phase=True,
+                                           unwrap=bool(s.filter.unwrap_phase), degrees=s.filter.phase_mode == "degrees")
+                res["filter"] = filt
+        if s.run_spectrogram:
+            sp = _spec.spectrogram_device(eng, batch, sr, s.spectrogram)
+            res["spectrogram"] = sp
+            m[:, M_SPEC_FRAMES] = sp["cols"]
+        if s.run_waterfall:
+            wf = _wf.waterfall_device(eng, batch, sr, s.waterfall)
+            res["waterfall"] = wf
+            m[:, M_WF_SLICES] = wf["cols"]
+            m[:, M_WF_BINS] = wf["nsel"]
+        if s.run_modal_cloud:
+            mc = _modal.modal_cloud_device(eng, batch, sr, s.modal_cloud)
+            res["modal"] = mc
+        if s.run_zplane:
+            poles, _ = _zp.zplane_device(eng, batch, sr, s.zplane)
+            for i, p in enumerate(poles):
+                m[i, M_AR_POLES] = p.size
+                if p.size:
+                    rad = np.abs(p)
+                    m[i, M_AR_MAX_R], m[i, M_AR_MEDIAN_R] = float(rad.max()), float(np.median(rad))
+                    m[i, M_AR_UNSTABLE] = int(np.sum(rad >= 1.0))
+
+        # ---- small device -> host copies (fit records, statistics), then the fixed-width record -----------------
+        if s.run_decay:
+            d = res["decay"]
+            fits = d["fits"].cpu().numpy()
+            cross = d["cross"].cpu().numpy()
+            m[:, M_START] = d["starts"]
+            ok = ~np.isnan(cross[:, 0]) & ~np.isnan(cross[:, 1]) & (cross[:, 1] >= cross[:, 0])
+            m[ok, M_EARLY10] = cross[ok, 1] - cross[ok, 0]
+            slot = {"EDT": M_FIT_EDT, "T20": M_FIT_T20, "T30": M_FIT_T30}
+            for j, (name, _) in enumerate(d["specs"]):
+                m[:, slot[name] : slot[name] + 8] = fits[:, j, :]
+        if spectrum is not None:
+            st = spectrum["stats"].cpu().numpy()
+            m[:, M_FR_PEAK] = st[:, 2]
+            with np.errstate(invalid="ignore", divide="ignore"):
+                m[:, M_FR_CENTROID] = np.where(st[:, 4] > 0.0, st[:, 3] / st[:, 4], st[:, 5])
+            m[st[:, 0] < 1.0, M_STATUS] = 1.0
+        if filt is not None:
+            st = filt["stats"].cpu().numpy() if filt is not spectrum else st
+            m[:, M_FILT_PEAK] = st[:, 2]
+            m[:, M_FILT_1K] = st[:, 7]
+        if s.run_modal_cloud:
+            rec = res["modal"]["fits"].cpu().numpy().reshape(n, res["modal"]["nbins"], 8)
+            valid = rec[:, :, 0] == 1.0
+            m[:, M_MODAL_POINTS] = valid.sum(axis=1)
+            for i in range(n):
+                if valid[i].any():
+                    rt = rec[i, valid[i], 6]
+                    m[i, M_MODAL_MEDIAN] = np.median(rt)
+                    m[i, M_MODAL_P90] = np.percentile(rt, 90)
+                    m[i, M_MODAL_MAX] = rt.max()
+        self.device_results = res
+        return m

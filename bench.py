@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""
+bench.py -- IRs/sec of the metrics-only full report (BASELINE.json metric) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--seconds S]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the full report (decay + rt60bands[three] + fr + filter + spectrogram + waterfall +
+modalcloud + zplane AR(64); PNG rendering, group delay and diffusion excluded -- SURVEY.md section 8d) over
+one batch of B synthetic 48 kHz, S-second mono IRs per GPU that is already resident in HBM, ending with the
+gather of the per-channel metrics records to rank 0 (RCCL when N > 1).  Weak scaling: B per GPU is fixed.
+Rank 0 prints ONE JSON line (contract in the task statement), including
+  "roofline"      for the dominant kernel (largest share of device time in the timed region), measured live with
+                  HIP events recorded on the launch stream,
+  "roofline_stft" for the float32 spectrogram STFT kernel (the north-star HBM gate), same method,
+  "cpu_baseline"  the oracle (NumPy restatement of the reference) timed on this box's host cores on a bounded
+                  sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix peak (not listed in the microarch guide)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CPU baseline (oracle) -- runs in spawned worker processes that never touch the GPU
+# ---------------------------------------------------------------------------------------------------------
+def _cpu_one(args):
+    index, seconds = args
+    import numpy as np  # noqa: F401
+    from audio_analysis_amd.synth import synth_ir
+    from oracle import ira_oracle as O
+    x = synth_ir(index, 0, int(seconds * 48000))
+    t0 = time.perf_counter()
+    O.analyse_decay(x)
+    O.analyse_rt60_bands(x, band_mode="three")
+    O.analyse_frequency_response(x)
+    O.analyse_filter_response(x)
+    O.analyse_spectrogram(x)
+    O.analyse_waterfall(x)
+    O.analyse_modal_cloud(x)
+    O.analyse_zplane(x, ar_order=64)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(seconds: float, budget_s: float = 20.0):
+    import multiprocessing as mp
+    for k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
+        os.environ[k] = "1"
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    workers = max(1, min(cores, 16))
+    ctx = mp.get_context("spawn")
+    t0 = time.perf_counter()
+    with ctx.Pool(workers) as pool:
+        per = pool.map(_cpu_one, [(1000 + i, seconds) for i in range(workers)])
+    wall = time.perf_counter() - t0
+    return {
+        "value": workers / wall, "unit": "IRs/s", "cores": workers, "kind": "port",
+        "sample": f"{workers} synthetic {seconds:g} s IRs, one per worker process (single-threaded NumPy oracle, "
+                  f"same blocks as the GPU step); mean {sum(per)/len(per):.2f} s per IR per core, wall {wall:.1f} s",
+    }
+
+
+# ---------------------------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="IRs per GPU per step")
+    ap.add_argument("--seconds", type=float, default=10.0, help="IR length")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    from audio_analysis_amd import dist as D
+    from audio_analysis_amd.engine import Engine
+    from audio_analysis_amd.pipeline import METRICS_WIDTH, FullReport, FullReportSettings
+    from audio_analysis_amd.synth import synth_ir
+
+    rank, local_rank, world = D.init_process_group()
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    eng = Engine(f"cuda:{local_rank}")
+    settings = FullReportSettings()
+    report = FullReport(eng, settings)
+
+    n = int(a.seconds * 48000)
+    first = rank * a.batch
+    host = np.stack([synth_ir(first + i, 0, n) for i in range(a.batch)])
+    batch = eng.wrap(eng.to_dev(host.reshape(-1)), np.arange(a.batch, dtype=np.int64) * n,
+                     np.full(a.batch, n, dtype=np.int64))
+    del host
+
+    def step():
+        batch.peak = None                      # the peak pick is part of the step
+        m = report.run(batch)
+        return D.gather_metrics(m, eng.device)
+
+    for _ in range(a.warmup):
+        step()
+    D.barrier(); torch.cuda.synchronize()
+    eng.events = []
+    t0 = time.perf_counter()
+    gathered = None
+    for _ in range(a.steps):
+        gathered = step()
+    D.barrier(); torch.cuda.synchronize()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, eng.device)
+    ev = eng.collect_events()
+    eng.events = None
+
+    if rank != 0:
+        return
+    assert gathered is not None and gathered.shape == (a.batch * world, METRICS_WIDTH)
+    total_irs = a.batch * world * a.steps
+    # ---- per-call device time over the timed region -> dominant kernel + rooflines ---------------------------
+    tot = {k: sum(v) for k, v in ev.items()}
+    dev_ms = sum(tot.values())
+    dominant = max(tot, key=tot.get)
+    peaks = np.asarray(batch.peak)
+    L = (n - peaks).astype(np.float64)
+
+    def stft_bytes(nfft, hop):
+        frames = 1 + (L - nfft) // hop
+        return float(np.sum(4.0 * L + 4.0 * (nfft // 2 + 1) * frames))
+
+    def roof(name):
+        avg_ms = tot[name] / len(ev[name])
+        if name.startswith("ira_ar_gram"):
+            p = settings.zplane.ar_order
+            flops = float(np.sum((L - p) * p * (p + 1)))          # symmetric half of 2(L-p)p(p+1)
+            ach = flops / (avg_ms * 1e-3) / 1e12
+            return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "avg_launch_ms": avg_ms, "algorithmic": "(L-p)*p*(p+1) fp64 flop per channel (lower triangle)"}
+        if name.startswith("ira_stft_mag_db[f32"):
+            b = stft_bytes(settings.spectrogram.n_fft, settings.spectrogram.hop_length)
+            what = "4L in + 4*F*T out bytes per channel"
+        elif name.startswith("ira_stft_mag_db[f64,n%d]" % settings.modal_cloud.n_fft):
+            b = stft_bytes(settings.modal_cloud.n_fft, settings.modal_cloud.hop_length)
+            what = "4L in + 4*F*T out bytes per channel"
+        elif name.startswith("ira_edc_db"):
+            b = float(np.sum(8.0 * L)) * (len(ev[name]) and 1)
+            what = "4L in + 4L out bytes per segment (decay launch; band launches carry 3 segments per channel)"
+        else:
+            return {"kernel": name, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": None, "traffic": None, "avg_launch_ms": avg_ms, "algorithmic": "not modelled"}
+        ach = b / (avg_ms * 1e-3) / 1e9
+        return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms, "algorithmic": what}
+
+    stft_name = next((k for k in tot if k.startswith("ira_stft_mag_db[f32")), None)
+    out = {
+        "metric": "IRs/sec full report (STFT+RT60bands+zplane), 48 kHz 10 s IR",
+        "value": total_irs / elapsed,
+        "unit": "IRs/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": 1e3 * elapsed / a.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"metrics-only full report on {a.batch} mono synthetic IRs per GPU, {a.seconds:g} s @ 48 kHz "
+                        f"(SURVEY.md 8d generator), inputs resident in HBM",
+            "blocks": settings.blocks(),
+            "excluded": ["png rendering", "group delay", "diffusion", "ir plots"],
+            "batch_per_gpu": a.batch, "ir_seconds": a.seconds, "parallelism": f"file-sharded dp{world}",
+            "arithmetic": "f64 (EDC scan, long FFTs, modal/waterfall STFT, AR Gram/solve/roots); "
+                          "f32 butterflies for the spectrogram STFT",
+        },
+        "roofline": roof(dominant),
+        "roofline_stft": roof(stft_name) if stft_name else None,
+        "device_ms_per_step_by_call": {k: v / a.steps for k, v in sorted(tot.items(), key=lambda kv: -kv[1])},
+        "device_ms_per_step": dev_ms / a.steps,
+    }
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a.seconds)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -188,6 +188,13 @@ int32_t ira_logbin_aggregate(const float* mag_dev, const int64_t* mag_off_dev, c
  * doubles, only needed when order > 128; info_dev (optional): 3 doubles per element
  * [0] 1 if a Cholesky pivot was not positive, [1] largest, [2] smallest pivot.  1 <= order <= 1024 < len. */
 int64_t ira_ar_partial_doubles(int32_t order, int32_t max_len);
+/* The two halves of ira_ar_fit, callable separately: the MFMA Gram contraction, and reduce + Cholesky solve. */
+int32_t ira_ar_gram(const float* x_dev, const double* x64_dev, const int64_t* xoff_dev,
+                    const int32_t* len_dev, const double* divisor_dev, int32_t nb, int32_t max_len,
+                    int32_t order, double* partial_dev, void* stream);
+int32_t ira_ar_solve(const double* partial_dev, const int32_t* len_dev, int32_t nb, int32_t max_len,
+                     int32_t order, double ridge, double* gscratch_dev, double* coeffs_dev,
+                     double* info_dev, void* stream);
 int32_t ira_ar_fit(const float* x_dev, const double* x64_dev, const int64_t* xoff_dev,
                    const int32_t* len_dev, const double* divisor_dev, int32_t nb, int32_t max_len, int32_t order, double ridge,
                    double* partial_dev, double* gscratch_dev, double* coeffs_dev, double* info_dev,
