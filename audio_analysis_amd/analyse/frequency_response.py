@@ -131,7 +131,11 @@ def analyse_frequency_response_batch(
             raise ValueError("analyse_frequency_response_for_channel expects a 1D mono array.")
     eng = get_engine()
     batch = eng.upload(list(channels))
-    dev = spectrum_device(eng, batch, sample_rate_hz, settings, "spectrum")
+    return frequency_response_results(spectrum_device(eng, batch, sample_rate_hz, settings, "spectrum"),
+                                      sample_rate_hz, channel_names, settings)
+
+
+def frequency_response_results(dev, sample_rate_hz: int, channel_names, settings) -> List[ChannelFrequencyResponse]:
     starts, lens, off, mag, f_lo, f_hi = dev["starts"], dev["lens"], dev["off"], dev["mag"], dev["f_lo"], dev["f_hi"]
     nyq = 0.5 * float(sample_rate_hz)
     smoothing = bool(settings.smoothing_log_bins and int(settings.smoothing_log_bins) > 1)

@@ -176,7 +176,10 @@ def analyse_rt60_bands_batch(
     chans = [c.astype(np.float32, copy=False) for c in channels]
     batch = eng.upload(chans)
     bands, values, have = rt60_bands_device(eng, batch, sample_rate_hz, settings)
+    return rt60_bands_results(bands, values, have, sample_rate_hz, channel_names)
 
+
+def rt60_bands_results(bands, values, have, sample_rate_hz: int, channel_names) -> List[Rt60BandsChannelResult]:
     def opt(v):
         return None if np.isnan(v) else float(v)
 

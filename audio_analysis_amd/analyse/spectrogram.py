@@ -94,7 +94,12 @@ def analyse_spectrogram_batch(
             raise ValueError("analyse_spectrogram_for_channel expects a 1D mono array.")
     eng = get_engine()
     batch = eng.upload(list(channels))
-    dev = spectrogram_device(eng, batch, sample_rate_hz, settings)
+    return spectrogram_results(spectrogram_device(eng, batch, sample_rate_hz, settings), sample_rate_hz,
+                               channel_names, settings)
+
+
+def spectrogram_results(dev, sample_rate_hz: int, channel_names, settings) -> List[ChannelSpectrogramResult]:
+    """Device -> host copy of the (F, T) matrices and result dataclasses."""
     out, out_off, cols, starts, lens = dev["mag"], dev["mag_off"], dev["cols"], dev["starts"], dev["lens"]
     n_fft, hop = int(settings.n_fft), int(settings.hop_length)
     host = out.cpu().numpy()

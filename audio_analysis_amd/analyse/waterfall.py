@@ -101,7 +101,11 @@ def analyse_waterfall_batch(
 ) -> List[ChannelWaterfallResult]:
     eng = get_engine()
     batch = eng.upload(list(channels))
-    dev = waterfall_device(eng, batch, sample_rate_hz, settings)
+    return waterfall_results(waterfall_device(eng, batch, sample_rate_hz, settings), sample_rate_hz, channel_names,
+                             settings)
+
+
+def waterfall_results(dev, sample_rate_hz: int, channel_names, settings) -> List[ChannelWaterfallResult]:
     rel_host = dev["rel"].cpu().numpy()
     out = []
     for i, name in enumerate(channel_names):

@@ -30,8 +30,9 @@ from scipy.io import wavfile
 HERE = Path(__file__).resolve().parent
 REPO = HERE.parent.parent
 sys.path.insert(0, str(REPO))
-if "/root/reference" not in sys.path:
-    sys.path.insert(0, "/root/reference")
+# the REFERENCE's `analyse` package must win over this repo's import-name shim of the same name
+sys.path[:] = [p for p in sys.path if p.rstrip("/") != "/root/reference"]
+sys.path.insert(0, "/root/reference")
 os.environ.setdefault("MPLBACKEND", "Agg")
 
 from audio_analysis_amd.synth import synth_ir  # noqa: E402
@@ -302,6 +303,36 @@ def main():
     fres = rfilt.analyse_filter_response_from_wav_file(tmp / "stereo16.wav", rfilt.FilterAnalysisSettings())
     rep["stereo16/filter"] = dict(summary=rfilt.summarise_filter_response_results_text(fres))
     META["cases"]["report"] = rep
+
+    # ---------------- CLI surface (flag spellings, dests, defaults) as data ---------------------------------
+    import argparse
+    import analyse.cli as rcli
+    grabbed = {}
+    real_parse = argparse.ArgumentParser.parse_args
+
+    def _grab(self, *a, **k):
+        grabbed["parser"] = self
+        raise SystemExit
+
+    argparse.ArgumentParser.parse_args = _grab
+    try:
+        rcli.parse_arguments()
+    except SystemExit:
+        pass
+    finally:
+        argparse.ArgumentParser.parse_args = real_parse
+    sub = [a for a in grabbed["parser"]._actions if isinstance(a, argparse._SubParsersAction)][0]
+    surface = {}
+    for name, sp in sub.choices.items():
+        rows = []
+        for act in sp._actions:
+            if act.dest == "help":
+                continue
+            rows.append(dict(flags=list(act.option_strings), dest=act.dest, kind=type(act).__name__,
+                             type=getattr(act.type, "__name__", None), default=act.default, required=bool(act.required),
+                             choices=list(act.choices) if act.choices else None))
+        surface[name] = rows
+    META["cases"]["cli_surface"] = surface
 
     np.savez_compressed(HERE / "goldens.npz", **ARR)
     (HERE / "goldens.json").write_text(json.dumps(META, indent=1, sort_keys=True))

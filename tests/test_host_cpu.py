@@ -1,0 +1,235 @@
+"""
+CPU-only tests (run with -m "not gpu"): the C-ABI library loads and exports every declared symbol, host-side
+integer/index logic matches the oracle and the goldens, the CLI surface matches the reference's, the product
+path refuses to run without a GPU, and the multi-rank metrics gather is rank-count invariant (gloo, world 2).
+"""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import ira_oracle as O
+
+REPO = Path(__file__).resolve().parent.parent
+SR = 48000
+
+
+# ---------------------------------------------------------------------------------------- C-ABI
+def _declared():
+    text = (REPO / "include" / "ira.h").read_text()
+    return sorted(set(re.findall(r"\b(ira_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    from audio_analysis_amd import _lib, build
+    path = build.build()
+    assert path.exists()
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/ira.h but not exported"
+        assert n in _lib.PROTOTYPES, f"{n} has no ctypes prototype"
+    assert set(_lib.PROTOTYPES) == set(names)
+    assert lib.ira_abi_version() == 1
+    assert lib.ira_error_string(0) == b"ok" and b"NULL" in lib.ira_error_string(-1)
+    assert lib.ira_ar_partial_doubles(64, 480000) == 30 * (64 * 64 + 64)   # ceil((480000-64)/16384) chunks
+    assert lib.ira_ar_partial_doubles(64, 10) == 0
+
+
+def test_argument_validation_without_gpu():
+    """Entry points reject bad arguments before touching the device (no compute calls here)."""
+    from audio_analysis_amd import _lib
+    lib = _lib.load()
+    assert lib.ira_peak_index(0, 0, 0, 1, 0, 0, 0) == -1                      # IRA_E_NULL
+    assert lib.ira_stft_mag_db(1, 1, 1, 1, 1, 1000, 512, 1, 1, 32, -120.0, 1, 1, 0, 0, 0) == -2   # n_fft not a power of 2
+    assert lib.ira_stft_mag_db(1, 1, 1, 1, 1, 4096, 512, 1, 1, 16, -120.0, 1, 1, 0, 0, 0) == -3  # precision
+    assert lib.ira_poly_roots(1, 1, 5000, 1e-14, 1, 1, 0) == -2
+    assert lib.ira_ar_gram(1, 0, 1, 1, 0, 1, 100, 2000, 1, 0) == -2
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from audio_analysis_amd._lib import IraError
+    from audio_analysis_amd.analyse import decay
+    with pytest.raises(IraError):
+        decay.analyse_decay_for_channel(np.zeros(100, np.float32), SR, "m", decay.DecayAnalysisSettings())
+
+
+def test_product_never_imports_the_oracle():
+    for py in (REPO / "audio_analysis_amd").rglob("*.py"):
+        text = py.read_text()
+        assert "import oracle" not in text and "from oracle" not in text, py
+
+
+# ---------------------------------------------------------------------------------------- host logic
+def test_segment_bounds_matches_oracle():
+    from audio_analysis_amd.analyse._common import segment_bounds
+    rng = np.random.default_rng(5)
+    for _ in range(500):
+        n = int(rng.integers(1, 100000)); pk = int(rng.integers(0, n))
+        trim = bool(rng.integers(0, 2)); ign = float(rng.choice([0.0, 0.001, 0.0105, 0.5, 3.0]))
+        dur = rng.choice([None, 0.0, 0.01, 0.25, 5.0])
+        dur = None if dur is None else float(dur)
+        assert segment_bounds(n, pk, SR, trim, ign, dur) == O.select_segment(n, pk, SR, trim, ign, dur)
+
+
+def test_io_conversion_and_channel_policy(golden):
+    from audio_analysis_amd.analyse import io
+    g, _, _ = golden
+    for k in ("i16", "i32", "f32"):
+        np.testing.assert_array_equal(io.convert_wav_samples_to_float32(g[f"io/{k}"]), g[f"io/{k}_f32"])
+    st = np.stack([g["in/xs_l"], g["in/xs_r"]], axis=1)
+    la = io.LoadedAudio(samples=st, sample_rate_hz=SR, file_path=Path("x.wav"))
+    ch = io.get_analysis_channels(la, True)
+    assert ch[0][0] == "mono"
+    np.testing.assert_array_equal(ch[0][1], g["io/downmix"])
+    assert [n for n, _ in io.get_analysis_channels(la, False)] == ["left", "right"]
+    with pytest.raises(ValueError):
+        io.validate_audio_format(io.LoadedAudio(st, 44100, Path("x.wav")), 48000, "stereo")
+    with pytest.raises(ValueError):
+        io.convert_wav_samples_to_float32(np.zeros(4, np.int8))
+
+
+def test_wav_round_trip(tmp_path, golden):
+    from scipy.io import wavfile
+    from audio_analysis_amd.analyse import io
+    g, _, _ = golden
+    pcm = g["report/stereo16/pcm"]
+    wavfile.write(str(tmp_path / "s.wav"), SR, pcm)
+    la = io.load_wav_file(tmp_path / "s.wav", expected_channel_mode="mono_or_stereo", allow_mono_and_upmix_to_stereo=False)
+    np.testing.assert_array_equal(la.samples, O.pcm_to_float32(pcm))
+    wavfile.write(str(tmp_path / "m.wav"), SR, pcm[:, 0])
+    la = io.load_wav_file(tmp_path / "m.wav")                      # default: stereo expected, mono upmixed
+    assert la.samples.shape[1] == 2 and np.array_equal(la.samples[:, 0], la.samples[:, 1])
+    with pytest.raises(ValueError):
+        io.load_wav_file(tmp_path / "m.wav", expected_channel_mode="stereo", allow_mono_and_upmix_to_stereo=False)
+
+
+def test_band_tables_and_mask_records(golden):
+    from audio_analysis_amd.analyse import rt60bands as rb
+    _, c, _ = golden
+    for mode in ("three", "octave", "third"):
+        got = rb._build_band_definitions(rb.Rt60BandsAnalysisSettings(band_mode=mode), SR)
+        assert [[b.name, b.centre_hz, b.kind, b.low_edge_hz, b.high_edge_hz] for b in got] == c[f"xb/rt60bands/{mode}"]["bands"]
+    assert len(rb._build_band_definitions(rb.Rt60BandsAnalysisSettings(band_mode="third"), SR)) == 26
+    rec = rb.band_mask_record(rb.BandDefinition("Low", 70.0, "lowpass", high_edge_hz=250.0), 1 / 6, 24000.0)
+    assert rec[0] == 1.0 and rec[3] == 250.0 and rec[4] == 250.0 * 2.0 ** (1 / 6)
+    rec = rb.band_mask_record(rb.BandDefinition("x", 1.0, "bandpass", 3000.0, 2000.0), 1 / 6, 24000.0)
+    assert rec[0] == 0.0                                            # inverted edges -> zero mask
+
+
+def test_slice_selection_and_log_bins(golden):
+    from audio_analysis_amd.analyse import modalcloud as mc, waterfall as wf
+    g, c, _ = golden
+    for T, modes in c["slice_select"].items():
+        ft = (np.arange(int(T), dtype=np.float32) * 512.0 / 48000.0).astype(np.float32)
+        assert wf._select_slice_frame_indices(ft, wf.WaterfallAnalysisSettings()).tolist() == modes["auto"]
+        assert wf._select_slice_frame_indices(
+            ft, wf.WaterfallAnalysisSettings(slice_mode="uniform_frames", num_slices=7)).tolist() == modes["uniform_frames"]
+    np.testing.assert_array_equal(mc._build_log_bins(20.0, 20000.0, 24, 24), g["modal/edges"])
+    freq = np.fft.rfftfreq(8192, 1 / 48000.0).astype(np.float32)
+    sel = freq[(freq >= 20.0) & (freq <= 20000.0)]
+    cen, first, count = mc.log_bin_rows(sel, g["modal/edges"])
+    cen_o, first_o, count_o = O.log_bin_membership(sel, g["modal/edges"])
+    np.testing.assert_array_equal(count, count_o)
+    np.testing.assert_array_equal(first[count > 0], first_o[count_o > 0])
+
+
+def test_synth_is_deterministic_and_matches_goldens(golden):
+    from audio_analysis_amd.synth import synth_ir
+    g, _, _ = golden
+    np.testing.assert_array_equal(synth_ir(0, 0, 24000, rt60_seconds=0.15), g["in/xa"])
+    np.testing.assert_array_equal(synth_ir(1, 0, 48000, rt60_seconds=0.32, pcm16_round_trip=True), g["in/xb16"])
+    x = synth_ir(7, 0, 9600)
+    assert x.dtype == np.float32 and abs(np.abs(x).max() - 0.95) < 1e-6 and int(np.argmax(np.abs(x))) == 247
+
+
+def test_summaries_format_without_gpu(golden):
+    """Text formatting of results is pure host code: feed it the golden numbers."""
+    from audio_analysis_amd.analyse import decay
+    _, c, _ = golden
+    case = c["xb/decay"]
+    fits = {k: decay.LinearDecayFit(k, (v[0], v[1]), v[2], v[3], v[4], v[5], v[6], v[7]) for k, v in case["fits"].items()}
+    r = decay.ChannelDecayAnalysis("mono", SR, case["start"], np.zeros(1, np.float32), np.zeros(1, np.float32),
+                                   case["early"], fits)
+    assert decay.summarise_decay_results_text([r]) == case["summary"]
+
+
+# ---------------------------------------------------------------------------------------- CLI surface
+IN_SCOPE = ("zplane", "bundle", "decay", "rt60bands", "fr", "filter", "spectrogram", "waterfall", "modalcloud", "report")
+
+
+def test_cli_surface_matches_reference(golden):
+    import argparse
+    from audio_analysis_amd.analyse import cli
+    _, c, _ = golden
+    sub = [a for a in cli.build_parser()._actions if isinstance(a, argparse._SubParsersAction)][0]
+    for name in IN_SCOPE:
+        mine = {}
+        for act in sub.choices[name]._actions:
+            if act.dest != "help":
+                mine[act.dest] = act
+        ref_rows = c["cli_surface"][name]
+        assert set(mine) == {r["dest"] for r in ref_rows}, name
+        for r in ref_rows:
+            act = mine[r["dest"]]
+            assert list(act.option_strings) == r["flags"], (name, r["dest"])
+            assert type(act).__name__ == r["kind"], (name, r["dest"])
+            assert act.default == r["default"], (name, r["dest"])
+            assert bool(act.required) == r["required"]
+            assert (list(act.choices) if act.choices else None) == r["choices"]
+            assert getattr(act.type, "__name__", None) == r["type"]
+    for name in ("ir", "groupdelay", "diffusion", "deconvolve"):
+        with pytest.raises(SystemExit):
+            cli.main([name])
+
+
+# ---------------------------------------------------------------------------------------- multi-rank
+def test_shard_files_partitions_everything():
+    from audio_analysis_amd.dist import shard_files
+    for f in (0, 1, 7, 8, 9, 65536, 65537):
+        for w in (1, 2, 3, 4, 8):
+            blocks = [shard_files(f, r, w) for r in range(w)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == f
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(w - 1))
+            assert max(hi - lo for lo, hi in blocks) <= -(-f // w) if f else True
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, os.environ["REPO"])
+import numpy as np
+from audio_analysis_amd import dist as D
+rank, local, world = D.init_process_group("gloo")
+full = np.random.default_rng(3).standard_normal((11, 128))
+full[2, 5] = np.nan
+lo, hi = D.shard_files(11, rank, world)
+got = D.gather_metrics(full[lo:hi])
+t = D.max_over_ranks(1.0 + rank)
+D.barrier()
+if rank == 0:
+    assert got.shape == full.shape and got.tobytes() == full.tobytes(), "gather is not byte-identical"
+    assert t == float(world)
+    print("GATHER_OK")
+else:
+    assert got is None
+"""
+
+
+def test_gloo_world2_gather_is_byte_identical(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, REPO=str(REPO), MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "GATHER_OK" in outs[0]
