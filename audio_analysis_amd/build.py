@@ -24,7 +24,10 @@ ARCH = "gfx950"
 SOURCES = {
     "ira_api.hip": [],
     "ira_edc.hip": ["-ffp-contract=off"],
-    "ira_stft.hip": [],
+    # -fno-slp-vectorize: hipcc otherwise packs the complex arithmetic into v_pk_{add,mul,fma}_f32, which issue at
+    # ~3x the cost of the scalar forms on gfx950 (MI355X_MICROARCH.md, "packed f32 VALU ... an anti-lever")
+    "ira_stft.hip": ["-fno-slp-vectorize"],
+    "ira_stft2.hip": ["-fno-slp-vectorize"],
     "ira_fftlong.hip": [],
     "ira_spectrum.hip": ["-ffp-contract=off"],
     "ira_modal.hip": ["-ffp-contract=off"],

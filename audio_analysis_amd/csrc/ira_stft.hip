@@ -4,6 +4,7 @@
 // collecting the TB columns in an LDS tile so that each output row is written as a TB-float run of the
 // C-contiguous (F, T) matrix the reference returns.
 #include <cmath>
+#include <cstdlib>
 
 #include "ira_fft_lds.h"
 
@@ -116,6 +117,12 @@ int32_t launch_stft(const float* x, const int64_t* off, const int32_t* nframes, 
 
 }  // namespace
 
+// register-resident configurations (ira_stft2.hip); IRA_E_UNSUPPORTED = use the generic kernel above
+int32_t ira_stft2_dispatch(const float* x, const int64_t* off, const int32_t* nframes, int32_t nseg,
+                           int32_t max_frames, int32_t n_fft, int32_t hop, const void* window, const void* tw,
+                           int32_t precision, double floor_db, float* out, const int64_t* out_off,
+                           const int32_t* frame_sel, const int64_t* sel_off, hipStream_t st);
+
 extern "C" int32_t ira_stft_mag_db(const float* x_dev, const int64_t* off_dev, const int32_t* nframes_dev,
                                    int32_t nseg, int32_t max_frames, int32_t n_fft, int32_t hop,
                                    const void* window_dev, const void* twiddle_dev, int32_t precision,
@@ -130,6 +137,14 @@ extern "C" int32_t ira_stft_mag_db(const float* x_dev, const int64_t* off_dev, c
   int log2n = 0;
   while ((1 << log2n) < n_fft) ++log2n;
   hipStream_t st = (hipStream_t)stream;
+  if (precision != 32 && precision != 64) return IRA_E_UNSUPPORTED;
+  static const bool force_generic = std::getenv("IRA_STFT_GENERIC") != nullptr;   // A/B switch for benchmarking
+  if (!force_generic) {
+    const int32_t rc = ira_stft2_dispatch(x_dev, off_dev, nframes_dev, nseg, max_frames, n_fft, hop, window_dev,
+                                          twiddle_dev, precision, floor_db, out_dev, out_off_dev, frame_sel_dev,
+                                          sel_off_dev, st);
+    if (rc != IRA_E_UNSUPPORTED) return rc;
+  }
   if (precision == 32)
     return launch_stft<float>(x_dev, off_dev, nframes_dev, nseg, max_frames, log2n, hop, window_dev, twiddle_dev,
                               floor_db, out_dev, out_off_dev, frame_sel_dev, sel_off_dev, st);
