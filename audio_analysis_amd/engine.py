@@ -101,6 +101,7 @@ class Engine:
         self.torch = torch
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self._tables: Dict[Tuple, object] = {}
+        self._filter_pools: Dict[int, dict] = {}
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -288,16 +289,67 @@ class Engine:
             for i in range(0, idx.size, step):
                 yield int(lm), idx[i : i + step]
 
+    # Chirp-filter spectra depend only on (length, log2m): they are PLAN data, like twiddle tables, and are kept in a
+    # small LRU pool of device slots so that repeated lengths (every step of a batch job, every band pair of a
+    # file) do not rebuild them.  filter_cache_bytes = 0 disables the cache.
+    filter_cache_bytes = 8 << 30
+
     def _filters(self, lengths: np.ndarray, log2m: int):
         """Chirp-filter spectra for the distinct lengths in `lengths`; returns (bfilt device, bidx int32 host)."""
         t = self.torch
         uniq, inv = np.unique(lengths.astype(np.int32), return_inverse=True)
         t1, t2, tf = self.long_tables(log2m)
-        bf = self.empty(int(uniq.size) * (2 << log2m), t.float64)
-        d_l = self.to_dev(uniq.astype(np.int32))
-        check(self.lib.ira_bluestein_filter(_ptr(d_l), int(uniq.size), log2m, _ptr(t1), _ptr(t2), _ptr(tf), _ptr(bf),
-                                            self.stream), "ira_bluestein_filter")
-        return bf, inv.astype(np.int32)
+        slot_doubles = 2 << log2m
+        cap = int(self.filter_cache_bytes // (8 * slot_doubles))
+        if cap < uniq.size:                       # does not fit the pool: build a private array for this call
+            bf = self.empty(int(uniq.size) * slot_doubles, t.float64)
+            d_l = self.to_dev(uniq.astype(np.int32))
+            check(self.lib.ira_bluestein_filter(_ptr(d_l), int(uniq.size), log2m, _ptr(t1), _ptr(t2), _ptr(tf),
+                                                _ptr(bf), self.stream), "ira_bluestein_filter")
+            return bf, inv.astype(np.int32)
+        pool = self._filter_pools.get(log2m)
+        if pool is None:
+            pool = dict(buf=self.empty(cap * slot_doubles, t.float64), slot_of={}, length_of=[None] * cap, tick=0,
+                        used=[0] * cap)
+            self._filter_pools[log2m] = pool
+        pool["tick"] += 1
+        tick = pool["tick"]
+        slots = np.empty(uniq.size, dtype=np.int32)
+        missing = []
+        for j, ln in enumerate(uniq.tolist()):
+            s = pool["slot_of"].get(ln)
+            if s is None:
+                missing.append(j)
+            else:
+                slots[j] = s
+                pool["used"][s] = tick
+        if missing:
+            # victims: least recently used slots not needed by this call
+            order = sorted(range(cap), key=lambda s: pool["used"][s])
+            victims = [s for s in order if pool["used"][s] != tick][: len(missing)]
+            for j, s in zip(missing, victims):
+                old_len = pool["length_of"][s]
+                if old_len is not None:
+                    del pool["slot_of"][old_len]
+                ln = int(uniq[j])
+                pool["slot_of"][ln] = s
+                pool["length_of"][s] = ln
+                pool["used"][s] = tick
+                slots[j] = s
+            # build the missing filters slot by slot runs (contiguous slots in one launch where possible)
+            todo = sorted((int(slots[j]), int(uniq[j])) for j in missing)
+            i = 0
+            while i < len(todo):
+                k = i
+                while k + 1 < len(todo) and todo[k + 1][0] == todo[k][0] + 1:
+                    k += 1
+                run = todo[i : k + 1]
+                d_l = self.to_dev(np.array([ln for _, ln in run], dtype=np.int32))
+                dst = pool["buf"][run[0][0] * slot_doubles:]
+                check(self.lib.ira_bluestein_filter(_ptr(d_l), len(run), log2m, _ptr(t1), _ptr(t2), _ptr(tf), _ptr(dst),
+                                                    self.stream), "ira_bluestein_filter")
+                i = k + 1
+        return pool["buf"], slots[inv].astype(np.int32)
 
     def rfft_any(self, x_dev, xoff: np.ndarray, lengths: np.ndarray, use_hann: bool):
         """

@@ -142,6 +142,17 @@ def main():
         frames = 1 + (L - nfft) // hop
         return float(np.sum(4.0 * L + 4.0 * (nfft // 2 + 1) * frames))
 
+    # HBM traffic per launch from the committed PMC profile (profiles/r01_traffic.json: FETCH_SIZE / WRITE_SIZE
+    # collected in separate rocprofv3 --pmc passes of this same command, gfx950 correction applied there)
+    try:
+        traffic_tab = json.load(open(os.path.join(REPO, "profiles", "r01_traffic.json")))["calls"]
+    except Exception:
+        traffic_tab = {}
+
+    def traffic_of(name):
+        t = traffic_tab.get(name)
+        return None if t is None else t["hbm_bytes_per_channel"] * a.batch
+
     def roof(name):
         avg_ms = tot[name] / len(ev[name])
         if name.startswith("ira_ar_gram"):
@@ -149,7 +160,7 @@ def main():
             flops = float(np.sum((L - p) * p * (p + 1)))          # symmetric half of 2(L-p)p(p+1)
             ach = flops / (avg_ms * 1e-3) / 1e12
             return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic_of(name),
                     "avg_launch_ms": avg_ms, "algorithmic": "(L-p)*p*(p+1) fp64 flop per channel (lower triangle)"}
         if name.startswith("ira_stft_mag_db[f32"):
             b = stft_bytes(settings.spectrogram.n_fft, settings.spectrogram.hop_length)
@@ -157,7 +168,17 @@ def main():
         elif name.startswith("ira_stft_mag_db[f64,n%d]" % settings.modal_cloud.n_fft):
             b = stft_bytes(settings.modal_cloud.n_fft, settings.modal_cloud.hop_length)
             what = "4L in + 4*F*T out bytes per channel"
+        elif name.startswith("ira_rfft_any") or name.startswith("ira_band_irfft"):
+            # compulsory traffic of one launch: samples in + half spectrum out (forward) / half spectrum in + two
+            # float32 band signals out (inverse); the three Bluestein passes move ~20x that through L2/HBM today
+            if name.startswith("ira_rfft_any"):
+                b = float(np.sum(4.0 * L + 16.0 * (L // 2 + 1)))
+                what = "4L in + 16(L/2+1) out bytes per channel (3-pass float64 Bluestein moves ~112 MB per channel)"
+            else:
+                b = float(a.batch * 2 * (16.0 * (n // 2 + 1) + 8.0 * n))
+                what = "16(n/2+1) in + 2*4n out bytes per band pair, 2 pairs per channel"
         elif name.startswith("ira_edc_db"):
+
             b = float(np.sum(8.0 * L)) * (len(ev[name]) and 1)
             what = "4L in + 4L out bytes per segment (decay launch; band launches carry 3 segments per channel)"
         else:
@@ -165,7 +186,8 @@ def main():
                     "frac": None, "traffic": None, "avg_launch_ms": avg_ms, "algorithmic": "not modelled"}
         ach = b / (avg_ms * 1e-3) / 1e9
         return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms, "algorithmic": what}
+                "frac": ach / HBM_PEAK_GBS, "traffic": traffic_of(name), "algorithmic_bytes": b,
+                "avg_launch_ms": avg_ms, "algorithmic": what}
 
     stft_name = next((k for k in tot if k.startswith("ira_stft_mag_db[f32")), None)
     out = {
