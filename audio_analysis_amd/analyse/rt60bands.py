@@ -196,10 +196,12 @@ def rt60_bands_results(bands, values, have, sample_rate_hz: int, channel_names) 
     return out
 
 
-def rt60_bands_device(eng, batch, sample_rate_hz: int, settings: Rt60BandsAnalysisSettings):
+def rt60_bands_device(eng, batch, sample_rate_hz: int, settings: Rt60BandsAnalysisSettings, defer: bool = False):
     """
     Filter bank + per-band decay fits for a device-resident batch.
     Returns (bands, values (nch, nbands, 3) float64 [t30, t20, edt; NaN = no fit], have (nch, nbands) bool).
+    With defer=True the device->host copy of the fit records is postponed: the second element is then a
+    zero-argument callable producing `values` (lets a pipeline enqueue more work before synchronising).
     """
     t = eng.torch
     dec = settings.decay_settings
@@ -274,12 +276,20 @@ def rt60_bands_device(eng, batch, sample_rate_hz: int, settings: Rt60BandsAnalys
             raise ValueError("Not enough samples after trimming/ignoring to compute EDC.")
         edc, edc_off = eng.edc_db(y, seg_off_a, seg_len_a, dec.edc_epsilon, dec.edc_floor_db)
         fit_dev, _ = eng.curve_fits(edc, edc_off, seg_len_a, 1.0, float(sample_rate_hz), ranges, 8)
-        fit = fit_dev.cpu().numpy()
-        for s, (c, b) in enumerate(zip(seg_c, seg_b)):
-            have[c, b] = True
+        ci, bi = np.array(seg_c), np.array(seg_b)
+        have[ci, bi] = True
+
+        def finish():
+            fit = fit_dev.cpu().numpy()
             for j, (key, _) in enumerate(fits_spec):
-                if fit[s, j, 0] == 1.0:
-                    values[c, b, {"t30": 0, "t20": 1, "edt": 2}[key]] = fit[s, j, 6]
+                col = {"t30": 0, "t20": 1, "edt": 2}[key]
+                ok = fit[:, j, 0] == 1.0
+                values[ci[ok], bi[ok], col] = fit[ok, j, 6]
+            return values
+
+        if defer:
+            return bands, finish, have
+        finish()
 
     return bands, values, have
 

@@ -126,11 +126,15 @@ def waterfall_device(eng, batch, sample_rate_hz: int, settings: WaterfallAnalysi
     starts, lens, nframes = select_stft_segments(eng, batch, sample_rate_hz, settings, "waterfall")
     n_fft, hop = int(settings.n_fft), int(settings.hop_length)
     picks = []
+    by_count = {}                      # the selection depends only on the frame count (and the settings)
     for i in range(batch.count):
-        idx = _select_slice_frame_indices(frame_time_axis(int(nframes[i]), hop, sample_rate_hz), settings)
-        if idx.size < 2:
-            raise ValueError("Not enough slices selected for waterfall (increase duration or num_slices).")
-        picks.append(idx.astype(np.int32))
+        tcount = int(nframes[i])
+        if tcount not in by_count:
+            idx = _select_slice_frame_indices(frame_time_axis(tcount, hop, sample_rate_hz), settings)
+            if idx.size < 2:
+                raise ValueError("Not enough slices selected for waterfall (increase duration or num_slices).")
+            by_count[tcount] = idx.astype(np.int32)
+        picks.append(by_count[tcount])
     freq = np.fft.rfftfreq(n_fft, d=1.0 / float(sample_rate_hz)).astype(np.float32)
     nyq = float(freq[-1]) if freq.size else 0.0
     f_lo = float(np.clip(settings.f_min_hz, 1.0, nyq))

@@ -122,8 +122,9 @@ def analyse_zplane_batch(
             for i, name in enumerate(channel_names)]
 
 
-def zplane_device(eng, batch, sample_rate_hz: int, settings: ZPlaneAnalysisSettings):
-    """AR fit + roots for a device-resident batch; returns host lists (poles, zeros) of complex128 arrays."""
+def zplane_device(eng, batch, sample_rate_hz: int, settings: ZPlaneAnalysisSettings, defer: bool = False):
+    """AR fit + roots for a device-resident batch; returns host lists (poles, zeros) of complex128 arrays
+    (or, with defer=True, a zero-argument callable producing them after all launches have been enqueued)."""
     nch = batch.count
     peaks = eng.peaks(batch) if settings.trim_to_peak else np.zeros(nch, dtype=np.int64)
     skip = int(round(float(settings.ignore_leading_seconds) * sample_rate_hz))
@@ -151,6 +152,7 @@ def zplane_device(eng, batch, sample_rate_hz: int, settings: ZPlaneAnalysisSetti
     else:
         eff = np.where(seg_len <= order, np.maximum(1, seg_len - 1), order).astype(np.int64)
     ridge = float(settings.ridge_lambda) if settings.ridge_lambda and settings.ridge_lambda > 0.0 else 0.0
+    pending = []
     for p in sorted(set(eff.tolist())):
         if p < 1:
             continue
@@ -158,15 +160,23 @@ def zplane_device(eng, batch, sample_rate_hz: int, settings: ZPlaneAnalysisSetti
         div = None if divisor is None else divisor[idx]
         co, _ = eng.ar_fit(batch.x, seg_off[idx], seg_len[idx], div, int(p), ridge)
         roots, cnt = eng.poly_roots(co, int(idx.size), int(p) + 1, 1e-14)
-        for k, r in zip(idx, _to_complex(roots, cnt)):
-            poles[k] = r
+        zr = zc = None
         if settings.derive_zeros:
             q = int(max(0, settings.zero_order))
             b = eng.fir_numerator(co, int(p), batch.x, seg_off[idx], seg_len[idx], div, q)
             zr, zc = eng.poly_roots(b, int(idx.size), q + 1, 1e-14)
-            for k, r in zip(idx, _to_complex(zr, zc)):
-                zeros[k] = r
-    return poles, zeros
+        pending.append((idx, roots, cnt, zr, zc))
+
+    def finish():
+        for idx, roots, cnt, zr, zc in pending:
+            for k, r in zip(idx, _to_complex(roots, cnt)):
+                poles[k] = r
+            if zr is not None:
+                for k, r in zip(idx, _to_complex(zr, zc)):
+                    zeros[k] = r
+        return poles, zeros
+
+    return finish if defer else finish()
 
 
 def plot_zplane_from_wav_file(

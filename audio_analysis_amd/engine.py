@@ -77,6 +77,10 @@ class _TimedLib:
         return self._cache[name]
 
 
+def _TORCH_DTYPES(t):
+    return {"<i8": t.int64, "<i4": t.int32, "<f8": t.float64, "<f4": t.float32, "|u1": t.uint8, "<i2": t.int16}
+
+
 _ENGINE = None
 
 
@@ -102,6 +106,7 @@ class Engine:
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self._tables: Dict[Tuple, object] = {}
         self._filter_pools: Dict[int, dict] = {}
+        self._ring = None
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -121,8 +126,29 @@ class Engine:
     def sync(self) -> None:
         self.torch.cuda.current_stream(self.device).synchronize()
 
+    # Small host arrays (offsets, lengths, job tables) go through a pinned staging ring and an ASYNC copy: a
+    # pageable .to(device) blocks the host until the stream has drained, which would serialise host and GPU.
+    _RING_BYTES = 32 << 20
+    _ASYNC_LIMIT = 1 << 20
+
     def to_dev(self, a: np.ndarray):
-        return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.device, non_blocking=False)
+        t = self.torch
+        a = np.ascontiguousarray(a)
+        nbytes = a.nbytes
+        if nbytes == 0 or nbytes > self._ASYNC_LIMIT:
+            return t.from_numpy(a).to(self.device, non_blocking=False)
+        if self._ring is None:
+            self._ring = t.empty(self._RING_BYTES, dtype=t.uint8).pin_memory()
+            self._ring_np = self._ring.numpy()
+            self._ring_pos = 0
+        pos = (self._ring_pos + 63) & ~63
+        if pos + nbytes > self._RING_BYTES:
+            self.sync()                      # every copy issued so far has left the ring before it wraps
+            pos = 0
+        self._ring_np[pos : pos + nbytes] = a.view(np.uint8).reshape(-1)
+        self._ring_pos = pos + nbytes
+        src = self._ring[pos : pos + nbytes].view(_TORCH_DTYPES(t)[a.dtype.str]).view(a.shape)
+        return src.to(self.device, non_blocking=True)
 
     def empty(self, n: int, dtype):
         return self.torch.empty(int(max(n, 1)), dtype=dtype, device=self.device)

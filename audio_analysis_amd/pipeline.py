@@ -101,11 +101,8 @@ class FullReport:
             d = _decay.decay_device(eng, batch, sr, s.decay)
             res["decay"] = d
         if s.run_rt60_bands:
-            bands, values, have = _bands.rt60_bands_device(eng, batch, sr, s.rt60_bands)
-            nb = min(len(bands), MAX_BANDS)
-            m[:, M_NBANDS] = nb
-            if nb:
-                m[:, M_BANDS : M_BANDS + 3 * nb] = values[:, :nb, :].reshape(n, 3 * nb)
+            bands, band_values, have = _bands.rt60_bands_device(eng, batch, sr, s.rt60_bands, defer=True)
+            res["rt60bands"] = dict(bands=bands, values=band_values, have=have)
         spectrum = None
         if s.run_frequency_response:
             share = s.run_filter and _same_spectrum(s.frequency_response, s.filter)
@@ -133,15 +130,32 @@ class FullReport:
             mc = _modal.modal_cloud_device(eng, batch, sr, s.modal_cloud)
             res["modal"] = mc
         if s.run_zplane:
-            poles, _ = _zp.zplane_device(eng, batch, sr, s.zplane)
-            for i, p in enumerate(poles):
-                m[i, M_AR_POLES] = p.size
-                if p.size:
-                    rad = np.abs(p)
-                    m[i, M_AR_MAX_R], m[i, M_AR_MEDIAN_R] = float(rad.max()), float(np.median(rad))
-                    m[i, M_AR_UNSTABLE] = int(np.sum(rad >= 1.0))
+            res["zplane"] = dict(finish=_zp.zplane_device(eng, batch, sr, s.zplane, defer=True))
 
         # ---- small device -> host copies (fit records, statistics), then the fixed-width record -----------------
+        # (everything above only ENQUEUED work; the first .cpu() below is where the host waits for the GPU)
+        if s.run_rt60_bands:
+            bands = res["rt60bands"]["bands"]
+            values = res["rt60bands"]["values"]
+            values = values() if callable(values) else values
+            nb = min(len(bands), MAX_BANDS)
+            m[:, M_NBANDS] = nb
+            if nb:
+                m[:, M_BANDS : M_BANDS + 3 * nb] = values[:, :nb, :].reshape(n, 3 * nb)
+        if s.run_zplane:
+            poles, _ = res["zplane"]["finish"]()
+            sizes = np.array([p.size for p in poles])
+            m[:, M_AR_POLES] = sizes
+            if n and sizes.min() == sizes.max() and sizes[0] > 0:
+                rad = np.abs(np.stack(poles))
+                m[:, M_AR_MAX_R], m[:, M_AR_MEDIAN_R] = rad.max(axis=1), np.median(rad, axis=1)
+                m[:, M_AR_UNSTABLE] = (rad >= 1.0).sum(axis=1)
+            else:
+                for i, p in enumerate(poles):
+                    if p.size:
+                        rad = np.abs(p)
+                        m[i, M_AR_MAX_R], m[i, M_AR_MEDIAN_R] = float(rad.max()), float(np.median(rad))
+                        m[i, M_AR_UNSTABLE] = int(np.sum(rad >= 1.0))
         if s.run_decay:
             d = res["decay"]
             fits = d["fits"].cpu().numpy()
@@ -166,11 +180,14 @@ class FullReport:
             rec = res["modal"]["fits"].cpu().numpy().reshape(n, res["modal"]["nbins"], 8)
             valid = rec[:, :, 0] == 1.0
             m[:, M_MODAL_POINTS] = valid.sum(axis=1)
-            for i in range(n):
-                if valid[i].any():
-                    rt = rec[i, valid[i], 6]
-                    m[i, M_MODAL_MEDIAN] = np.median(rt)
-                    m[i, M_MODAL_P90] = np.percentile(rt, 90)
-                    m[i, M_MODAL_MAX] = rt.max()
+            rt = np.where(valid, rec[:, :, 6], np.nan)
+            some = valid.any(axis=1)
+            if some.any():
+                import warnings
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore", category=RuntimeWarning)      # all-NaN rows stay NaN
+                    m[some, M_MODAL_MEDIAN] = np.nanmedian(rt[some], axis=1)
+                    m[some, M_MODAL_P90] = np.nanpercentile(rt[some], 90, axis=1)
+                    m[some, M_MODAL_MAX] = np.nanmax(rt[some], axis=1)
         self.device_results = res
         return m
