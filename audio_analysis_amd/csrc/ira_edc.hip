@@ -55,11 +55,10 @@ __global__ void peak_decode_kernel(unsigned long long* __restrict__ keys, float*
 }
 
 // ------------------------------------------------------------------------------------------------
-// a3: Schroeder EDC.  One 1024-thread workgroup per segment walks 4096-sample tiles from the end of
-// the segment to its start (that is the direction numpy.cumsum(e[::-1]) accumulates in).  Pass 1
-// records the running carry per tile; pass 2 re-scans with the carries, now knowing edc[0], and
-// emits 10*log10(max(edc,eps)/edc[0]) floored, as float32.  Both passes run the SAME scan code so the
-// value used as edc[0] is bit-identical to the value the emit pass produces at index 0 (=> exactly 0 dB).
+// a3: Schroeder EDC.  1024-thread workgroups walk 4096-sample tiles from the END of the segment towards its
+// start (the direction numpy.cumsum(e[::-1]) accumulates in) with a wave-shuffle suffix scan per tile; a first
+// pass collects per-chunk sums, a second re-scans with the carries, now knowing edc[0], and emits
+// 10*log10(max(edc,eps)/edc[0]) floored, as float32.  Both passes run the SAME scan code.
 // ------------------------------------------------------------------------------------------------
 constexpr int EDC_THREADS = 1024;
 constexpr int EDC_PER_THREAD = 4;
@@ -119,40 +118,88 @@ __device__ __forceinline__ double tile_suffix_scan(const float* __restrict__ src
   return total;
 }
 
-__global__ __launch_bounds__(EDC_THREADS) void edc_kernel(
-    const float* __restrict__ x, const int64_t* __restrict__ off, const int64_t* __restrict__ len, double eps,
-    double floor_db, float* __restrict__ out, double* __restrict__ out64, const int64_t* __restrict__ out_off,
+// The scan is split over many workgroups so that a small batch still fills the chip:
+//   edc_sums_kernel   (chunks x segments)  per 16384-sample chunk (4 tiles, counted from the END of the segment):
+//                     chunk total, plus the last tile's total and the local carry in front of it
+//   edc_carry_kernel  (1 thread / segment) sequential carries over the chunks and the normaliser edc[0]
+//   edc_emit_kernel   (chunks x segments)  re-scan with the carries and emit the dB curve
+// Every value is formed as  s + (local_run + chunk_carry)  in all three kernels, so the normaliser is bit-identical
+// to the value the emit pass produces at index 0 (=> edc_db[0] is exactly 0 dB, which the 0 dB crossing needs).
+constexpr int EDC_CHUNK_TILES = 4;
+constexpr int EDC_MAX_CHUNKS = IRA_EDC_SCRATCH_DOUBLES / 4 - 1;   // scratch: totals | last-tile totals | local carries | carries(+norm)
+
+__global__ __launch_bounds__(EDC_THREADS) void edc_sums_kernel(
+    const float* __restrict__ x, const int64_t* __restrict__ off, const int64_t* __restrict__ len,
     double* __restrict__ scratch) {
   __shared__ EdcShared sh;
-  const int seg = blockIdx.x;
+  const int seg = blockIdx.y, chunk = blockIdx.x;
+  const int64_t n = len[seg];
+  const int64_t ntiles = (n + EDC_TILE - 1) / EDC_TILE;
+  const int64_t t0 = (int64_t)chunk * EDC_CHUNK_TILES;
+  if (t0 >= ntiles) return;
+  const float* src = x + off[seg];
+  double* sc = scratch + (int64_t)seg * IRA_EDC_SCRATCH_DOUBLES;
+  double run = 0.0, before = 0.0, tot = 0.0;
+  double s[EDC_PER_THREAD];
+  for (int64_t j = t0; j < t0 + EDC_CHUNK_TILES && j < ntiles; ++j) {
+    const int64_t hi = n - j * EDC_TILE;
+    const int64_t lo = hi - EDC_TILE > 0 ? hi - EDC_TILE : 0;
+    before = run;
+    tot = tile_suffix_scan(src + lo, (int)(hi - lo), sh, s);
+    run = tot + run;
+  }
+  if (threadIdx.x == 0) {
+    const int q = IRA_EDC_SCRATCH_DOUBLES / 4;
+    sc[chunk] = run; sc[q + chunk] = tot; sc[2 * q + chunk] = before;
+  }
+}
+
+__global__ void edc_carry_kernel(const int64_t* __restrict__ len, int nseg, double eps, double* __restrict__ scratch) {
+  const int seg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (seg >= nseg) return;
   const int64_t n = len[seg];
   if (n <= 0) return;
+  const int q = IRA_EDC_SCRATCH_DOUBLES / 4;
+  double* sc = scratch + (int64_t)seg * IRA_EDC_SCRATCH_DOUBLES;
+  const int64_t ntiles = (n + EDC_TILE - 1) / EDC_TILE;
+  const int nchunks = (int)((ntiles + EDC_CHUNK_TILES - 1) / EDC_CHUNK_TILES);
+  double carry = 0.0;
+  for (int c = 0; c < nchunks; ++c) {
+    sc[3 * q + c] = carry;
+    if (c == nchunks - 1) {
+      // edc[0] exactly as the emit pass forms it: last tile's local-0 value + (local carry + chunk carry)
+      const double v = sc[q + c] + (sc[2 * q + c] + carry);
+      sc[4 * q - 1] = fmax(v, eps);
+    }
+    carry = sc[c] + carry;
+  }
+}
+
+__global__ __launch_bounds__(EDC_THREADS) void edc_emit_kernel(
+    const float* __restrict__ x, const int64_t* __restrict__ off, const int64_t* __restrict__ len, double eps,
+    double floor_db, float* __restrict__ out, double* __restrict__ out64, const int64_t* __restrict__ out_off,
+    const double* __restrict__ scratch) {
+  __shared__ EdcShared sh;
+  const int seg = blockIdx.y, chunk = blockIdx.x;
+  const int64_t n = len[seg];
+  const int64_t ntiles = (n + EDC_TILE - 1) / EDC_TILE;
+  const int64_t t0 = (int64_t)chunk * EDC_CHUNK_TILES;
+  if (t0 >= ntiles) return;
   const float* src = x + off[seg];
   float* dst = out ? out + out_off[seg] : nullptr;
   double* dst64 = out64 ? out64 + out_off[seg] : nullptr;
-  double* carry = scratch + (int64_t)seg * IRA_EDC_SCRATCH_DOUBLES;
-  const int64_t ntiles = (n + EDC_TILE - 1) / EDC_TILE;
-  // The first tile (at the START of the segment) is the ragged one, so tile boundaries are aligned to the
-  // end of the segment: tile j (counted from the end) covers [n-(j+1)*TILE, n-j*TILE) clipped at 0.
+  const int q = IRA_EDC_SCRATCH_DOUBLES / 4;
+  const double* sc = scratch + (int64_t)seg * IRA_EDC_SCRATCH_DOUBLES;
+  const double chunk_carry = sc[3 * q + chunk];
+  const double norm = sc[4 * q - 1];
   double run = 0.0;
   double s[EDC_PER_THREAD];
-  for (int64_t j = 0; j < ntiles; ++j) {
-    const int64_t hi = n - j * EDC_TILE;
-    const int64_t lo = hi - EDC_TILE > 0 ? hi - EDC_TILE : 0;
-    if (threadIdx.x == 0) carry[j] = run;
-    const double tot = tile_suffix_scan(src + lo, (int)(hi - lo), sh, s);
-    run = tot + run;
-  }
-  // `run` is now edc[0] exactly as the emit pass will compute it: for the last tile the emit value at local
-  // index 0 is s[0] + carry with s[0] == tot bit-for-bit (same code path), and IEEE addition commutes.
-  const double norm = fmax(run, eps);
-  for (int64_t j = 0; j < ntiles; ++j) {
+  for (int64_t j = t0; j < t0 + EDC_CHUNK_TILES && j < ntiles; ++j) {
     const int64_t hi = n - j * EDC_TILE;
     const int64_t lo = hi - EDC_TILE > 0 ? hi - EDC_TILE : 0;
     const int tl = (int)(hi - lo);
-    // carry[j] was written by this workgroup's thread 0 before a barrier inside tile_suffix_scan
-    const double c = carry[j];
-    (void)tile_suffix_scan(src + lo, tl, sh, s);
+    const double tot = tile_suffix_scan(src + lo, tl, sh, s);
+    const double c = run + chunk_carry;
 #pragma unroll
     for (int r = 0; r < EDC_PER_THREAD; ++r) {
       const int i = EDC_PER_THREAD * threadIdx.x + r;
@@ -172,6 +219,7 @@ __global__ __launch_bounds__(EDC_THREADS) void edc_kernel(
       if (dst && i < tl) dst[lo + i] = sh.stage[i];
     }
     __syncthreads();
+    run = tot + run;
   }
 }
 
@@ -404,14 +452,21 @@ extern "C" int32_t ira_peak_index(const float* x_dev, const int64_t* off_dev, co
 }
 
 extern "C" int32_t ira_edc_db(const float* x_dev, const int64_t* off_dev, const int64_t* len_dev, int32_t nseg,
-                              double eps, double floor_db, float* edc_db_dev, double* edc_db64_dev,
+                              int64_t max_len, double eps, double floor_db, float* edc_db_dev, double* edc_db64_dev,
                               const int64_t* edc_off_dev, double* scratch_dev, void* stream) {
   IRA_CHECK_PTR(x_dev); IRA_CHECK_PTR(off_dev); IRA_CHECK_PTR(len_dev);
   if (edc_db_dev == nullptr && edc_db64_dev == nullptr) return IRA_E_NULL;
   IRA_CHECK_PTR(edc_off_dev); IRA_CHECK_PTR(scratch_dev);
   if (nseg <= 0) return nseg == 0 ? IRA_OK : IRA_E_SIZE;
-  edc_kernel<<<nseg, EDC_THREADS, 0, (hipStream_t)stream>>>(x_dev, off_dev, len_dev, eps, floor_db, edc_db_dev,
-                                                            edc_db64_dev, edc_off_dev, scratch_dev);
+  if (max_len <= 0 || max_len > (int64_t)EDC_MAX_CHUNKS * EDC_CHUNK_TILES * EDC_TILE) return IRA_E_SIZE;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t ntiles = (max_len + EDC_TILE - 1) / EDC_TILE;
+  const int nchunks = (int)((ntiles + EDC_CHUNK_TILES - 1) / EDC_CHUNK_TILES);
+  if (nseg > 65535) return IRA_E_SIZE;
+  edc_sums_kernel<<<dim3(nchunks, nseg), EDC_THREADS, 0, st>>>(x_dev, off_dev, len_dev, scratch_dev);
+  edc_carry_kernel<<<(nseg + 63) / 64, 64, 0, st>>>(len_dev, nseg, eps, scratch_dev);
+  edc_emit_kernel<<<dim3(nchunks, nseg), EDC_THREADS, 0, st>>>(x_dev, off_dev, len_dev, eps, floor_db, edc_db_dev,
+                                                               edc_db64_dev, edc_off_dev, scratch_dev);
   IRA_RETURN_LAUNCH();
 }
 

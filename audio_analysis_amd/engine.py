@@ -208,7 +208,7 @@ class Engine:
         """Schroeder EDC in dB for segments of x_dev.  Returns (edc flat f32 device, edc_off host int64[, f64])."""
         t = self.torch
         n = int(seg_off.size)
-        if np.any(seg_len > EDC_SCRATCH_DOUBLES * EDC_TILE):
+        if np.any(seg_len > 511 * 4 * EDC_TILE):
             raise ValueError("segment too long for the EDC kernel (> 8.3 M samples)")
         edc_off = np.zeros(n, dtype=np.int64)
         if n > 1:
@@ -219,7 +219,8 @@ class Engine:
         # NOTE: device temporaries must stay referenced until the call is enqueued (the caching allocator
         # would otherwise hand the same block to the next to_dev()).
         d_off, d_len, d_eoff = self.to_dev(seg_off), self.to_dev(seg_len), self.to_dev(edc_off)
-        check(self.lib.ira_edc_db(_ptr(x_dev), _ptr(d_off), _ptr(d_len), n, float(eps), float(floor_db), _ptr(out),
+        check(self.lib.ira_edc_db(_ptr(x_dev), _ptr(d_off), _ptr(d_len), n, int(seg_len.max()), float(eps),
+                                  float(floor_db), _ptr(out),
                                   _ptr(out64), _ptr(d_eoff), _ptr(scratch), self.stream), "ira_edc_db")
         if want_f64:
             return out, edc_off, out64

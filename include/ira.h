@@ -50,10 +50,11 @@ int32_t ira_peak_index(const float* x_dev, const int64_t* off_dev, const int64_t
  * (edc_off_dev).  Replaces compute_schroeder_edc_db, reference analyse/decay.py:115-170
  * edc_db64_dev (optional, may be NULL): the same curve as float64 BEFORE the floor, for the optional
  * host-side dB smoothing of decay.py:161-164.  edc_db_dev may be NULL if only that is wanted.
- * scratch_dev: nseg * IRA_EDC_SCRATCH_DOUBLES doubles.  Segments up to 2048*4096 samples. */
+ * max_len = longest segment (sizes the grid; up to 511*16384 samples).
+ * scratch_dev: nseg * IRA_EDC_SCRATCH_DOUBLES doubles. */
 #define IRA_EDC_SCRATCH_DOUBLES 2048
 int32_t ira_edc_db(const float* x_dev, const int64_t* off_dev, const int64_t* len_dev, int32_t nseg,
-                   double eps, double floor_db, float* edc_db_dev, double* edc_db64_dev,
+                   int64_t max_len, double eps, double floor_db, float* edc_db_dev, double* edc_db64_dev,
                    const int64_t* edc_off_dev, double* scratch_dev, void* stream);
 
 /* ---- a4/a5/a16: threshold crossings + straight-line decay fits on a float32 dB curve -------------
