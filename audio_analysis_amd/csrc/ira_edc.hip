@@ -341,28 +341,44 @@ __global__ void curve_fit_kernel(const float* __restrict__ ybase, const int64_t*
   }
   __syncthreads();
   float targets[FIT_MAX_TARGETS];
-  long long first[FIT_MAX_TARGETS];
 #pragma unroll
-  for (int k = 0; k < FIT_MAX_TARGETS; ++k) { targets[k] = (float)sh.tgt[k]; first[k] = n; }
-  for (long long i = tid; i < n; i += nt) {
-    const float v = y[i] - peak;
+  for (int k = 0; k < FIT_MAX_TARGETS; ++k) targets[k] = (float)sh.tgt[k];
+  // Swept in blocks with an early exit: once every target has a crossing, later samples cannot change any FIRST
+  // crossing index, so the rest of the curve need not be read (for an EDC the -35 dB point sits in the first
+  // few percent of a 10 s curve).  A target that is never reached still scans to the end, like the reference.
+  constexpr int SWEEP_U = 8;
+  for (long long base = 0; base < n; base += (long long)nt * SWEEP_U) {
+    long long first[FIT_MAX_TARGETS];
 #pragma unroll
-    for (int k = 0; k < FIT_MAX_TARGETS; ++k)
-      if (k < ntargets && v <= targets[k] && i < first[k]) first[k] = i;
-  }
+    for (int k = 0; k < FIT_MAX_TARGETS; ++k) first[k] = n;
 #pragma unroll
-  for (int k = 0; k < FIT_MAX_TARGETS; ++k) {
-    if (k < ntargets) {
-      long long f = first[k];
+    for (int u = 0; u < SWEEP_U; ++u) {
+      const long long i = base + tid + (long long)nt * u;
+      if (i < n) {
+        const float v = y[i] - peak;
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const long long other = __shfl_xor(f, o, 64);
-        f = other < f ? other : f;
+        for (int k = 0; k < FIT_MAX_TARGETS; ++k)
+          if (k < ntargets && v <= targets[k] && i < first[k]) first[k] = i;
       }
-      if ((tid & 63) == 0) atomicMin(&sh.idx[k], f);
     }
+#pragma unroll
+    for (int k = 0; k < FIT_MAX_TARGETS; ++k) {
+      if (k < ntargets) {
+        long long f = first[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const long long other = __shfl_xor(f, o, 64);
+          f = other < f ? other : f;
+        }
+        if ((tid & 63) == 0 && f < n) atomicMin(&sh.idx[k], f);
+      }
+    }
+    __syncthreads();
+    bool all_found = true;
+    for (int k = 0; k < ntargets; ++k) all_found = all_found && (sh.idx[k] < n);
+    __syncthreads();
+    if (all_found) break;
   }
-  __syncthreads();
   const double* targets_d = sh.tgt;
 
   if (co && tid == 0) {
