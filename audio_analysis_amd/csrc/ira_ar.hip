@@ -23,7 +23,7 @@ namespace {
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int GR_KC = 1024;       // rows (samples n) staged in LDS per tile
-constexpr int GR_CHUNK = 16384;   // rows per workgroup (one wave)
+constexpr int GR_CHUNK = 8192;    // rows per workgroup (one wave); ~4 waves per SIMD at batch 64 x 10 s
 constexpr int GR_GROUP = 64;      // a workgroup accumulates one 64 x 64 block of G
 constexpr int GR_PART = GR_GROUP * GR_GROUP + GR_GROUP;   // doubles per partial record (block + rhs slice)
 constexpr int GR_MAX_P = 1024;
@@ -31,62 +31,33 @@ constexpr int GR_MAX_P = 1024;
 __host__ __device__ inline int groups_side(int p) { return (p + GR_GROUP - 1) / GR_GROUP; }
 __host__ __device__ inline int groups_total(int p) { const int g = groups_side(p); return g * (g + 1) / 2; }
 
-// lower-triangular enumeration: id -> (gi >= gj)
-__device__ __forceinline__ void group_from_id(int id, int& gi, int& gj) {
-  gi = 0;
-  while ((gi + 1) * (gi + 2) / 2 <= id) ++gi;
-  gj = id - gi * (gi + 1) / 2;
-}
-
+// Operand fragments of one k-step (4 rows n0..n0+3): lane (i = lane & 15, kk = lane >> 4) holds s[n0+kk-1-(16b+i)]
+// for each 16-wide block b; the A fragment of block row b and the B fragment of block column b are the SAME value.
 template <bool DIAG>
-__device__ __forceinline__ void gram_tile_loop(const double* __restrict__ lds, long long t0, long long origin,
-                                               long long n_end, int kc, int gi, int gj, d4 (&acc)[4][4],
-                                               double& rhs) {
+__device__ __forceinline__ void load_frags(const double* __restrict__ lds, long long t0, int ks, long long origin,
+                                           long long n_end, int gi, int gj, double (&fa)[4], double (&fb)[4]) {
   const int lane = threadIdx.x;
   const int i = lane & 15, kk = lane >> 4;
-  for (int ks = 0; ks < kc; ks += 4) {
-    const long long n = t0 + ks + kk;          // row of this lane's operand element
-    const bool valid = n < n_end;
-    const long long base = (n - 1 - i) - origin;   // LDS index of s[n-1-i]
-    double fa[4], fb[4];
+  const long long n = t0 + ks + kk;
+  const bool valid = n < n_end;                     // rows past the end of the chunk contribute nothing
+  const long long base = (n - 1 - i) - origin;      // LDS index of s[n-1-i]
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const double v = lds[base - (GR_GROUP * gi + 16 * a)];
-      fa[a] = valid ? v : 0.0;
-    }
-    if (DIAG) {
+  for (int a = 0; a < 4; ++a) {
+    const double v = lds[base - (GR_GROUP * gi + 16 * a)];
+    fa[a] = valid ? v : 0.0;
+  }
+  if (!DIAG) {
 #pragma unroll
-      for (int b = 0; b < 4; ++b) fb[b] = fa[b];
-    } else {
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const double v = lds[base - (GR_GROUP * gj + 16 * b)];
-        fb[b] = valid ? v : 0.0;
-      }
-    }
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        if (DIAG && b > a) continue;
-        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
-      }
-    }
-    if (DIAG) {
-      // rhs slice r[64 gi + lane] = - sum_n s[n - 1 - j'] s[n]
-      const long long jb = (long long)GR_GROUP * gi + lane;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const long long nn = t0 + ks + q;
-        if (nn < n_end) {
-          const double sn = lds[nn - origin];
-          rhs -= lds[nn - 1 - jb - origin] * sn;
-        }
-      }
+    for (int b = 0; b < 4; ++b) {
+      const double v = lds[base - (GR_GROUP * gj + 16 * b)];
+      fb[b] = valid ? v : 0.0;
     }
   }
 }
 
+// DIAG and off-diagonal groups are SEPARATE kernels: a fused one carries both accumulator sets (80 + 128 AGPRs)
+// and drops to one wave per SIMD.  The operand fetch is software-pipelined one k-step ahead of the MFMAs.
+template <bool DIAG>
 __global__ __launch_bounds__(64) void ar_gram_kernel(const float* __restrict__ x, const double* __restrict__ x64,
                                                      const int64_t* __restrict__ xoff,
                                                      const int32_t* __restrict__ nlen,
@@ -100,18 +71,24 @@ __global__ __launch_bounds__(64) void ar_gram_kernel(const float* __restrict__ x
   if (row0 >= N) return;
   const long long n_end = (row0 + GR_CHUNK < N) ? row0 + GR_CHUNK : N;
   int gi, gj;
-  group_from_id(blockIdx.y, gi, gj);
-  const int halo = GR_GROUP * groups_side(p) + 1;   // largest lag touched (padded) + 1
+  if (DIAG) {
+    gi = gj = blockIdx.y;
+  } else {                                           // strictly-lower groups: id -> (gi > gj)
+    gi = 1;
+    while (gi * (gi + 1) / 2 <= (int)blockIdx.y) ++gi;
+    gj = blockIdx.y - gi * (gi - 1) / 2;
+  }
+  const int gid = gi * (gi + 1) / 2 + gj;            // slot in the lower-triangular partial record
+  const int halo = GR_GROUP * groups_side(p) + 1;    // largest lag touched (padded) + 1
   const float* xs = x ? x + xoff[e] : nullptr;
   const double* xd = x64 ? x64 + xoff[e] : nullptr;
   const double div = divisor ? divisor[e] : 1.0;
   const int lane = threadIdx.x;
 
-  d4 acc[4][4];
+  constexpr int NACC = DIAG ? 10 : 16;
+  d4 acc[NACC];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+  for (int t = 0; t < NACC; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
   double rhs = 0.0;
 
   for (long long t0 = row0; t0 < n_end; t0 += GR_KC) {
@@ -124,26 +101,54 @@ __global__ __launch_bounds__(64) void ar_gram_kernel(const float* __restrict__ x
       lds[m] = (idx >= 0 && idx < N) ? (xd ? xd[idx] : (double)xs[idx]) / div : 0.0;
     }
     __syncthreads();
-    if (gi == gj) gram_tile_loop<true>(lds, t0, origin, n_end, kc4, gi, gj, acc, rhs);
-    else gram_tile_loop<false>(lds, t0, origin, n_end, kc4, gi, gj, acc, rhs);
+
+    double fa[4], fb[4], na[4], nb[4];
+    load_frags<DIAG>(lds, t0, 0, origin, n_end, gi, gj, fa, fb);
+    for (int ks = 0; ks < kc4; ks += 4) {
+      if (ks + 4 < kc4) load_frags<DIAG>(lds, t0, ks + 4, origin, n_end, gi, gj, na, nb);
+      int t = 0;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          if (DIAG && b > a) continue;
+          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], DIAG ? fa[b] : fb[b], acc[t], 0, 0, 0);
+          ++t;
+        }
+      }
+      if (DIAG) {
+        // rhs slice r[64 gi + lane] = - sum_n s[n - 1 - j'] s[n]  (VALU, rides under the MFMAs)
+        const long long jb = (long long)GR_GROUP * gi + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const long long nn = t0 + ks + q;
+          const double sn = (nn < n_end) ? lds[nn - origin] : 0.0;
+          rhs -= lds[nn - 1 - jb - origin] * sn;
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) { fa[a] = na[a]; fb[a] = nb[a]; }
+    }
   }
 
   // D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
-  double* out = part + (((long long)e * nchunks_max + chunk) * groups_total(p) + blockIdx.y) * GR_PART;
+  double* out = part + (((long long)e * nchunks_max + chunk) * groups_total(p) + gid) * GR_PART;
   const int col = lane & 15, rq = lane >> 4;
+  int t = 0;
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      if (gi == gj && b > a) continue;
+      if (DIAG && b > a) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = rq + 4 * r;
-        out[(16 * a + row) * GR_GROUP + 16 * b + col] = acc[a][b][r];
+        out[(16 * a + row) * GR_GROUP + 16 * b + col] = acc[t][r];
       }
+      ++t;
     }
   }
-  if (gi == gj) out[GR_GROUP * GR_GROUP + lane] = rhs;
+  if (DIAG) out[GR_GROUP * GR_GROUP + lane] = rhs;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -391,8 +396,12 @@ extern "C" int32_t ira_ar_gram(const float* x_dev, const double* x64_dev, const 
   const int32_t rc = ar_check(nb, max_len, order);
   if (rc != IRA_OK || nb == 0) return rc;
   const int nchunks = (int)(((int64_t)max_len - order + GR_CHUNK - 1) / GR_CHUNK);
-  ar_gram_kernel<<<dim3(nchunks, groups_total(order), nb), 64, 0, (hipStream_t)stream>>>(
+  const int gs = groups_side(order);
+  ar_gram_kernel<true><<<dim3(nchunks, gs, nb), 64, 0, (hipStream_t)stream>>>(
       x64_dev ? nullptr : x_dev, x64_dev, xoff_dev, len_dev, divisor_dev, order, nchunks, partial_dev);
+  if (gs > 1)
+    ar_gram_kernel<false><<<dim3(nchunks, gs * (gs - 1) / 2, nb), 64, 0, (hipStream_t)stream>>>(
+        x64_dev ? nullptr : x_dev, x64_dev, xoff_dev, len_dev, divisor_dev, order, nchunks, partial_dev);
   IRA_RETURN_LAUNCH();
 }
 

@@ -161,7 +161,9 @@ def main():
             ach = flops / (avg_ms * 1e-3) / 1e12
             return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic_of(name),
-                    "avg_launch_ms": avg_ms, "algorithmic": "(L-p)*p*(p+1) fp64 flop per channel (lower triangle)"}
+                    "avg_launch_ms": avg_ms, "algorithmic": "(L-p)*p*(p+1) fp64 flop per channel (lower triangle)",
+                    "measured_mfma_f64_ceiling_tflops": 49.2,
+                    "ceiling_source": "profiles/r01_mfma_f64_peak.txt (tools/mfma_f64_peak.hip on the same GPU)"}
         if name.startswith("ira_stft_mag_db[f32"):
             b = stft_bytes(settings.spectrogram.n_fft, settings.spectrogram.hop_length)
             what = "4L in + 4*F*T out bytes per channel"
