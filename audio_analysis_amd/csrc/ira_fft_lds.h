@@ -3,13 +3,14 @@
 //  lds_fft_dif : decimation-in-frequency, natural-order input -> BIT-REVERSED output (forward, e^{-i...}).
 //  lds_fft_dit : decimation-in-time, BIT-REVERSED input -> natural-order output; with conj_tw it is the
 //                (unnormalised) inverse of lds_fft_dif, so a forward/inverse pair needs no reorder pass.
-// Radix-4 passes plus one radix-2 pass when log2(M) is odd; in place; `nbat` independent transforms laid out
+// Radix-16 passes (16-point DFT in registers, ONE twiddle lookup per butterfly, powers by a shallow tree) while at
+// least 4 bits remain, then radix-4 and radix-2 for the remainder; in place; `nbat` independent transforms laid out
 // `bstride` elements apart are processed together (all `nt` threads must call; the functions contain barriers).
 //
 // Twiddles come from a caller-provided table tw[k] = exp(-2*pi*i*k/TWN), k < TWN/2, TWN = M * tw_per_m;
 // angles in [pi, 2pi) use W^(k+TWN/2) = -W^k.
 #pragma once
-#include "ira_common.h"
+#include "ira_fft_reg.h"
 
 namespace ira {
 
@@ -34,6 +35,33 @@ __device__ __forceinline__ void lds_fft_dif(cplx<T>* buf, int log2m, const cplx<
   const unsigned M = 1u << log2m;
   const unsigned half = (M * tw_per_m) >> 1;
   int s = log2m;  // log2 of the current block length S
+  while (s >= 4) {
+    // radix-16: elements base + r*q (r < 16), q = S/16.  dft_dif leaves X[k] in v[brev4(k)], and storing v[i] at
+    // base + i*q is exactly the position the equivalent four radix-2 stages would have used (bit-reversed order).
+    const unsigned q = 1u << (s - 4);
+    const unsigned step = tw_per_m << (log2m - s);
+    const unsigned per = M >> 4;
+    for (unsigned g = tid; g < per * (unsigned)nbat; g += nt) {
+      const unsigned which = g >> (log2m - 4), b = g & (per - 1);
+      cplx<T>* p = buf + which * bstride;
+      const unsigned j = b & (q - 1);
+      const unsigned base = ((b >> (s - 4)) << s) + j;
+      cplx<T> v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = p[base + r * q];
+      dft_dif<T, 16>(v);
+      if (j != 0) {
+        cplx<T> pw[16];
+        powers16<T>(tw[j * step], pw);                 // W_S^(j k), k < 16  (j*step < half/8)
+#pragma unroll
+        for (int i = 1; i < 16; ++i) v[i] = cmul(v[i], pw[brev_bits(i, 4)]);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) p[base + i * q] = v[i];
+    }
+    __syncthreads();
+    s -= 4;
+  }
   while (s >= 2) {
     const unsigned q = 1u << (s - 2);               // quarter block
     const unsigned step = tw_per_m << (log2m - s);  // table steps per unit of j at block length S
@@ -97,7 +125,8 @@ __device__ __forceinline__ void lds_fft_dit(cplx<T>* buf, int log2m, const cplx<
     __syncthreads();
     s = 1;
   }
-  while (s < log2m) {
+  const int s16_start = log2m & 3;   // the radix-2 / radix-4 passes cover these low bits; radix-16 does the rest
+  while (s < s16_start) {
     // combine blocks of length q = 2^s into blocks of length S = 4q
     const unsigned q = 1u << s;
     const int sS = s + 2;
@@ -126,6 +155,45 @@ __device__ __forceinline__ void lds_fft_dit(cplx<T>* buf, int log2m, const cplx<
       p[base + q] = cadd(d01, d23);
       p[base + 2 * q] = csub(s01, s23);
       p[base + 3 * q] = csub(d01, d23);
+    }
+    __syncthreads();
+    s = sS;
+  }
+  while (s < log2m) {
+    // radix-16: the exact inverse of the DIF pass above.  Position base + i*q holds frequency index k = brev4(i) of
+    // the 16-point stage; untwiddle, then the 16-point (inverse) DFT puts sample n at base + n*q.
+    const unsigned q = 1u << s;
+    const int sS = s + 4;
+    const unsigned step = tw_per_m << (log2m - sS);
+    const unsigned per = M >> 4;
+    for (unsigned g = tid; g < per * (unsigned)nbat; g += nt) {
+      const unsigned which = g >> (log2m - 4), b = g & (per - 1);
+      cplx<T>* p = buf + which * bstride;
+      const unsigned j = b & (q - 1);
+      const unsigned base = ((b >> s) << sS) + j;
+      cplx<T> u[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) u[k] = p[base + brev_bits(k, 4) * q];
+      if (j != 0) {
+        cplx<T> pw[16];
+        cplx<T> w = tw[j * step];
+        if (conj_tw) w.im = -w.im;
+        powers16<T>(w, pw);
+#pragma unroll
+        for (int k = 1; k < 16; ++k) u[k] = cmul(u[k], pw[k]);
+      }
+      if (conj_tw) {
+        // inverse 16-point DFT = conj(DFT(conj(.)))
+#pragma unroll
+        for (int k = 0; k < 16; ++k) u[k].im = -u[k].im;
+        dft_dif<T, 16>(u);
+#pragma unroll
+        for (int n = 0; n < 16; ++n) { cplx<T> r = u[brev_bits(n, 4)]; r.im = -r.im; p[base + n * q] = r; }
+      } else {
+        dft_dif<T, 16>(u);
+#pragma unroll
+        for (int n = 0; n < 16; ++n) p[base + n * q] = u[brev_bits(n, 4)];
+      }
     }
     __syncthreads();
     s = sS;

@@ -18,6 +18,7 @@
 // All arithmetic is float64: the reference computes these FFTs in float64 (numpy pocketfft) and the unwrapped
 // phase / band RT60 values are discrete functions of them.
 #include <cmath>
+#include <cstdlib>
 
 #include "ira_fft_lds.h"
 
@@ -149,6 +150,16 @@ __device__ __forceinline__ cd gen_input(const Jobs& J, int e, long long n, long 
   }
 }
 
+// XCD-aware remap (speed only): give each XCD a contiguous range of (element, tile) pairs so that neighbouring
+// column tiles -- which touch the two halves of the same 128-byte lines -- meet in one L2.
+__device__ __forceinline__ void remap_xcd(unsigned& bx, unsigned& by) {
+  const unsigned gx = gridDim.x, nwg = gridDim.x * gridDim.y;
+  const unsigned orig = blockIdx.y * gx + blockIdx.x;
+  const unsigned q = nwg / 8, r = nwg % 8, xcd = orig % 8;
+  const unsigned wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+  bx = wg % gx; by = wg / gx;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // K1: columns forward.  grid (N2 / C, nb); LDS C * (N1 + 1) complex.
 // ---------------------------------------------------------------------------------------------------------
@@ -156,11 +167,13 @@ template <int MODE>
 __global__ __launch_bounds__(FL_THREADS) void cols_fwd_kernel(Geom g, Jobs J, cd* __restrict__ work, int C) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   cd* lds = reinterpret_cast<cd*>(smem_raw);
-  const int e = blockIdx.y;
+  unsigned bx, by;
+  remap_xcd(bx, by);
+  const int e = by;
   const long long L = J.L[e];
   const unsigned N1 = 1u << g.log2n1, N2 = 1u << g.log2n2;
   const long long M = 1ll << g.log2m;
-  const unsigned n2_0 = blockIdx.x * C;
+  const unsigned n2_0 = bx * C;
   const unsigned stride = N1 + 1;
   const int tid = threadIdx.x;
   for (unsigned i = tid; i < N1 * (unsigned)C; i += FL_THREADS) {
@@ -187,10 +200,12 @@ template <int MODE>
 __global__ __launch_bounds__(FL_THREADS) void rows_kernel(Geom g, Jobs J, cd* __restrict__ work, int R) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   cd* lds = reinterpret_cast<cd*>(smem_raw);
-  const int e = blockIdx.y;
+  unsigned bx, by;
+  remap_xcd(bx, by);
+  const int e = by;
   const unsigned N2 = 1u << g.log2n2;
   const long long M = 1ll << g.log2m;
-  const unsigned r0 = blockIdx.x * R;
+  const unsigned r0 = bx * R;
   const int tid = threadIdx.x;
   cd* w = work + (long long)e * M + (long long)r0 * N2;
   for (unsigned i = tid; i < N2 * (unsigned)R; i += FL_THREADS) lds[i] = w[i];
@@ -220,11 +235,13 @@ template <int MODE>
 __global__ __launch_bounds__(FL_THREADS) void cols_inv_kernel(Geom g, Jobs J, const cd* __restrict__ work, int C) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   cd* lds = reinterpret_cast<cd*>(smem_raw);
-  const int e = blockIdx.y;
+  unsigned bx, by;
+  remap_xcd(bx, by);
+  const int e = by;
   const long long L = J.L[e];
   const unsigned N1 = 1u << g.log2n1, N2 = 1u << g.log2n2;
   const long long M = 1ll << g.log2m;
-  const unsigned n2_0 = blockIdx.x * C;
+  const unsigned n2_0 = bx * C;
   const unsigned stride = N1 + 1;
   const int tid = threadIdx.x;
   // outputs needed: n <= L/2 (spectrum) or n < L (bands); rows beyond that are computed but not stored
@@ -272,11 +289,15 @@ int32_t make_plan(int log2m, const void* t1, const void* t2, const void* tf, Pla
   p->g.t2 = static_cast<const cd*>(t2);
   p->g.tf = static_cast<const cd*>(tf);
   const int N1 = 1 << p->g.log2n1, N2 = 1 << p->g.log2n2;
+  // ~32 KB of LDS per workgroup (C = R = 2 at N1 = N2 = 1024): measured fastest on MI355X -- 4 workgroups per CU
+  // hide each other's barriers (rfft_any, 64 x 2^20: C/R = 4/4 2.75 ms, 2/2 2.39 ms, 1/1 2.92 ms)
   int C = 8;
-  while (C > 1 && (size_t)C * (N1 + 1) * sizeof(cd) > 66 * 1024) C >>= 1;
+  while (C > 1 && (size_t)C * (N1 + 1) * sizeof(cd) > 33 * 1024) C >>= 1;
   if (C > N2) C = N2;
   int R = 1;
-  while (R * 2 * N2 * (int)sizeof(cd) <= 64 * 1024 && R * 2 <= N1 && R < 16) R <<= 1;
+  while (R * 2 * N2 * (int)sizeof(cd) <= 32 * 1024 && R * 2 <= N1 && R < 16) R <<= 1;
+  if (const char* ev = std::getenv("IRA_FFT_C")) { const int v = std::atoi(ev); if (v >= 1 && v <= N2) C = v; }   // tuning
+  if (const char* ev = std::getenv("IRA_FFT_R")) { const int v = std::atoi(ev); if (v >= 1 && v <= N1) R = v; }
   p->C = C;
   p->R = R;
   p->lds_cols = (size_t)C * (N1 + 1) * sizeof(cd);
