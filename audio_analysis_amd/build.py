@@ -24,10 +24,12 @@ ARCH = "gfx950"
 SOURCES = {
     "ira_api.hip": [],
     "ira_edc.hip": ["-ffp-contract=off"],
-    # -fno-slp-vectorize: hipcc otherwise packs the complex arithmetic into v_pk_{add,mul,fma}_f32, which issue at
-    # ~3x the cost of the scalar forms on gfx950 (MI355X_MICROARCH.md, "packed f32 VALU ... an anti-lever")
+    # -fno-slp-vectorize: hipcc otherwise packs the complex arithmetic into v_pk_{add,mul,fma}_f32.  Measured with
+    # tools/pk_f32_rate.hip on MI355X: a packed op occupies the SIMD twice as long as a scalar one (0.87 vs 1.5
+    # wave-instructions per CU-cycle at saturation) and the packing itself costs register moves.
     "ira_stft.hip": ["-fno-slp-vectorize"],
     "ira_stft2.hip": ["-fno-slp-vectorize"],
+    "ira_stft3.hip": ["-fno-slp-vectorize"],
     "ira_fftlong.hip": [],
     "ira_spectrum.hip": ["-ffp-contract=off"],
     "ira_modal.hip": ["-ffp-contract=off"],

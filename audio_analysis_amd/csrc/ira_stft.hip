@@ -123,6 +123,12 @@ int32_t ira_stft2_dispatch(const float* x, const int64_t* off, const int32_t* nf
                            int32_t precision, double floor_db, float* out, const int64_t* out_off,
                            const int32_t* frame_sel, const int64_t* sel_off, hipStream_t st);
 
+// float32 / n_fft 4096 at 16 one-wave teams per CU (ira_stft3.hip)
+int32_t ira_stft3_dispatch(const float* x, const int64_t* off, const int32_t* nframes, int32_t nseg,
+                           int32_t max_frames, int32_t n_fft, int32_t hop, const void* window, const void* tw,
+                           int32_t precision, double floor_db, float* out, const int64_t* out_off,
+                           const int32_t* frame_sel, const int64_t* sel_off, hipStream_t st);
+
 extern "C" int32_t ira_stft_mag_db(const float* x_dev, const int64_t* off_dev, const int32_t* nframes_dev,
                                    int32_t nseg, int32_t max_frames, int32_t n_fft, int32_t hop,
                                    const void* window_dev, const void* twiddle_dev, int32_t precision,
@@ -139,6 +145,13 @@ extern "C" int32_t ira_stft_mag_db(const float* x_dev, const int64_t* off_dev, c
   hipStream_t st = (hipStream_t)stream;
   if (precision != 32 && precision != 64) return IRA_E_UNSUPPORTED;
   static const bool force_generic = std::getenv("IRA_STFT_GENERIC") != nullptr;   // A/B switch for benchmarking
+  static const bool no_v3 = std::getenv("IRA_STFT_NO_V3") != nullptr;             // A/B switch for benchmarking
+  if (!force_generic && !no_v3) {
+    const int32_t rc = ira_stft3_dispatch(x_dev, off_dev, nframes_dev, nseg, max_frames, n_fft, hop, window_dev,
+                                          twiddle_dev, precision, floor_db, out_dev, out_off_dev, frame_sel_dev,
+                                          sel_off_dev, st);
+    if (rc != IRA_E_UNSUPPORTED) return rc;
+  }
   if (!force_generic) {
     const int32_t rc = ira_stft2_dispatch(x_dev, off_dev, nframes_dev, nseg, max_frames, n_fft, hop, window_dev,
                                           twiddle_dev, precision, floor_db, out_dev, out_off_dev, frame_sel_dev,

@@ -1,0 +1,308 @@
+// STFT v3: the float32 / n_fft = 4096 configuration (the reference's spectrogram default, spectrogram.py:107-160)
+// at SIXTEEN one-wave teams per CU.
+//
+// Why a third kernel: tools/pk_f32_rate.hip shows that on gfx950 one wave can issue an f32 VALU instruction only
+// every ~5 cycles while the SIMD retires one every ~2.5, and that packed f32 math saturates the SIMD with a single
+// wave.  v2 (ira_stft2.hip) holds a whole 2048-point exchange (16 KB + padding) per wave, which caps the CU at 8
+// waves = 2 per SIMD: its ~2200 VALU instructions per frame then cost ~5 cycles each plus every exposed load/LDS
+// latency.  The lever is occupancy, and occupancy is LDS: v3 moves the same data through HALF-size exchanges
+// (8.4 KB per wave), so 16 waves = 4 per SIMD fit beside nothing else, with <= 128 VGPRs each.
+//
+// Same transform as v2: packed real FFT, z[n] = xw[2n] + i xw[2n+1], M = 2048 = 16 * 16 * 8, DIF,
+//   n = n1*128 + n2*8 + n3,  k = k1 + 16*k2 + 256*k3.
+//   step 1  lane m = q + 64h (h = 0, 1): 16-point DFT over n1 from global memory, twiddle W_M^(k1 m)
+//   E1      half h at a time: [16 k1][64 m'] complex, row stride 66   -> (k1 = q & 15, n3 = (q >> 4) + 4 hb) reads n2
+//   step 2  two 16-point DFTs over n2 (hb = 0, 1), twiddle W_M^(16 k2 n3)
+//   E2      half hb at a time: k1 + 16 k2 + 272 n3' complex           -> row r = q + 64 hh = k1 + 16 k2 reads n3
+//   step 3  four 8-point DFTs over n3 -> lane holds Z[r + 256 k3]
+//   E3      natural order, real parts then imaginary parts through one 2048-float buffer
+//   post    (Z[k], Z[M-k]) -> |X[k]|, |X[M-k]| in dB, exactly as v2
+// Every LDS access is bank-conflict free: 8-byte accesses go half a wave at a time over 32 bank pairs (the strides
+// 66 = 2 mod 32 and 272 = 16 mod 32 spread the 16 x 2 lanes of a half wave), 4-byte accesses are unit stride.
+// The 16 teams of a workgroup then write their 16 columns into one [F][17] float tile that aliases the exchange
+// buffers and store 64-byte runs of the C-contiguous (F, T) matrix.
+#include <cmath>
+#include <cstdlib>
+
+#include "ira_fft_reg.h"
+
+namespace {
+
+using ira::brev_bits;
+using ira::cplx;
+using ira::dft_dif;
+using ira::powers16;
+
+typedef cplx<float> cf;
+
+constexpr int M3 = 2048, F3 = M3 + 1;
+constexpr int ROWH = 66;     // E1 half: row stride (complex)
+constexpr int E2N3 = 272;    // E2 half: n3' stride (complex)
+constexpr int EXC = 1072;    // complex slots per team: max(16*66, 15 + 240 + 3*272 + 1, 2048 floats / 2)
+static_assert(EXC >= 16 * ROWH && EXC >= 15 + 16 * 15 + 3 * E2N3 + 1 && EXC * 2 >= M3, "exchange buffer too small");
+
+__device__ __forceinline__ void wave_sync() {
+  // One-wave team: LDS instructions of a wave execute in order; only the compiler must not reorder across this.
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ float db_of(float re, float im, float floor_pow, float floor_db) {
+  const float p = re * re + im * im;
+  if (!(p > floor_pow)) return floor_db;
+  return 3.0102999566398120f * __log2f(p);   // 10 log10(p) = 20 log10 |X|
+}
+
+template <int NT3>
+__global__ __launch_bounds__(64 * NT3) void stft3_kernel(
+    const float* __restrict__ x, const int64_t* __restrict__ off, const int32_t* __restrict__ nframes, int hop,
+    const float* __restrict__ window, const cf* __restrict__ tw, float floor_lin, float floor_db,
+    float* __restrict__ out, const int64_t* __restrict__ out_off, const int32_t* __restrict__ frame_sel,
+    const int64_t* __restrict__ sel_off, int ablate) {
+  constexpr int TB3 = NT3;   // one frame per team -> NT3 output columns per workgroup
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // XCD-aware bijective remap: each XCD (own L2) gets a contiguous range of (segment, frame group) pairs, so the
+  // groups that share 7/8 of their samples and adjacent halves of the same output lines meet in one L2.
+  const unsigned gx = gridDim.x, nwg = gridDim.x * gridDim.y;
+  const unsigned orig = blockIdx.y * gx + blockIdx.x;
+  const unsigned xq = nwg / 8, xr = nwg % 8, xcd = orig % 8;
+  const unsigned wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + orig / 8;
+  if ((ablate & 48) && orig < 256u * (16 / NT3) * 1u) {
+    // diagnostic: stagger the first round of workgroups so that co-resident ones are out of phase
+    const unsigned slot = (NT3 == 16) ? ((ablate & 16) ? ((orig >> 3) & 1u) : ((orig >> 3) & 3u))
+                                      : ((ablate & 16) ? (orig / 256u) % (16 / NT3) : orig % (16 / NT3));
+    for (unsigned i = 0; i < slot * (unsigned)(ablate >> 8); ++i) __builtin_amdgcn_s_sleep(100);
+  }
+  const int seg = (int)(wg / gx);
+  const int T_out = nframes[seg];
+  const int col0 = (int)(wg % gx) * TB3;
+  if (col0 >= T_out) return;
+  const int tid = threadIdx.x;
+  const int team = __builtin_amdgcn_readfirstlane(tid >> 6), q = tid & 63;
+  cf* ex = reinterpret_cast<cf*>(smem_raw) + (size_t)team * EXC;
+  unsigned long long st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define IRA_STAMP(i) do { if (ablate & 128) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); st[i] = t_; } } while (0)
+  IRA_STAMP(0);
+  float* exf = reinterpret_cast<float*>(ex);
+
+  const int col = col0 + team;
+  // Columns past the end transform frame 0 and are dropped at the store (a per-load select makes hipcc branch
+  // around every load).
+  const int64_t frame = (col < T_out) ? (frame_sel ? (int64_t)frame_sel[sel_off[seg] + col] : (int64_t)col) : 0;
+  const float* fx = x + off[seg] + frame * hop;
+  if (ablate & 64) fx = x + ((size_t)(wg * TB3 + team) * 4096u) % (size_t)(30720000u - 8192u);   // diagnostic: disjoint frames
+  const int k1l = q & 15, n3a = q >> 4;
+
+  // ---- step 1 -------------------------------------------------------------------------------------------------
+  cf a1[16];   // half h = 1, held in registers until E1 is free again
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int m = q + 64 * h;
+    float xa[16], xb[16], wa[16], wb[16];
+    // all loads first, one wait (left alone hipcc serialises them behind vmcnt(1) waits)
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+      const int n = n1 * 128 + m;
+      if (ablate & 1) { xa[n1] = (float)n; xb[n1] = (float)(n + 1); } else { xa[n1] = fx[2 * n]; xb[n1] = fx[2 * n + 1]; }
+      if (ablate & 2) { wa[n1] = 0.5f; wb[n1] = 0.25f; } else { wa[n1] = window[2 * n]; wb[n1] = window[2 * n + 1]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    cf v[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) v[n1] = {xa[n1] * wa[n1], xb[n1] * wb[n1]};
+    dft_dif<float, 16>(v);
+    cf p[16];
+    powers16<float>(tw[2 * m], p);                      // W_M^m = W_N^(2m)
+    if (h == 0) {
+#pragma unroll
+      for (int k1 = 0; k1 < 16; ++k1) {
+        const cf a = v[brev_bits(k1, 4)];
+        ex[k1 * ROWH + q] = (k1 == 0) ? a : ira::cmul(a, p[k1]);
+      }
+    } else {
+#pragma unroll
+      for (int k1 = 0; k1 < 16; ++k1) {
+        const cf a = v[brev_bits(k1, 4)];
+        a1[k1] = (k1 == 0) ? a : ira::cmul(a, p[k1]);
+      }
+    }
+  }
+  wave_sync();
+  IRA_STAMP(1);
+
+  // ---- E1 -> step-2 operands: n2 = 0..7 come from half 0, n2 = 8..15 from half 1 ------------------------------------
+  cf b2[2][16];
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+    for (int n2 = 0; n2 < 8; ++n2) b2[hb][n2] = ex[k1l * ROWH + n2 * 8 + n3a + 4 * hb];
+  wave_sync();
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) ex[k1 * ROWH + q] = a1[k1];
+  wave_sync();
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+    for (int n2 = 0; n2 < 8; ++n2) b2[hb][8 + n2] = ex[k1l * ROWH + n2 * 8 + n3a + 4 * hb];
+  wave_sync();
+
+  // ---- step 2 and E2 (half hb = n3 in [4hb, 4hb + 4)) -> step-3 operands ---------------------------------------------
+  cf z3[4][8];
+  {
+    cf p[16];
+    dft_dif<float, 16>(b2[0]);
+    powers16<float>(tw[32 * n3a], p);                    // W_M^(16 n3) = W_N^(32 n3)
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) {
+      const cf a = b2[0][brev_bits(k2, 4)];
+      ex[k1l + 16 * k2 + E2N3 * n3a] = (k2 == 0) ? a : ira::cmul(a, p[k2]);
+    }
+    dft_dif<float, 16>(b2[1]);
+    powers16<float>(tw[32 * (n3a + 4)], p);
+#pragma unroll
+    for (int k2 = 1; k2 < 16; ++k2) b2[1][brev_bits(k2, 4)] = ira::cmul(b2[1][brev_bits(k2, 4)], p[k2]);
+  }
+  wave_sync();
+#pragma unroll
+  for (int hh = 0; hh < 4; ++hh)
+#pragma unroll
+    for (int n3 = 0; n3 < 4; ++n3) z3[hh][n3] = ex[k1l + 16 * (n3a + 4 * hh) + E2N3 * n3];
+  wave_sync();
+#pragma unroll
+  for (int k2 = 0; k2 < 16; ++k2) ex[k1l + 16 * k2 + E2N3 * n3a] = b2[1][brev_bits(k2, 4)];
+  wave_sync();
+#pragma unroll
+  for (int hh = 0; hh < 4; ++hh)
+#pragma unroll
+    for (int n3 = 0; n3 < 4; ++n3) z3[hh][4 + n3] = ex[k1l + 16 * (n3a + 4 * hh) + E2N3 * n3];
+  wave_sync();
+
+  // ---- step 3: lane holds Z[r + 256 k3], r = q + 64 hh -----------------------------------------------------------------
+#pragma unroll
+  for (int hh = 0; hh < 4; ++hh) dft_dif<float, 8>(z3[hh]);
+
+  // ---- E3: real parts, then imaginary parts, natural order ------------------------------------------------------------
+  float zkr[16], zpr[16], zki[16], zpi[16], midr, midi;
+#pragma unroll
+  for (int hh = 0; hh < 4; ++hh)
+#pragma unroll
+    for (int k3 = 0; k3 < 8; ++k3) exf[q + 64 * hh + 256 * k3] = z3[hh][brev_bits(k3, 3)].re;
+  wave_sync();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int k = q + 64 * i;
+    zkr[i] = exf[k];
+    zpr[i] = exf[(M3 - k) & (M3 - 1)];
+  }
+  midr = exf[M3 / 2];
+  wave_sync();
+#pragma unroll
+  for (int hh = 0; hh < 4; ++hh)
+#pragma unroll
+    for (int k3 = 0; k3 < 8; ++k3) exf[q + 64 * hh + 256 * k3] = z3[hh][brev_bits(k3, 3)].im;
+  wave_sync();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int k = q + 64 * i;
+    zki[i] = exf[k];
+    zpi[i] = exf[(M3 - k) & (M3 - 1)];
+  }
+  midi = exf[M3 / 2];
+
+  // ---- post: X[k] = E + P, X[M-k] = conj(E - P) with E = (Zk + conj Zp)/2, P = W_N^k (-i)(Zk - conj Zp)/2 ---------------
+  const float floor_pow = floor_lin * floor_lin;
+  const cf wlane = tw[q];
+  float lo[16], hi[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const cf e = {0.5f * (zkr[i] + zpr[i]), 0.5f * (zki[i] - zpi[i])};
+    const cf d = {0.5f * (zkr[i] - zpr[i]), 0.5f * (zki[i] + zpi[i])};
+    const cf o = {d.im, -d.re};
+    const cf wk = ira::cmul(wlane, tw[64 * i]);          // W_N^k = W_N^q W_N^(64 i); second factor wave-uniform
+    const cf pp = ira::cmul(wk, o);
+    if (ablate & 8) { lo[i] = e.re + pp.re; hi[i] = e.im - pp.im; continue; }
+    lo[i] = db_of(e.re + pp.re, e.im + pp.im, floor_pow, floor_db);
+    hi[i] = db_of(e.re - pp.re, e.im - pp.im, floor_pow, floor_db);
+  }
+  const float mid = db_of(midr, midi, floor_pow, floor_db);
+  IRA_STAMP(2);
+
+  __syncthreads();
+  IRA_STAMP(3);   // every team is done with its exchange buffer: the tile may overwrite them
+  float* tile = reinterpret_cast<float*>(smem_raw);      // [F][TB + 1]
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int k = q + 64 * i;
+    tile[k * (TB3 + 1) + team] = lo[i];
+    tile[(M3 - k) * (TB3 + 1) + team] = hi[i];            // k = 0 -> bin M (Nyquist)
+  }
+  if (q == 0) tile[(M3 / 2) * (TB3 + 1) + team] = mid;
+  __syncthreads();
+  IRA_STAMP(4);
+
+  const int ncol = (T_out - col0 < TB3) ? T_out - col0 : TB3;
+  float* o = out + out_off[seg];
+  // 16-byte stores: four lanes cover one 64-byte output row segment.  Rows of the (F, T) matrix are only 4-byte
+  // aligned (T is arbitrary); global dwordx4 stores accept that.
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  constexpr int QR = TB3 / 4;
+  for (int idx = tid; idx < ((ablate & 4) ? 1 : F3 * QR); idx += 64 * NT3) {
+    const int k = idx / QR, c4 = (idx % QR) * 4;
+    const float* tp = tile + k * (TB3 + 1) + c4;
+    float* gp = o + (int64_t)k * T_out + col0 + c4;
+    if (c4 + 3 < ncol) {
+      f4u v = {tp[0], tp[1], tp[2], tp[3]};
+      *reinterpret_cast<f4u*>(gp) = v;
+    } else {
+      for (int c = 0; c < 4; ++c)
+        if (c4 + c < ncol) gp[c] = tp[c];
+    }
+  }
+  if (ablate & 128) {
+    unsigned long long t5, t6;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t5) :: "memory");          // stores issued, not yet acknowledged
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t6) :: "memory");
+    if ((wg == nwg / 2 || wg == nwg / 2 + 1) && q == 0 && (team == 0 || team == NT3 - 1))
+      printf("STAMP wg %u team %d: step1(load+dft) %llu  steps2-3+post %llu  barrier1 %llu  tile %llu  store-issue %llu  store-ack %llu\n",
+             wg, team, st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], t5 - st[4], t6 - t5);
+  }
+#undef IRA_STAMP
+}
+
+// float32 / n_fft 4096 only; anything else returns IRA_E_UNSUPPORTED and the caller falls through to v2 / v1.
+template <int NT3>
+int32_t launch3(const float* x, const int64_t* off, const int32_t* nframes, int32_t nseg, int32_t max_frames,
+                int32_t hop, const void* window, const void* tw, double floor_db, float* out, const int64_t* out_off,
+                const int32_t* frame_sel, const int64_t* sel_off, hipStream_t st) {
+  constexpr int TB3 = NT3;
+  constexpr size_t lds_ex = (size_t)NT3 * EXC * sizeof(cf);
+  constexpr size_t lds_tile = (size_t)F3 * (TB3 + 1) * sizeof(float);
+  constexpr size_t lds = lds_ex > lds_tile ? lds_ex : lds_tile;
+  static_assert(lds <= 160 * 1024, "one workgroup must fit the CU's LDS");
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&stft3_kernel<NT3>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr != hipSuccess) return ira_hip_status(attr);
+  const double floor_lin = std::pow(10.0, floor_db / 20.0);
+  static const int ablate = std::getenv("IRA_STFT3_ABLATE") ? std::atoi(std::getenv("IRA_STFT3_ABLATE")) : 0;   // diagnostics
+  dim3 grid((max_frames + TB3 - 1) / TB3, nseg);
+  stft3_kernel<NT3><<<grid, 64 * NT3, lds, st>>>(x, off, nframes, hop, static_cast<const float*>(window),
+                                            static_cast<const cf*>(tw), (float)floor_lin, (float)floor_db, out,
+                                            out_off, frame_sel, sel_off, ablate);
+  IRA_RETURN_LAUNCH();
+}
+
+}  // namespace
+
+int32_t ira_stft3_dispatch(const float* x, const int64_t* off, const int32_t* nframes, int32_t nseg,
+                           int32_t max_frames, int32_t n_fft, int32_t hop, const void* window, const void* tw,
+                           int32_t precision, double floor_db, float* out, const int64_t* out_off,
+                           const int32_t* frame_sel, const int64_t* sel_off, hipStream_t st) {
+  if (precision != 32 || n_fft != 4096) return IRA_E_UNSUPPORTED;
+  static const int nt = std::getenv("IRA_STFT3_NT") ? std::atoi(std::getenv("IRA_STFT3_NT")) : 16;   // tuning
+  if (nt == 8)
+    return launch3<8>(x, off, nframes, nseg, max_frames, hop, window, tw, floor_db, out, out_off, frame_sel, sel_off, st);
+  if (nt == 4)
+    return launch3<4>(x, off, nframes, nseg, max_frames, hop, window, tw, floor_db, out, out_off, frame_sel, sel_off, st);
+  return launch3<16>(x, off, nframes, nseg, max_frames, hop, window, tw, floor_db, out, out_off, frame_sel, sel_off, st);
+}
