@@ -91,7 +91,7 @@ __global__ void logbin_kernel(const float* __restrict__ mag, const int64_t* __re
   double acc = 0.0;
   for (int k = 0; k < c; ++k) {
     const double db = (double)m[(int64_t)(k0 + k) * T + t];
-    const double lin = pow(10.0, db / 20.0);
+    const double lin = exp10(db * 0.05);           // 10^(dB/20); pow() costs 4.5x the instructions for the same f32 result
     acc = (k == 0) ? lin : acc + lin;
   }
   double mean = acc / (double)c;

@@ -23,18 +23,52 @@ using ira::brev_bits;
 using ira::dft_dif;
 using ira::powers16;
 
+// float64 log2 of a positive normal number from a 128-entry table in LDS: p = 2^e * m, m in [1, 2);
+// m = c_k (1 + r) with c_k the centre of the k-th of 128 mantissa intervals, |r| <= 2^-8;
+// log2 p = e + log2 c_k + log1p(r) / ln 2, log1p by its series to r^6 (next term < 2e-18).  ~25 instructions
+// instead of ~130 for hypot + log10 (which were two thirds of the float64 kernel's VALU work); the result
+// differs from 20 log10(hypot) by a few 1e-16 relative, invisible after the rounding to float32.
+struct LogTabEntry { double inv_c, log2_c; };
+constexpr int LOGTAB_N = 128;
+
+__device__ __forceinline__ void build_log_table(LogTabEntry* tab, int tid) {
+  if (tid < LOGTAB_N) {
+    const double inv_c = 1.0 / (1.0 + ((double)tid + 0.5) / (double)LOGTAB_N);
+    tab[tid] = {inv_c, -log2(inv_c)};              // consistent with the ROUNDED reciprocal
+  }
+}
+
+__device__ __forceinline__ double log2_table(double p, const LogTabEntry* tab) {
+  const long long bits = __double_as_longlong(p);
+  const int e = (int)((bits >> 52) & 0x7ff) - 1023;
+  const int k = (int)((bits >> 45) & (LOGTAB_N - 1));
+  const double m = __longlong_as_double((bits & 0x000fffffffffffffll) | 0x3ff0000000000000ll);
+  const LogTabEntry t = tab[k];
+  const double r = fma(m, t.inv_c, -1.0);
+  double s = fma(r, -1.0 / 6.0, 0.2);
+  s = fma(r, s, -0.25);
+  s = fma(r, s, 1.0 / 3.0);
+  s = fma(r, s, -0.5);
+  s = fma(r, s, 1.0);
+  return (double)e + fma(r * s, 1.4426950408889634, t.log2_c);
+}
+
 template <typename T>
-__device__ __forceinline__ float power_to_db(T re, T im, T floor_lin, float floor_db);
+__device__ __forceinline__ float power_to_db(T re, T im, T floor_lin, float floor_db, const LogTabEntry* tab);
 template <>
-__device__ __forceinline__ float power_to_db<float>(float re, float im, float floor_lin, float floor_db) {
+__device__ __forceinline__ float power_to_db<float>(float re, float im, float floor_lin, float floor_db,
+                                                    const LogTabEntry*) {
   const float p = re * re + im * im;
   if (!(p > floor_lin * floor_lin)) return floor_db;
   return 3.0102999566398120f * __log2f(p);   // 10*log10(p) = 20*log10(|X|)
 }
 template <>
-__device__ __forceinline__ float power_to_db<double>(double re, double im, double floor_lin, float floor_db) {
-  const double m = fmax(hypot(re, im), floor_lin);
-  return (float)(20.0 * log10(m));
+__device__ __forceinline__ float power_to_db<double>(double re, double im, double floor_lin, float floor_db,
+                                                     const LogTabEntry* tab) {
+  const double p = fma(re, re, im * im);
+  if (!(p > floor_lin * floor_lin)) return floor_db;                        // also catches NaN
+  if (!(p < 1.0e300)) return (float)(20.0 * log10(hypot(re, im)));          // overflow / infinity: slow exact path
+  return (float)(3.0102999566398120 * log2_table(p, tab));
 }
 
 template <typename T, int TW>
@@ -78,7 +112,7 @@ __global__ __launch_bounds__(64 * TW * NT) void stft2_kernel(
     const float* __restrict__ x, const int64_t* __restrict__ off, const int32_t* __restrict__ nframes, int hop,
     const T* __restrict__ window, const cplx<T>* __restrict__ tw, T floor_lin, float floor_db,
     float* __restrict__ out, const int64_t* __restrict__ out_off, const int32_t* __restrict__ frame_sel,
-    const int64_t* __restrict__ sel_off, int ablate) {
+    const int64_t* __restrict__ sel_off, int ablate, unsigned lds_main) {
   using C = Cfg<T, TW>;
   constexpr int TB = NT * FS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -98,6 +132,12 @@ __global__ __launch_bounds__(64 * TW * NT) void stft2_kernel(
   const int team = __builtin_amdgcn_readfirstlane(tid / C::TL), q0 = tid % C::TL;
   cplx<T>* ex = reinterpret_cast<cplx<T>*>(smem_raw) + (size_t)team * C::EX;
   const float* xs = x + off[seg];
+  // float64 only: log table behind everything else in LDS (never aliased by the tile)
+  LogTabEntry* ltab = reinterpret_cast<LogTabEntry*>(smem_raw + lds_main);
+  if (sizeof(T) == 8) {
+    build_log_table(ltab, tid);
+    __syncthreads();
+  }
 
   // per-lane twiddle bases (same for every frame)
   cplx<T> base1[2];
@@ -224,12 +264,12 @@ __global__ __launch_bounds__(64 * TW * NT) void stft2_kernel(
       const cplx<T> o = {d.im, -d.re};
       const cplx<T> wk = ira::cmul(wlane, tw[C::TL * i]);       // W_N^k = W_N^q * W_N^(TL*i); second factor wave-uniform
       const cplx<T> pp = ira::cmul(wk, o);
-      lo[i] = power_to_db<T>(e.re + pp.re, e.im + pp.im, floor_lin, floor_db);
-      hi[i] = power_to_db<T>(e.re - pp.re, e.im - pp.im, floor_lin, floor_db);
+      lo[i] = power_to_db<T>(e.re + pp.re, e.im + pp.im, floor_lin, floor_db, ltab);
+      hi[i] = power_to_db<T>(e.re - pp.re, e.im - pp.im, floor_lin, floor_db, ltab);
     }
     {
       const cplx<T> zm = ex[C::M / 2 + (C::M / 32)];
-      mid = power_to_db<T>(zm.re, zm.im, floor_lin, floor_db);
+      mid = power_to_db<T>(zm.re, zm.im, floor_lin, floor_db, ltab);
     }
     if (fs == FS - 1) IRA_STAMP(4);
     if (FS == 2 && fs == 0) {
@@ -300,7 +340,8 @@ int32_t launch2(const float* x, const int64_t* off, const int32_t* nframes, int3
   constexpr int TB = NT * FS;
   size_t lds_ex = (size_t)NT * C::EX * sizeof(cplx<T>);
   size_t lds_tile = (size_t)C::F * (TB + 1) * sizeof(float);
-  size_t lds = lds_ex > lds_tile ? lds_ex : lds_tile;
+  const size_t lds_main = ((lds_ex > lds_tile ? lds_ex : lds_tile) + 15) & ~(size_t)15;
+  const size_t lds = lds_main + (sizeof(T) == 8 ? LOGTAB_N * sizeof(LogTabEntry) : 0);
   if (lds > 160 * 1024) return IRA_E_SIZE;
   auto kern = stft2_kernel<T, TW, NT, FS>;
   if (lds > 64 * 1024) {
@@ -313,7 +354,7 @@ int32_t launch2(const float* x, const int64_t* off, const int32_t* nframes, int3
   dim3 grid((max_frames + TB - 1) / TB, nseg);
   kern<<<grid, 64 * TW * NT, lds, st>>>(x, off, nframes, hop, static_cast<const T*>(window),
                                         static_cast<const cplx<T>*>(tw), (T)floor_lin, (float)floor_db, out, out_off,
-                                        frame_sel, sel_off, ablate);
+                                        frame_sel, sel_off, ablate, (unsigned)lds_main);
   IRA_RETURN_LAUNCH();
 }
 
