@@ -223,7 +223,6 @@ def rt60_bands_device(eng, batch, sample_rate_hz: int, settings: Rt60BandsAnalys
     records = np.stack([band_mask_record(b, settings.transition_width_octaves, nyq) for b in bands]) \
         if bands else np.zeros((0, 8))
     nb = len(bands)
-    npair = (nb + 1) // 2
 
     fits_spec = [("t30", dec.t30_range_db)]
     if settings.include_t20:
@@ -249,16 +248,15 @@ def rt60_bands_device(eng, batch, sample_rate_hz: int, settings: Rt60BandsAnalys
             pos += int(n_all[c])
     y = eng.empty(pos, t.float32)
     if nb:
-        el_spec, el_len, el_par, el_fv, el_y1, el_y2 = [], [], [], [], [], []
+        # one entry per (channel, band); the engine pairs entries of equal length two per inverse transform
+        el_spec, el_len, el_par, el_fv, el_y = [], [], [], [], []
         for c in range(nch):
             fv = rfft_bin_step(int(n_all[c]), sample_rate_hz)
-            for p in range(npair):
-                b1, b2 = 2 * p, 2 * p + 1
+            for b in range(nb):
                 el_spec.append(spec_off[c]); el_len.append(int(n_all[c])); el_fv.append(fv)
-                el_par.append(np.stack([records[b1], records[b2] if b2 < nb else np.zeros(8)]))
-                el_y1.append(y_off[c, b1]); el_y2.append(y_off[c, b2] if b2 < nb else -1)
+                el_par.append(records[b]); el_y.append(y_off[c, b])
         eng.band_irfft(spec, np.array(el_spec, np.int64), np.array(el_len, np.int32), np.stack(el_par),
-                       np.array(el_fv, np.float64), y, np.array(el_y1, np.int64), np.array(el_y2, np.int64))
+                       np.array(el_fv, np.float64), y, np.array(el_y, np.int64))
 
     # Schroeder EDC + fits on every (channel, band) tail with at least 8 samples
     seg_c, seg_b, seg_off, seg_len = [], [], [], []

@@ -97,10 +97,12 @@ struct Jobs {
   // signal input
   const float* x;
   const int64_t* xoff;
+  const int64_t* x2off;     // optional: second real signal of the same length (-1: none) -> z = x1 + i x2
   int use_hann;
   // masked-spectrum input
   const cd* spec;           // half spectra, complex f64
   const int64_t* spec_off;  // element e reads spec + spec_off[e], (L/2+1) bins
+  const int64_t* spec_off2; // optional: the SECOND band's spectrum (another channel of the same length); null = same
   const BandMask* bands;    // 2 per element
   const double* freq_val;   // rfftfreq step of element e: bin k -> float32(k * freq_val[e])
   // filter spectra
@@ -109,6 +111,9 @@ struct Jobs {
   // outputs
   cd* spec_out;
   const int64_t* spec_out_off;
+  const int64_t* spec_out_off2;  // second signal's half spectrum (paired elements)
+  cd* zpair;                // full-length DFT of x1 + i x2 (paired elements), L entries at zpair_off[e]
+  const int64_t* zpair_off;
   float* y;
   const int64_t* y1_off;    // first band signal of element e (length L)
   const int64_t* y2_off;    // second band signal or -1
@@ -123,9 +128,15 @@ __device__ __forceinline__ cd gen_input(const Jobs& J, int e, long long n, long 
   if (MODE == IN_SIGNAL) {
     if (n >= L) return {0.0, 0.0};
     double v = (double)J.x[J.xoff[e] + n];
-    if (J.use_hann) v *= hann_at(n, L);
+    const long long o2 = J.x2off ? J.x2off[e] : -1;
+    double v2 = o2 >= 0 ? (double)J.x[o2 + n] : 0.0;
+    if (J.use_hann) {
+      const double h = hann_at(n, L);
+      v *= h; v2 *= h;
+    }
     const cd w = chirp(n, L);
-    return {v * w.re, v * w.im};
+    if (o2 < 0) return {v * w.re, v * w.im};
+    return {v * w.re - v2 * w.im, v * w.im + v2 * w.re};
   } else if (MODE == IN_FILTER) {
     long long m = n;
     if (n >= L) {
@@ -144,7 +155,14 @@ __device__ __forceinline__ cd gen_input(const Jobs& J, int e, long long n, long 
     const float f = (float)((double)k * J.freq_val[e]);
     const double m1 = (double)mask_at(J.bands[2 * e], f);
     const double m2 = (double)mask_at(J.bands[2 * e + 1], f);
-    const cd wk = ira::cmul(xk, cd{m1, m2});
+    cd wk;
+    if (J.spec_off2 == nullptr || J.spec_off2[e] == J.spec_off[e]) {
+      wk = ira::cmul(xk, cd{m1, m2});
+    } else {                                        // X1 m1 + i X2 m2: band 1 of one channel, band 2 of another
+      cd x2 = J.spec[J.spec_off2[e] + k];
+      if (upper) x2.im = -x2.im;
+      wk = {xk.re * m1 - x2.im * m2, xk.im * m1 + x2.re * m2};
+    }
     const cd cw = {wk.re, -wk.im};
     return ira::cmul(cw, chirp(n, L));
   }
@@ -245,7 +263,8 @@ __global__ __launch_bounds__(FL_THREADS) void cols_inv_kernel(Geom g, Jobs J, co
   const unsigned stride = N1 + 1;
   const int tid = threadIdx.x;
   // outputs needed: n <= L/2 (spectrum) or n < L (bands); rows beyond that are computed but not stored
-  const long long n_need = (MODE == OUT_SPECTRUM) ? L / 2 + 1 : L;
+  const bool paired = (MODE == OUT_SPECTRUM) && J.x2off != nullptr && J.x2off[e] >= 0;
+  const long long n_need = (MODE == OUT_SPECTRUM && !paired) ? L / 2 + 1 : L;
   const cd* w = work + (long long)e * M;
   for (unsigned i = tid; i < N1 * (unsigned)C; i += FL_THREADS) {
     const unsigned c = i % C, r = i / C;
@@ -262,8 +281,12 @@ __global__ __launch_bounds__(FL_THREADS) void cols_inv_kernel(Geom g, Jobs J, co
     v = ira::cmul(v, chirp(n, L));
     if (MODE == OUT_SPECTRUM) {
       v.re *= inv_m; v.im *= inv_m;
-      if (n == 0 || (2 * n == L)) v.im = 0.0;  // DC / Nyquist of a real signal
-      J.spec_out[J.spec_out_off[e] + n] = v;
+      if (paired) {
+        J.zpair[J.zpair_off[e] + n] = v;         // split into the two half spectra by pair_split_kernel
+      } else {
+        if (n == 0 || (2 * n == L)) v.im = 0.0;  // DC / Nyquist of a real signal
+        J.spec_out[J.spec_out_off[e] + n] = v;
+      }
     } else {
       const double sc = inv_m / (double)L;
       // y1 + i y2 = conj(v) / L
@@ -272,6 +295,34 @@ __global__ __launch_bounds__(FL_THREADS) void cols_inv_kernel(Geom g, Jobs J, co
       if (o2 >= 0) J.y[o2 + n] = (float)(-v.im * sc);
     }
   }
+}
+
+// Two real signals per transform: with Z = DFT(x1 + i x2),
+//   X1[k] = (Z[k] + conj Z[L-k]) / 2,   X2[k] = (Z[k] - conj Z[L-k]) / (2i),   k = 0 .. L/2.
+// k = 0 and k = L/2 pair a bin with itself, so their imaginary parts come out exactly zero like numpy's rfft.
+__global__ __launch_bounds__(256) void pair_split_kernel(Jobs J) {
+  const int e = blockIdx.y;
+  if (J.x2off[e] < 0) return;
+  const long long L = J.L[e];
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > L / 2) return;
+  const cd* z = J.zpair + J.zpair_off[e];
+  const cd zk = z[k], zl = z[k == 0 ? 0 : L - k];
+  J.spec_out[J.spec_out_off[e] + k] = {0.5 * (zk.re + zl.re), 0.5 * (zk.im - zl.im)};
+  J.spec_out[J.spec_out_off2[e] + k] = {0.5 * (zk.im + zl.im), 0.5 * (zl.re - zk.re)};
+}
+
+// M = N1 x N2.  The column passes (K1, K3) touch C adjacent columns of every row, i.e. C*16-byte pieces at a stride
+// of N2*16 bytes, and C is what fits in LDS: a SHORT column (small N1) buys wide pieces.  IRA_FFT_SPLIT overrides
+// log2(N1) for tuning; ira_fft_split() is the single source of truth the host sizes its tables from.
+int split_log2n1(int log2m) {
+  static const int forced = std::getenv("IRA_FFT_SPLIT") ? std::atoi(std::getenv("IRA_FFT_SPLIT")) : 0;
+  int l1 = (log2m + 1) / 2;
+  if (forced > 0) l1 = forced;
+  if (l1 < 2) l1 = 2;
+  if (l1 > log2m - 2) l1 = log2m - 2;
+  if (log2m - l1 > 13) l1 = log2m - 13;      // one row (N2 complex f64) must fit in LDS: N2 <= 8192
+  return l1;
 }
 
 struct Plan {
@@ -283,8 +334,8 @@ struct Plan {
 int32_t make_plan(int log2m, const void* t1, const void* t2, const void* tf, Plan* p) {
   if (log2m < 4 || log2m > 22) return IRA_E_SIZE;
   p->g.log2m = log2m;
-  p->g.log2n1 = (log2m + 1) / 2;
-  p->g.log2n2 = log2m / 2;
+  p->g.log2n1 = split_log2n1(log2m);
+  p->g.log2n2 = log2m - p->g.log2n1;
   p->g.t1 = static_cast<const cd*>(t1);
   p->g.t2 = static_cast<const cd*>(t2);
   p->g.tf = static_cast<const cd*>(tf);
@@ -354,7 +405,9 @@ extern "C" int32_t ira_bluestein_filter(const int32_t* L_dev, int32_t nfilt, int
 extern "C" int32_t ira_rfft_any(const float* x_dev, const int64_t* xoff_dev, const int32_t* L_dev, int32_t nb,
                                 int32_t use_hann, int32_t log2m, const void* t1_dev, const void* t2_dev,
                                 const void* tf_dev, const double* bfilt_dev, const int32_t* bidx_dev,
-                                double* work_dev, double* spec_out_dev, const int64_t* spec_off_dev, void* stream) {
+                                double* work_dev, double* spec_out_dev, const int64_t* spec_off_dev,
+                                const int64_t* x2off_dev, const int64_t* spec_off2_dev, double* zpair_dev,
+                                const int64_t* zpair_off_dev, int32_t max_len, void* stream) {
   IRA_CHECK_PTR(x_dev); IRA_CHECK_PTR(xoff_dev); IRA_CHECK_PTR(L_dev); IRA_CHECK_PTR(t1_dev); IRA_CHECK_PTR(t2_dev);
   IRA_CHECK_PTR(tf_dev); IRA_CHECK_PTR(bfilt_dev); IRA_CHECK_PTR(bidx_dev); IRA_CHECK_PTR(work_dev);
   IRA_CHECK_PTR(spec_out_dev); IRA_CHECK_PTR(spec_off_dev);
@@ -366,14 +419,24 @@ extern "C" int32_t ira_rfft_any(const float* x_dev, const int64_t* xoff_dev, con
   J.L = L_dev; J.x = x_dev; J.xoff = xoff_dev; J.use_hann = use_hann;
   J.bfilt = reinterpret_cast<const cd*>(bfilt_dev); J.bidx = bidx_dev;
   J.spec_out = reinterpret_cast<cd*>(spec_out_dev); J.spec_out_off = spec_off_dev;
-  return run_convolution<IN_SIGNAL, OUT_SPECTRUM>(p, J, reinterpret_cast<cd*>(work_dev), nb, (hipStream_t)stream);
+  if (x2off_dev != nullptr) {
+    if (spec_off2_dev == nullptr || zpair_dev == nullptr || zpair_off_dev == nullptr) return IRA_E_NULL;
+    if (max_len <= 0) return IRA_E_SIZE;
+    J.x2off = x2off_dev; J.spec_out_off2 = spec_off2_dev;
+    J.zpair = reinterpret_cast<cd*>(zpair_dev); J.zpair_off = zpair_off_dev;
+  }
+  rc = run_convolution<IN_SIGNAL, OUT_SPECTRUM>(p, J, reinterpret_cast<cd*>(work_dev), nb, (hipStream_t)stream);
+  if (rc != IRA_OK || x2off_dev == nullptr) return rc;
+  pair_split_kernel<<<dim3((max_len / 2 + 1 + 255) / 256, nb), 256, 0, (hipStream_t)stream>>>(J);
+  IRA_RETURN_LAUNCH();
 }
 
 extern "C" int32_t ira_band_irfft(const double* spec_dev, const int64_t* spec_off_dev, const int32_t* L_dev,
                                   int32_t nb, const double* band_params_dev, const double* freq_val_dev,
                                   int32_t log2m, const void* t1_dev, const void* t2_dev, const void* tf_dev,
                                   const double* bfilt_dev, const int32_t* bidx_dev, double* work_dev, float* y_dev,
-                                  const int64_t* y1_off_dev, const int64_t* y2_off_dev, void* stream) {
+                                  const int64_t* y1_off_dev, const int64_t* y2_off_dev,
+                                  const int64_t* spec_off2_dev, void* stream) {
   IRA_CHECK_PTR(spec_dev); IRA_CHECK_PTR(spec_off_dev); IRA_CHECK_PTR(L_dev); IRA_CHECK_PTR(band_params_dev);
   IRA_CHECK_PTR(freq_val_dev); IRA_CHECK_PTR(t1_dev); IRA_CHECK_PTR(t2_dev); IRA_CHECK_PTR(tf_dev);
   IRA_CHECK_PTR(bfilt_dev); IRA_CHECK_PTR(bidx_dev); IRA_CHECK_PTR(work_dev); IRA_CHECK_PTR(y_dev);
@@ -385,9 +448,17 @@ extern "C" int32_t ira_band_irfft(const double* spec_dev, const int64_t* spec_of
   static_assert(sizeof(BandMask) == 8 * sizeof(double), "band parameter record is 8 doubles");
   Jobs J{};
   J.L = L_dev;
-  J.spec = reinterpret_cast<const cd*>(spec_dev); J.spec_off = spec_off_dev;
+  J.spec = reinterpret_cast<const cd*>(spec_dev); J.spec_off = spec_off_dev; J.spec_off2 = spec_off2_dev;
   J.bands = reinterpret_cast<const BandMask*>(band_params_dev); J.freq_val = freq_val_dev;
   J.bfilt = reinterpret_cast<const cd*>(bfilt_dev); J.bidx = bidx_dev;
   J.y = y_dev; J.y1_off = y1_off_dev; J.y2_off = y2_off_dev;
   return run_convolution<IN_SPECTRUM, OUT_BANDS>(p, J, reinterpret_cast<cd*>(work_dev), nb, (hipStream_t)stream);
+}
+
+extern "C" int32_t ira_fft_split(int32_t log2m, int32_t* log2n1, int32_t* log2n2) {
+  IRA_CHECK_PTR(log2n1); IRA_CHECK_PTR(log2n2);
+  if (log2m < 4 || log2m > 22) return IRA_E_SIZE;
+  *log2n1 = split_log2n1(log2m);
+  *log2n2 = log2m - *log2n1;
+  return IRA_OK;
 }

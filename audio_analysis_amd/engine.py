@@ -297,7 +297,10 @@ class Engine:
     def long_tables(self, log2m: int):
         key = ("long", log2m)
         if key not in self._tables:
-            n1, n2, m = 1 << ((log2m + 1) // 2), 1 << (log2m // 2), 1 << log2m
+            import ctypes
+            l1, l2 = ctypes.c_int32(0), ctypes.c_int32(0)
+            check(self.lib.ira_fft_split(int(log2m), ctypes.byref(l1), ctypes.byref(l2)), "ira_fft_split")
+            n1, n2, m = 1 << l1.value, 1 << l2.value, 1 << log2m
 
             def tab(count, period):
                 ang = -2.0 * np.pi * np.arange(count, dtype=np.float64) / float(period)
@@ -378,6 +381,24 @@ class Engine:
                 i = k + 1
         return pool["buf"], slots[inv].astype(np.int32)
 
+    # Two real signals of equal length share one complex transform (z = x1 + i*x2, Hermitian split), and the odd
+    # band of one channel shares an inverse transform with the odd band of another.  Set False to force one
+    # transform per signal / per channel band pair (A/B switch; results agree to ~1e-16 of the larger signal).
+    pair_real_ffts = True
+
+    @staticmethod
+    def _pair_by_key(idx: np.ndarray, keys: np.ndarray):
+        """Pairs of entries of idx whose keys are equal; leftovers are paired with -1.  Order-stable."""
+        first, second = [], []
+        order = idx[np.argsort(keys[idx], kind="stable")]
+        i = 0
+        while i < order.size:
+            if i + 1 < order.size and keys[order[i]] == keys[order[i + 1]]:
+                first.append(order[i]); second.append(order[i + 1]); i += 2
+            else:
+                first.append(order[i]); second.append(-1); i += 1
+        return np.asarray(first, dtype=np.int64), np.asarray(second, dtype=np.int64)
+
     def rfft_any(self, x_dev, xoff: np.ndarray, lengths: np.ndarray, use_hann: bool):
         """
         Half spectra (complex f64) of x[xoff[e] : xoff[e]+L[e]] (* hanning) for every element.
@@ -386,6 +407,7 @@ class Engine:
         t = self.torch
         n = int(xoff.size)
         lengths = np.ascontiguousarray(lengths, dtype=np.int32)
+        xoff = np.ascontiguousarray(xoff, dtype=np.int64)
         bins = lengths.astype(np.int64) // 2 + 1
         spec_off = np.zeros(n, dtype=np.int64)
         if n > 1:
@@ -393,33 +415,76 @@ class Engine:
         spec = self.empty(int(bins.sum()) * 2, t.float64)
         for lm, idx in self._chunks_by_log2m(lengths):
             t1, t2, tf = self.long_tables(lm)
-            bf, bidx = self._filters(lengths[idx], lm)
-            work = self.empty(int(idx.size) * (2 << lm), t.float64)
-            d_xo, d_l = self.to_dev(np.ascontiguousarray(xoff[idx], dtype=np.int64)), self.to_dev(lengths[idx])
-            d_bi, d_so = self.to_dev(bidx), self.to_dev(spec_off[idx])
-            check(self.lib.ira_rfft_any(_ptr(x_dev), _ptr(d_xo), _ptr(d_l), int(idx.size), 1 if use_hann else 0, lm,
+            if self.pair_real_ffts and idx.size > 1:
+                j1, j2 = self._pair_by_key(idx, lengths)
+            else:
+                j1, j2 = idx.astype(np.int64), np.full(idx.size, -1, dtype=np.int64)
+            jl = lengths[j1]
+            bf, bidx = self._filters(jl, lm)
+            work = self.empty(int(j1.size) * (2 << lm), t.float64)
+            d_xo, d_l = self.to_dev(xoff[j1]), self.to_dev(jl)
+            d_bi, d_so = self.to_dev(bidx), self.to_dev(spec_off[j1])
+            paired = j2 >= 0
+            if paired.any():
+                safe = np.maximum(j2, 0)
+                d_x2 = self.to_dev(np.where(paired, xoff[safe], -1).astype(np.int64))
+                d_so2 = self.to_dev(np.where(paired, spec_off[safe], 0).astype(np.int64))
+                zlen = np.where(paired, jl.astype(np.int64), 0)
+                zoff = np.zeros(j1.size, dtype=np.int64)
+                zoff[1:] = np.cumsum(zlen[:-1])
+                zpair = self.empty(int(zlen.sum()) * 2, t.float64)
+                d_zo = self.to_dev(zoff)
+            else:
+                d_x2 = d_so2 = zpair = d_zo = None
+            check(self.lib.ira_rfft_any(_ptr(x_dev), _ptr(d_xo), _ptr(d_l), int(j1.size), 1 if use_hann else 0, lm,
                                         _ptr(t1), _ptr(t2), _ptr(tf), _ptr(bf), _ptr(d_bi), _ptr(work), _ptr(spec),
-                                        _ptr(d_so), self.stream), "ira_rfft_any")
+                                        _ptr(d_so), _ptr(d_x2), _ptr(d_so2), _ptr(zpair), _ptr(d_zo), int(jl.max()),
+                                        self.stream), "ira_rfft_any")
         return spec, spec_off
 
     def band_irfft(self, spec_dev, spec_off: np.ndarray, lengths: np.ndarray, band_params: np.ndarray,
-                   freq_val: np.ndarray, y_dev, y1_off: np.ndarray, y2_off: np.ndarray):
-        """Masked inverse transforms, two bands per element (see ira_band_irfft in include/ira.h)."""
+                   freq_val: np.ndarray, y_dev, y_off: np.ndarray):
+        """
+        Masked inverse transforms, ONE BAND PER ENTRY: entry j filters the half spectrum at spec_off[j] (length
+        lengths[j], bin step freq_val[j]) with the 8-double mask record band_params[j] and writes lengths[j]
+        float32 samples at y_off[j].  Entries with the same (length, bin step) are inverse-transformed two at a
+        time (y1 + i*y2; see ira_band_irfft in include/ira.h) -- bands of one channel or of two different channels.
+        """
         t = self.torch
         lengths = np.ascontiguousarray(lengths, dtype=np.int32)
-        for lm, idx in self._chunks_by_log2m(lengths):
+        spec_off = np.ascontiguousarray(spec_off, dtype=np.int64)
+        y_off = np.ascontiguousarray(y_off, dtype=np.int64)
+        band_params = np.ascontiguousarray(band_params, dtype=np.float64).reshape(-1, 8)
+        freq_val = np.ascontiguousarray(freq_val, dtype=np.float64)
+        # pair key: same transform length AND same float64 bin step (AND same spectrum when cross-channel pairing is off)
+        cols = [lengths.astype(np.float64), freq_val]
+        if not self.pair_real_ffts:
+            cols.append(spec_off.astype(np.float64))
+        _, key = np.unique(np.stack(cols, axis=1), axis=0, return_inverse=True)
+        j1, j2 = self._pair_by_key(np.arange(lengths.size), key.reshape(-1))
+        jl = lengths[j1]
+        safe = np.maximum(j2, 0)
+        has2 = j2 >= 0
+        el_par = np.zeros((j1.size, 2, 8), dtype=np.float64)
+        el_par[:, 0, :] = band_params[j1]
+        el_par[has2, 1, :] = band_params[safe[has2]]
+        el_so2 = np.where(has2, spec_off[safe], spec_off[j1]).astype(np.int64)
+        el_y2 = np.where(has2, y_off[safe], -1).astype(np.int64)
+        for lm, sel in self._chunks_by_log2m(jl):
             t1, t2, tf = self.long_tables(lm)
-            bf, bidx = self._filters(lengths[idx], lm)
-            work = self.empty(int(idx.size) * (2 << lm), t.float64)
-            d_so, d_l = self.to_dev(np.ascontiguousarray(spec_off[idx], np.int64)), self.to_dev(lengths[idx])
-            d_bp = self.to_dev(np.ascontiguousarray(band_params[idx], dtype=np.float64))
-            d_fv = self.to_dev(np.ascontiguousarray(freq_val[idx], dtype=np.float64))
+            bf, bidx = self._filters(jl[sel], lm)
+            work = self.empty(int(sel.size) * (2 << lm), t.float64)
+            d_so, d_l = self.to_dev(spec_off[j1][sel]), self.to_dev(jl[sel])
+            d_bp = self.to_dev(np.ascontiguousarray(el_par[sel]))
+            d_fv = self.to_dev(np.ascontiguousarray(freq_val[j1][sel]))
             d_bi = self.to_dev(bidx)
-            d_y1 = self.to_dev(np.ascontiguousarray(y1_off[idx], np.int64))
-            d_y2 = self.to_dev(np.ascontiguousarray(y2_off[idx], np.int64))
-            check(self.lib.ira_band_irfft(_ptr(spec_dev), _ptr(d_so), _ptr(d_l), int(idx.size), _ptr(d_bp), _ptr(d_fv),
+            d_y1 = self.to_dev(np.ascontiguousarray(y_off[j1][sel]))
+            d_y2 = self.to_dev(np.ascontiguousarray(el_y2[sel]))
+            d_so2 = self.to_dev(np.ascontiguousarray(el_so2[sel]))
+            check(self.lib.ira_band_irfft(_ptr(spec_dev), _ptr(d_so), _ptr(d_l), int(sel.size), _ptr(d_bp), _ptr(d_fv),
                                           lm, _ptr(t1), _ptr(t2), _ptr(tf), _ptr(bf), _ptr(d_bi), _ptr(work),
-                                          _ptr(y_dev), _ptr(d_y1), _ptr(d_y2), self.stream), "ira_band_irfft")
+                                          _ptr(y_dev), _ptr(d_y1), _ptr(d_y2), _ptr(d_so2), self.stream),
+                  "ira_band_irfft")
 
     def spectrum_mag_phase(self, spec_dev, spec_off: np.ndarray, lengths: np.ndarray, floor_db: float,
                            want_phase: bool):

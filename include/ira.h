@@ -106,11 +106,15 @@ int32_t ira_stft_mag_db(const float* x_dev, const int64_t* off_dev, const int32_
 
 /* ---- a9/a17: arbitrary-length float64 DFTs (Bluestein over a four-step power-of-two FFT) ---------------
  * Common arguments: log2m with M = 2^log2m >= 2*max(L) - 1 (4 <= log2m <= 22); three caller-provided
- * complex-f64 tables for M = N1*N2, N1 = 2^ceil(log2m/2), N2 = 2^floor(log2m/2):
+ * complex-f64 tables for M = N1*N2 with the split ira_fft_split() reports (N1 = 2^log2n1, N2 = 2^log2n2):
  *   t1_dev[k] = exp(-2 pi i k/N1), k < N1;  t2_dev[k] = exp(-2 pi i k/N2), k < N2;
  *   tf_dev[k] = exp(-2 pi i k/M),  k < N2.
  * work_dev: nb * M complex f64 of scratch.  bfilt_dev: chirp-filter spectra built by ira_bluestein_filter,
  * M complex f64 each; bidx_dev[e] selects the filter (the one built for length L[e]) of element e. */
+
+/* The four-step split the library uses for M = 2^log2m (host code sizes t1/t2/tf from it).  No reference
+ * counterpart: numpy's pocketfft plans internally (reference analyse/frequency_response.py:204). */
+int32_t ira_fft_split(int32_t log2m, int32_t* log2n1, int32_t* log2n2);
 
 /* bfilt_dev[j] = FFT_M of the Bluestein chirp filter for length L_dev[j], j < nfilt. */
 int32_t ira_bluestein_filter(const int32_t* L_dev, int32_t nfilt, int32_t log2m, const void* t1_dev,
@@ -119,11 +123,18 @@ int32_t ira_bluestein_filter(const int32_t* L_dev, int32_t nfilt, int32_t log2m,
 /* spec_out[e][k] = sum_n x[xoff[e]+n] * (hanning(L[e])[n] | 1) * exp(-2 pi i n k / L[e]),  k = 0..L[e]/2,
  * complex f64 at spec_out_dev + 2*spec_off_dev[e] doubles.  Replaces np.fft.rfft(x * w) of arbitrary
  * length at reference analyse/frequency_response.py:204-213, analyse/filterplot.py:145-152 and the
- * forward transform of analyse/rt60bands.py:172. */
+ * forward transform of analyse/rt60bands.py:172.
+ * Two real signals of the SAME length can share one transform (z = x1 + i*x2, split by Hermitian symmetry):
+ * x2off_dev (may be NULL = no pairs) gives the second signal of element e or -1; its spectrum goes to
+ * spec_off2_dev[e]; zpair_dev/zpair_off_dev is scratch for the full-length complex DFT (L[e] complex f64 per
+ * paired element) and max_len >= max L[e].  Cross-talk between the two signals is at the 1e-16 level of the
+ * larger one. */
 int32_t ira_rfft_any(const float* x_dev, const int64_t* xoff_dev, const int32_t* L_dev, int32_t nb,
                      int32_t use_hann, int32_t log2m, const void* t1_dev, const void* t2_dev,
                      const void* tf_dev, const double* bfilt_dev, const int32_t* bidx_dev,
-                     double* work_dev, double* spec_out_dev, const int64_t* spec_off_dev, void* stream);
+                     double* work_dev, double* spec_out_dev, const int64_t* spec_off_dev,
+                     const int64_t* x2off_dev, const int64_t* spec_off2_dev, double* zpair_dev,
+                     const int64_t* zpair_off_dev, int32_t max_len, void* stream);
 
 /* Band filter bank: element e takes the half spectrum at spec_dev + 2*spec_off_dev[e] (length L[e]/2+1),
  * multiplies it by TWO real masks (band_params_dev: 2 records of IRA_BAND_DOUBLES doubles per element:
@@ -131,13 +142,16 @@ int32_t ira_rfft_any(const float* x_dev, const int64_t* xoff_dev, const int32_t*
  * [3] lp ramp start (pass edge), [4] lp ramp end; masks are evaluated in float32 on the float32 axis
  * float32(k*freq_val[e]) exactly as reference analyse/rt60bands.py:116-167) and inverse-transforms both
  * at once (y1 + i*y2), writing float32 signals of length L[e] at y_dev + y1_off[e] and y_dev + y2_off[e]
- * (y2_off[e] < 0: no second band).  Replaces _apply_fft_mask, reference analyse/rt60bands.py:170-175. */
+ * (y2_off[e] < 0: no second band).  spec_off2_dev (may be NULL) lets the SECOND band come from another
+ * spectrum of the same length and bin step (e.g. the odd band of two different channels share one inverse
+ * transform): band 2 of element e then filters spec_dev + 2*spec_off2_dev[e].  Replaces _apply_fft_mask, reference analyse/rt60bands.py:170-175. */
 #define IRA_BAND_DOUBLES 8
 int32_t ira_band_irfft(const double* spec_dev, const int64_t* spec_off_dev, const int32_t* L_dev,
                        int32_t nb, const double* band_params_dev, const double* freq_val_dev,
                        int32_t log2m, const void* t1_dev, const void* t2_dev, const void* tf_dev,
                        const double* bfilt_dev, const int32_t* bidx_dev, double* work_dev, float* y_dev,
-                       const int64_t* y1_off_dev, const int64_t* y2_off_dev, void* stream);
+                       const int64_t* y1_off_dev, const int64_t* y2_off_dev,
+                       const int64_t* spec_off2_dev, void* stream);
 
 /* ---- a17/a18: spectrum post-processing -------------------------------------------------------------------
  * mag_db[e][k] = float32(20 log10(max(|X|, 10^(floor_db/20)))), optional phase[e][k] = atan2(im, re) (f64).

@@ -39,6 +39,76 @@ def test_rfft_any_lengths():
             assert g[0, 1] == 0.0
 
 
+def test_rfft_any_pairs_equal_lengths():
+    """Equal-length signals share one complex transform (x1 + i*x2): same spectra as unpaired, odd counts, DC/Nyquist."""
+    from audio_analysis_amd.engine import get_engine
+    eng = get_engine()
+    rng = np.random.default_rng(5)
+    n = 30011
+    # very different levels on purpose: cross-talk stays at 1e-16 of the LARGER partner
+    chans = [(rng.standard_normal(n) * np.exp(-np.arange(n) / 4000.0) * s).astype(np.float32) for s in (1.0, 1e-3, 0.3, 2.0, 0.7)]
+    b = eng.upload(chans)
+    for L_list in ([30000, 30000, 30000, 30000, 30000], [30011, 30000, 30011, 30000, 30011], [2, 2, 1, 1, 3], [4096] * 5):
+        for hann in (False, True):
+            lens = np.array(L_list, np.int32)
+            assert eng.pair_real_ffts
+            spec, off = eng.rfft_any(b.x, b.off, lens, hann)
+            h = spec.cpu().numpy()
+            peak = 0.0
+            refs = []
+            for c, L in zip(chans, L_list):
+                seg = c[:L].astype(np.float64)
+                if hann:
+                    seg = seg * np.hanning(L)
+                refs.append(np.fft.rfft(seg))
+                peak = max(peak, float(np.max(np.abs(refs[-1]))))
+            for o, L, ref in zip(off, L_list, refs):
+                g = h[2 * o : 2 * (o + L // 2 + 1)].reshape(-1, 2)
+                err = np.max(np.abs(g[:, 0] + 1j * g[:, 1] - ref)) / max(peak, 1e-300)
+                assert err < 5e-14, (L_list, hann, err)
+                assert g[0, 1] == 0.0
+                if L % 2 == 0:
+                    assert g[-1, 1] == 0.0
+    # A/B: unpaired path gives the same numbers to rounding
+    try:
+        eng.pair_real_ffts = False
+        lens = np.array([30000] * 5, np.int32)
+        s1, off = eng.rfft_any(b.x, b.off, lens, True)
+    finally:
+        eng.pair_real_ffts = True
+    s2, _ = eng.rfft_any(b.x, b.off, lens, True)
+    a1, a2 = s1.cpu().numpy(), s2.cpu().numpy()
+    assert np.max(np.abs(a1 - a2)) / np.max(np.abs(a1)) < 1e-14
+
+
+def test_band_pairs_across_channels_match_unpaired():
+    """rt60bands, three bands x two equal-length channels: the odd bands share one inverse transform."""
+    from audio_analysis_amd.analyse import rt60bands as rb
+    from audio_analysis_amd.engine import get_engine
+    from audio_analysis_amd.synth import synth_ir
+    eng = get_engine()
+    chans = [synth_ir(40 + i, 0, 60000, rt60_seconds=0.4 + 0.2 * i) for i in range(3)]
+    names = ["a", "b", "c"]
+    st = rb.Rt60BandsAnalysisSettings(band_mode="three", include_t20=True, include_edt=True)
+    paired = rb.analyse_rt60_bands_batch(chans, SR, names, st)
+    try:
+        eng.pair_real_ffts = False
+        single = rb.analyse_rt60_bands_batch(chans, SR, names, st)
+    finally:
+        eng.pair_real_ffts = True
+    for x, p, s in zip(chans, paired, single):
+        o = O.analyse_rt60_bands(x, SR, band_mode="three", include_t20=True, include_edt=True)
+        assert list(p.band_metrics_by_name) == list(s.band_metrics_by_name) == [b["name"] for b in o["bands"]]
+        for name, mp in p.band_metrics_by_name.items():
+            ms, mo = s.band_metrics_by_name[name], o["metrics"][name]
+            for field, key in (("rt60_t30_seconds", "t30"), ("rt60_t20_seconds", "t20"), ("edt_seconds", "edt")):
+                vp, vs, vo = getattr(mp, field), getattr(ms, field), mo[key]
+                assert (vp is None) == (vo is None) == (vs is None), (name, field, vp, vs, vo)
+                if vo is not None:
+                    assert _rel(vp, vo) < 1e-4 and _rel(vs, vo) < 1e-4, (name, field, vp, vs, vo)
+                    assert _rel(vp, vs) < 1e-6
+
+
 @pytest.mark.parametrize("tag,inp", [("xa", "xa"), ("xc", "xc"), ("xd", "xd"), ("xa_sel", "xa"), ("xa_rect", "xa")])
 def test_fr_and_filter_vs_golden(golden, tag, inp):
     from audio_analysis_amd.analyse import filterplot, frequency_response as fr

@@ -11,7 +11,7 @@ DEFAULT_GROUPS="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LD
 IFS=';' read -ra GROUPS_ARR <<< "${PMC_GROUPS:-$DEFAULT_GROUPS}"
 for grp in "${GROUPS_ARR[@]}"; do
   i=$((i+1))
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$R/$out/p$i" -- python3 "$R/tools/stft_probe.py" --iters 3 "$@" > "$R/$out/p$i.log" 2>&1 || echo "pass $i failed" >> "$R/$out/fail.log"
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$R/$out/p$i" -- python3 "$R/tools/${PMC_PROBE:-stft_probe.py}" ${PMC_PROBE_ARGS:---iters 3} "$@" > "$R/$out/p$i.log" 2>&1 || echo "pass $i failed" >> "$R/$out/fail.log"
 done
 python3 - "$R/$out" <<'PY'
 import csv, glob, sys, collections
@@ -23,6 +23,6 @@ for f in sorted(glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[(k, r["Counter_Name"])] += 1
     for k, d in acc.items():
-        if "stft" in k:
+        if any(t in k for t in ("stft", "cols_", "rows_", "edc", "curve", "gram")):
             print(f.split("/")[-3] if "/p" in f else f, k, {c: v / cnt[(k, c)] for c, v in d.items()})
 PY
