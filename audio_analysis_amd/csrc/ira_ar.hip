@@ -3,7 +3,13 @@
 // The reference solves the covariance-method least squares  min || A a + x ||,  A[n,k] = x[n-k] (n = p..N-1,
 // k = 1..p) with an SVD (numpy.linalg.lstsq) over an (N-p) x p matrix -- 4 s of LAPACK per 10 s channel.
 // Here:
-//   1. ar_gram_kernel   G = A^T A and r = A^T y as a dense float64 contraction on the matrix cores
+//   1. ar_lag_kernel    (default) the normal equations of the covariance method have SHIFT structure: with
+//                       Phi[a][b] = sum_{n=p}^{N-1} s[n-a] s[n-b],  G[i][j] = Phi[i+1][j+1],  r[j] = -Phi[0][j+1] and
+//                         Phi[a+1][b+1] = Phi[a][b] + s[p-1-a] s[p-1-b] - s[N-1-a] s[N-1-b],
+//                       so p+1 lag sums Phi[0][0..p] (one pass over the samples, float64 FMAs on exact products of
+//                       float32 samples) plus O(p^2) head/tail corrections give all of G: 2(p+1)N flops instead
+//                       of p(p+1)N.  The corrections are accumulated with compensated (Neumaier) sums.
+//   1'. ar_gram_kernel  (IRA_AR_DENSE=1, cross-check) G = A^T A and r = A^T y as a dense float64 contraction on the matrix cores
 //                       (v_mfma_f64_16x16x4_f64).  A is an implicit Hankel view of the signal: every operand
 //                       fragment is a shifted window of the LDS-staged samples, nothing is materialised.
 //   2. ar_solve_kernel  deterministic reduction of the per-chunk partial Grams, optional ridge, Cholesky,
@@ -15,6 +21,7 @@
 // Float32 is not an option for G: on coloured IRs a float32 Gram loses the poles entirely (SURVEY.md
 // section 7, hard part 1).
 #include <cmath>
+#include <cstdlib>
 
 #include "ira_common.h"
 
@@ -152,6 +159,96 @@ __global__ __launch_bounds__(64) void ar_gram_kernel(const float* __restrict__ x
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Lag sums.  grid (chunks of LAG_CHUNK rows, 1, nb), 256 threads.  The chunk (plus a p+3 sample halo) is staged in
+// LDS as float64; a thread owns FOUR consecutive lags and a sub-range of the rows, sliding a 4-value window so
+// that each row costs two LDS reads for four FMAs; sub-range sums are combined in a fixed order.
+// Partial record of element e (doubles):  [nchunks_max][p+1] lag sums | head s[0..p] | tail s[N-1], s[N-2] .. s[N-1-p]
+// ------------------------------------------------------------------------------------------------------------
+constexpr int LAG_CHUNK = 4096;
+constexpr int LAG_THREADS = 256;
+
+__host__ __device__ inline int lag_chunks(long long max_len, int p) {
+  return (int)((max_len - p + LAG_CHUNK - 1) / LAG_CHUNK);
+}
+__host__ __device__ inline long long lag_record_doubles(long long max_len, int p) {
+  return (long long)lag_chunks(max_len, p) * (p + 1) + 2ll * (p + 1);
+}
+
+__global__ __launch_bounds__(LAG_THREADS) void ar_lag_kernel(const float* __restrict__ x,
+                                                             const double* __restrict__ x64,
+                                                             const int64_t* __restrict__ xoff,
+                                                             const int32_t* __restrict__ nlen,
+                                                             const double* __restrict__ divisor, int p,
+                                                             int nchunks_max, long long rec_doubles,
+                                                             double* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int e = blockIdx.z;
+  const int chunk = blockIdx.x;
+  const long long N = nlen[e];
+  const long long row0 = (long long)p + (long long)chunk * LAG_CHUNK;
+  if (row0 >= N) return;
+  const long long n_end = (row0 + LAG_CHUNK < N) ? row0 + LAG_CHUNK : N;
+  const int rows = (int)(n_end - row0);
+  const int halo = p + 3;
+  const long long origin = row0 - halo;              // sample index of lds[0]
+  double* lds = reinterpret_cast<double*>(smem_raw);                 // halo + LAG_CHUNK samples
+  const int nlag = p + 1, ngroups = (nlag + 3) / 4;
+  const int nsub = ngroups >= LAG_THREADS ? 1 : LAG_THREADS / ngroups;
+  double* red = lds + halo + LAG_CHUNK;                              // [nsub][4 * ngroups]
+  const float* xs = x ? x + xoff[e] : nullptr;
+  const double* xd = x64 ? x64 + xoff[e] : nullptr;
+  const double div = divisor ? divisor[e] : 1.0;
+  const int tid = threadIdx.x;
+  double* rec = part + (long long)e * rec_doubles;
+
+  for (int m = tid; m < halo + rows; m += LAG_THREADS) {
+    const long long idx = origin + m;
+    lds[m] = (idx >= 0 && idx < N) ? (xd ? xd[idx] : (double)xs[idx]) / div : 0.0;
+  }
+  if (chunk == 0) {
+    // head and tail samples for the O(p^2) corrections of the solve kernel
+    double* head = rec + (long long)nchunks_max * nlag;
+    double* tail = head + nlag;
+    for (int m = tid; m < nlag; m += LAG_THREADS) {
+      head[m] = (xd ? xd[m] : (double)xs[m]) / div;                         // m <= p < N
+      tail[m] = (xd ? xd[N - 1 - m] : (double)xs[N - 1 - m]) / div;
+    }
+  }
+  __syncthreads();
+
+  const int sub_len = (rows + nsub - 1) / nsub;
+  for (int item = tid; item < ngroups * nsub; item += LAG_THREADS) {
+    const int g = item % ngroups, sub = item / ngroups;
+    const int b0 = 4 * g;
+    const int r_begin = sub * sub_len;
+    const int r_end = (r_begin + sub_len < rows) ? r_begin + sub_len : rows;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (r_begin < r_end) {
+      const double* cur = lds + halo + r_begin;       // s[n] for the first row of the sub-range
+      const double* lag = cur - b0;                   // s[n - b0]
+      double w1 = lag[-1], w2 = lag[-2], w3 = lag[-3];
+      for (int r = r_begin; r < r_end; ++r) {
+        const double sn = *cur++;
+        const double w0 = *lag++;
+        a0 = fma(sn, w0, a0);
+        a1 = fma(sn, w1, a1);
+        a2 = fma(sn, w2, a2);
+        a3 = fma(sn, w3, a3);
+        w3 = w2; w2 = w1; w1 = w0;
+      }
+    }
+    double* o = red + (size_t)sub * (4 * ngroups) + b0;
+    o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+  }
+  __syncthreads();
+  for (int b = tid; b < nlag; b += LAG_THREADS) {
+    double sum = 0.0;
+    for (int sub = 0; sub < nsub; ++sub) sum += red[(size_t)sub * (4 * ngroups) + b];
+    rec[(long long)chunk * nlag + b] = sum;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Reduction of partials + Cholesky + solves.  One 256-thread workgroup per element.
 // The p x p matrix lives in LDS when it fits (p <= 128), otherwise in caller-provided global scratch.
 // ------------------------------------------------------------------------------------------------------------
@@ -163,7 +260,8 @@ __global__ __launch_bounds__(SV_THREADS) void ar_solve_kernel(const double* __re
                                                               int nchunks_max, double ridge,
                                                               double* __restrict__ gscratch,
                                                               double* __restrict__ coeffs,
-                                                              double* __restrict__ info) {
+                                                              double* __restrict__ info, int lag_mode,
+                                                              int lag_nchunks_max, long long lag_rec_doubles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ double piv;
   __shared__ int fail;
@@ -176,26 +274,59 @@ __global__ __launch_bounds__(SV_THREADS) void ar_solve_kernel(const double* __re
   double* G = (p <= SV_LDS_P) ? vec + p : gscratch + (long long)e * p * p;
   const double* pe = part + (long long)e * nchunks_max * ng * GR_PART;
 
-  // ---- deterministic reduction over chunks (fixed order), lower triangle + mirror -------------------------
-  for (int idx = tid; idx < p * p; idx += SV_THREADS) {
-    const int r = idx / p, c = idx - r * p;
-    if (c > r) continue;
-    const int gi = r / GR_GROUP, gj = c / GR_GROUP;
-    const int gid = gi * (gi + 1) / 2 + gj;
-    const int lr = r - gi * GR_GROUP, lc = c - gj * GR_GROUP;
-    double s = 0.0;
-    for (int ch = 0; ch < nchunks; ++ch) s += pe[((long long)ch * ng + gid) * GR_PART + lr * GR_GROUP + lc];
-    if (r == c) s += ridge;
-    G[r * p + c] = s;
-    G[c * p + r] = s;
-  }
-  for (int j = tid; j < p; j += SV_THREADS) {
-    const int gi = j / GR_GROUP;
-    const int gid = gi * (gi + 1) / 2 + gi;
-    double s = 0.0;
-    for (int ch = 0; ch < nchunks; ++ch)
-      s += pe[((long long)ch * ng + gid) * GR_PART + GR_GROUP * GR_GROUP + (j - gi * GR_GROUP)];
-    vec[j] = s;
+  if (lag_mode) {
+    // ---- G and r from the p+1 lag sums and the head/tail samples (see ar_lag_kernel) -----------------------------------
+    const int nlag = p + 1;
+    const double* rec = part + (long long)e * lag_rec_doubles;
+    const double* head = rec + (long long)lag_nchunks_max * nlag;
+    const double* tail = head + nlag;
+    const int lchunks = lag_chunks(N, p);
+    for (int d = tid; d < nlag; d += SV_THREADS) {
+      double c = 0.0;
+      for (int ch = 0; ch < lchunks; ++ch) c += rec[(long long)ch * nlag + d];      // Phi[0][d]
+      if (d >= 1) vec[d - 1] = -c;
+      // walk down diagonal d:  Phi[a][a+d] = Phi[0][d] + sum_{m<a} (s[p-1-m] s[p-1-m-d] - s[N-1-m] s[N-1-m-d])
+      double run = c, comp = 0.0;                                                     // Neumaier compensated sum
+      for (int a = 1; a + d <= p; ++a) {
+        const int m = a - 1;
+        const double t1 = head[p - 1 - m] * head[p - 1 - m - d];
+        const double t2 = -tail[m] * tail[m + d];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const double term = q == 0 ? t1 : t2;
+          const double t = run + term;
+          comp += (fabs(run) >= fabs(term)) ? (run - t) + term : (term - t) + run;
+          run = t;
+        }
+        double v = run + comp;
+        const int r = a + d - 1, cidx = a - 1;                                        // G[r][cidx], r >= cidx
+        if (d == 0) v += ridge;
+        G[r * p + cidx] = v;
+        G[cidx * p + r] = v;
+      }
+    }
+  } else {
+    // ---- deterministic reduction over chunks (fixed order), lower triangle + mirror -------------------------
+    for (int idx = tid; idx < p * p; idx += SV_THREADS) {
+      const int r = idx / p, c = idx - r * p;
+      if (c > r) continue;
+      const int gi = r / GR_GROUP, gj = c / GR_GROUP;
+      const int gid = gi * (gi + 1) / 2 + gj;
+      const int lr = r - gi * GR_GROUP, lc = c - gj * GR_GROUP;
+      double s = 0.0;
+      for (int ch = 0; ch < nchunks; ++ch) s += pe[((long long)ch * ng + gid) * GR_PART + lr * GR_GROUP + lc];
+      if (r == c) s += ridge;
+      G[r * p + c] = s;
+      G[c * p + r] = s;
+    }
+    for (int j = tid; j < p; j += SV_THREADS) {
+      const int gi = j / GR_GROUP;
+      const int gid = gi * (gi + 1) / 2 + gi;
+      double s = 0.0;
+      for (int ch = 0; ch < nchunks; ++ch)
+        s += pe[((long long)ch * ng + gid) * GR_PART + GR_GROUP * GR_GROUP + (j - gi * GR_GROUP)];
+      vec[j] = s;
+    }
   }
   if (tid == 0) fail = 0;
   __syncthreads();
@@ -378,7 +509,16 @@ __global__ void fir_numerator_kernel(const double* __restrict__ coeffs, int p, c
 extern "C" int64_t ira_ar_partial_doubles(int32_t p, int32_t max_len) {
   if (p < 1 || p > GR_MAX_P || max_len <= p) return 0;
   const int64_t nchunks = ((int64_t)max_len - p + GR_CHUNK - 1) / GR_CHUNK;
-  return nchunks * groups_total(p) * (int64_t)GR_PART;
+  const int64_t dense = nchunks * groups_total(p) * (int64_t)GR_PART;       // MFMA Gram partials (IRA_AR_DENSE)
+  const int64_t lag = lag_record_doubles(max_len, p);                        // lag sums + head/tail samples
+  return dense > lag ? dense : lag;
+}
+
+// IRA_AR_DENSE=1 selects the dense MFMA Gram (cross-check / A-B); gram and solve must agree on the record layout.
+// (read on every call so that a test can flip it between two fits)
+static bool ar_dense() {
+  const char* v = std::getenv("IRA_AR_DENSE");
+  return v != nullptr && v[0] != '\0' && v[0] != '0';
 }
 
 static int32_t ar_check(int32_t nb, int32_t max_len, int32_t order) {
@@ -395,6 +535,21 @@ extern "C" int32_t ira_ar_gram(const float* x_dev, const double* x64_dev, const 
   IRA_CHECK_PTR(xoff_dev); IRA_CHECK_PTR(len_dev); IRA_CHECK_PTR(partial_dev);
   const int32_t rc = ar_check(nb, max_len, order);
   if (rc != IRA_OK || nb == 0) return rc;
+  if (!ar_dense()) {
+    const int lchunks = lag_chunks(max_len, order);
+    const int ngroups = (order + 1 + 3) / 4;
+    const int nsub = ngroups >= LAG_THREADS ? 1 : LAG_THREADS / ngroups;
+    const size_t lds = sizeof(double) * ((size_t)(order + 3) + LAG_CHUNK + (size_t)nsub * 4 * ngroups);
+    if (lds > 64 * 1024) {
+      hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&ar_lag_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (er != hipSuccess) return ira_hip_status(er);
+    }
+    ar_lag_kernel<<<dim3(lchunks, 1, nb), LAG_THREADS, lds, (hipStream_t)stream>>>(
+        x64_dev ? nullptr : x_dev, x64_dev, xoff_dev, len_dev, divisor_dev, order, lchunks,
+        lag_record_doubles(max_len, order), partial_dev);
+    IRA_RETURN_LAUNCH();
+  }
   const int nchunks = (int)(((int64_t)max_len - order + GR_CHUNK - 1) / GR_CHUNK);
   const int gs = groups_side(order);
   ar_gram_kernel<true><<<dim3(nchunks, gs, nb), 64, 0, (hipStream_t)stream>>>(
@@ -421,7 +576,9 @@ extern "C" int32_t ira_ar_solve(const double* partial_dev, const int32_t* len_de
     if (e != hipSuccess) return ira_hip_status(e);
   }
   ar_solve_kernel<<<nb, SV_THREADS, lds, (hipStream_t)stream>>>(partial_dev, len_dev, order, nchunks, ridge,
-                                                                 gscratch_dev, coeffs_dev, info_dev);
+                                                                 gscratch_dev, coeffs_dev, info_dev,
+                                                                 ar_dense() ? 0 : 1, lag_chunks(max_len, order),
+                                                                 lag_record_doubles(max_len, order));
   IRA_RETURN_LAUNCH();
 }
 

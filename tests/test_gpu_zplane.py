@@ -92,3 +92,34 @@ def test_zplane_batch_vs_oracle():
         rad, rad_ref = np.sort(np.abs(r.poles)), np.sort(np.abs(o["poles"]))
         assert np.max(np.abs(rad - rad_ref) / rad_ref) < 1e-4
         assert int(np.sum(rad >= 1.0)) == o["unstable"]
+
+
+def test_ar_lag_path_matches_dense_mfma_gram():
+    """The O(pN) lag-sum normal equations (default) against the dense MFMA Gram (IRA_AR_DENSE=1): same coefficients."""
+    import os
+    from audio_analysis_amd.engine import get_engine
+    from audio_analysis_amd.synth import synth_ir
+    eng = get_engine()
+    chans = [synth_ir(70 + i, 0, 30000 + 1234 * i, rt60_seconds=0.3 + 0.1 * i, lowpass_pole=0.2 * i) for i in range(4)]
+    b = eng.upload(chans)
+    for order in (1, 7, 64, 130, 300):
+        lens = b.length.astype(np.int32)
+        c_lag, info_lag = eng.ar_fit(b.x, b.off, lens, None, order)
+        try:
+            os.environ["IRA_AR_DENSE"] = "1"
+            c_dense, info_dense = eng.ar_fit(b.x, b.off, lens, None, order)
+        finally:
+            os.environ.pop("IRA_AR_DENSE", None)
+        a, d = c_lag.cpu().numpy().reshape(len(chans), order + 1), c_dense.cpu().numpy().reshape(len(chans), order + 1)
+        assert np.all(a[:, 0] == 1.0)
+        # both solve the same normal equations; the difference is cond(G) * 1e-16
+        scale = np.max(np.abs(d), axis=1, keepdims=True)
+        assert np.max(np.abs(a - d) / scale) < 1e-7, (order, np.max(np.abs(a - d) / scale))
+        # and against a float64 lstsq on the explicit matrix for the small orders
+        if order <= 64:
+            for i, x in enumerate(chans):
+                s = x.astype(np.float64)
+                n = np.arange(order, s.size)
+                A = np.stack([s[n - k] for k in range(1, order + 1)], axis=1)
+                ref = np.linalg.lstsq(A, -s[n], rcond=None)[0]
+                assert np.max(np.abs(a[i, 1:] - ref)) / np.max(np.abs(ref)) < 1e-6, (order, i)
