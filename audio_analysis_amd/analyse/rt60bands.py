@@ -277,8 +277,10 @@ def rt60_bands_device(eng, batch, sample_rate_hz: int, settings: Rt60BandsAnalys
         ci, bi = np.array(seg_c), np.array(seg_b)
         have[ci, bi] = True
 
+        fut = eng.fetch(fit_dev) if defer else None
+
         def finish():
-            fit = fit_dev.cpu().numpy()
+            fit = fut.get() if fut is not None else fit_dev.cpu().numpy()
             for j, (key, _) in enumerate(fits_spec):
                 col = {"t30": 0, "t20": 1, "edt": 2}[key]
                 ok = fit[:, j, 0] == 1.0

@@ -57,8 +57,9 @@ class ChannelZPlaneResult:
 
 
 def _to_complex(roots_dev, counts_dev) -> List[np.ndarray]:
-    r = roots_dev.cpu().numpy()
-    c = counts_dev.cpu().numpy()
+    """roots/counts: device tensors, or HostFutures from Engine.fetch (deferred path)."""
+    r = roots_dev.get() if hasattr(roots_dev, "get") else roots_dev.cpu().numpy()
+    c = counts_dev.get() if hasattr(counts_dev, "get") else counts_dev.cpu().numpy()
     return [(r[i, : c[i], 0] + 1j * r[i, : c[i], 1]).astype(np.complex128) for i in range(r.shape[0])]
 
 
@@ -139,7 +140,10 @@ def zplane_device(eng, batch, sample_rate_hz: int, settings: ZPlaneAnalysisSetti
     seg_off = batch.off + start
     divisor = None
     if settings.normalise_segment:
-        pk = eng.segment_peaks(batch.x, seg_off, seg_len)
+        if settings.trim_to_peak and skip == 0 and batch.peak_abs is not None:
+            pk = batch.peak_abs.astype(np.float64)      # the segment starts AT the global peak: its max is that sample
+        else:
+            pk = eng.segment_peaks(batch.x, seg_off, seg_len)
         divisor = np.where(pk > 0.0, pk, 1.0)
 
     order = int(settings.ar_order)
@@ -165,6 +169,10 @@ def zplane_device(eng, batch, sample_rate_hz: int, settings: ZPlaneAnalysisSetti
             q = int(max(0, settings.zero_order))
             b = eng.fir_numerator(co, int(p), batch.x, seg_off[idx], seg_len[idx], div, q)
             zr, zc = eng.poly_roots(b, int(idx.size), q + 1, 1e-14)
+        if defer:
+            roots, cnt = eng.fetch(roots), eng.fetch(cnt)
+            if zr is not None:
+                zr, zc = eng.fetch(zr), eng.fetch(zc)
         pending.append((idx, roots, cnt, zr, zc))
 
     def finish():

@@ -47,10 +47,12 @@ def shard_files(num_files: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, hi
 
 
-def gather_metrics(local: np.ndarray, device=None) -> Optional[np.ndarray]:
+def gather_metrics(local: np.ndarray, device=None, stream=None) -> Optional[np.ndarray]:
     """
     Gather per-channel records (n_local, width) float64 from every rank to rank 0, in rank order (= file order
     under shard_files).  Returns the concatenated array on rank 0 and None elsewhere.  Single process: identity.
+    `stream` (RCCL only): enqueue the collective relative to THIS stream instead of the current one, so that a
+    gather of step k does not queue behind the kernels of step k+1 that are already on the compute stream.
     """
     import torch
     import torch.distributed as dist
@@ -58,6 +60,15 @@ def gather_metrics(local: np.ndarray, device=None) -> Optional[np.ndarray]:
     local = np.ascontiguousarray(local, dtype=np.float64)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return local
+    if stream is not None and dist.get_backend() == "nccl":
+        with torch.cuda.stream(stream):
+            return _gather_metrics(local, device)
+    return _gather_metrics(local, device)
+
+
+def _gather_metrics(local: np.ndarray, device=None) -> Optional[np.ndarray]:
+    import torch
+    import torch.distributed as dist
     world, rank = dist.get_world_size(), dist.get_rank()
     on_gpu = dist.get_backend() == "nccl"
     dev = (device or torch.device("cuda", torch.cuda.current_device())) if on_gpu else torch.device("cpu")

@@ -36,6 +36,7 @@ class ChannelBatch:
     len_dev: "object"
     peak: Optional[np.ndarray] = None       # int64 (B,) host, filled by Engine.peaks()
     peak_abs: Optional[np.ndarray] = None   # float32 (B,)
+    ready: Optional[object] = None          # event recorded after the batch's arrays were enqueued for upload
 
     @property
     def count(self) -> int:
@@ -75,6 +76,17 @@ class _TimedLib:
 
             self._cache[name] = timed
         return self._cache[name]
+
+
+class HostFuture:
+    """Result of Engine.fetch(): a device tensor on its way into pinned host memory.  get() is valid once the
+    stream it was enqueued on has reached the copy (Engine.sync(), or the event of the step it belongs to)."""
+
+    def __init__(self, pinned, shape):
+        self._pinned, self._shape = pinned, shape
+
+    def get(self) -> np.ndarray:
+        return self._pinned.numpy().reshape(self._shape).copy()
 
 
 def _TORCH_DTYPES(t):
@@ -153,6 +165,40 @@ class Engine:
     def empty(self, n: int, dtype):
         return self.torch.empty(int(max(n, 1)), dtype=dtype, device=self.device)
 
+    # Small results (fit records, statistics, roots) leave through a pinned arena with ASYNC copies, so that a step's
+    # device->host traffic is enqueued with its kernels and read after ONE wait -- and so that the next step can be
+    # enqueued behind it (audio_analysis_amd.pipeline.FullReport.submit / finish).  The arena is a ring: at most
+    # _FETCH_BYTES / 3 may be outstanding per step with two steps in flight.
+    _FETCH_BYTES = 96 << 20
+
+    def fetch(self, tensor) -> HostFuture:
+        t = self.torch
+        tensor = tensor.contiguous()
+        nbytes = int(tensor.numel()) * tensor.element_size()
+        if nbytes > self._FETCH_BYTES // 3:
+            host = t.empty(tensor.shape, dtype=tensor.dtype).pin_memory()
+            host.copy_(tensor, non_blocking=True)
+            return HostFuture(host, tuple(tensor.shape))
+        if getattr(self, "_fetch_arena", None) is None:
+            self._fetch_arena = t.empty(self._FETCH_BYTES, dtype=t.uint8).pin_memory()
+            self._fetch_pos = 0
+        pos = (self._fetch_pos + 63) & ~63
+        if pos + nbytes > self._FETCH_BYTES:
+            pos = 0
+        self._fetch_pos = pos + nbytes
+        host = self._fetch_arena[pos : pos + nbytes].view(tensor.dtype).view(tensor.shape)
+        host.copy_(tensor, non_blocking=True)
+        return HostFuture(host, tuple(tensor.shape))
+
+    _side = None
+
+    def side_stream(self):
+        """High-priority stream for the tiny peak-pick launch whose result the HOST needs before it can lay out a
+        step: it overtakes whatever the main stream still has queued from the previous step."""
+        if self._side is None:
+            self._side = self.torch.cuda.Stream(device=self.device, priority=-1)
+        return self._side
+
     def upload(self, channels: Sequence[np.ndarray]) -> ChannelBatch:
         """Host float32 channels -> one flat device buffer (H2D)."""
         lens = np.array([int(c.size) for c in channels], dtype=np.int64)
@@ -169,7 +215,10 @@ class Engine:
     def wrap(self, x_dev, off: np.ndarray, lens: np.ndarray) -> ChannelBatch:
         off = np.ascontiguousarray(off, dtype=np.int64)
         lens = np.ascontiguousarray(lens, dtype=np.int64)
-        return ChannelBatch(x=x_dev, off=off, length=lens, off_dev=self.to_dev(off), len_dev=self.to_dev(lens))
+        b = ChannelBatch(x=x_dev, off=off, length=lens, off_dev=self.to_dev(off), len_dev=self.to_dev(lens))
+        b.ready = self.torch.cuda.Event()
+        b.ready.record(self.torch.cuda.current_stream(self.device))
+        return b
 
     # ------------------------------------------------------------------ tables (host NumPy -> device, cached)
     def window(self, n: int, use_hann: bool, precision: int):

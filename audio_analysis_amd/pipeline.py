@@ -89,17 +89,34 @@ class FullReport:
         self.device_results: Dict[str, dict] = {}
 
     def run(self, batch: ChannelBatch) -> np.ndarray:
+        """One step: submit + finish."""
+        return self.finish(self.submit(batch))
+
+    # submit() only ENQUEUES: every kernel of the step, then asynchronous copies of the small result records into
+    # pinned memory, then an event.  finish() waits for that event and builds the metrics record on the host.
+    # Calling submit(next batch) BEFORE finish(previous) keeps the GPU busy while the host post-processes: the one
+    # host round trip a step needs (the peak pick that fixes every block's geometry) runs on a high-priority side
+    # stream, so it is not queued behind the previous step's kernels.
+    def submit(self, batch: ChannelBatch) -> dict:
         eng, s, sr = self.eng, self.s, self.s.sample_rate_hz
+        t = eng.torch
         n = batch.count
         m = np.full((n, METRICS_WIDTH), np.nan, dtype=np.float64)
         m[:, M_STATUS] = 0.0
         m[:, M_NSAMPLES] = batch.length
-        eng.peaks(batch)                                   # the one host round trip every block's geometry needs
+        if batch.peak is None:
+            side = eng.side_stream()
+            if batch.ready is not None:
+                side.wait_event(batch.ready)               # the upload of this batch, nothing else
+            with t.cuda.stream(side):
+                eng.peaks(batch)                           # the one host round trip every block's geometry needs
         res: Dict[str, dict] = {}
+        fut: Dict[str, object] = {}
 
         if s.run_decay:
             d = _decay.decay_device(eng, batch, sr, s.decay)
             res["decay"] = d
+            fut["decay_fits"], fut["decay_cross"] = eng.fetch(d["fits"]), eng.fetch(d["cross"])
         if s.run_rt60_bands:
             bands, band_values, have = _bands.rt60_bands_device(eng, batch, sr, s.rt60_bands, defer=True)
             res["rt60bands"] = dict(bands=bands, values=band_values, have=have)
@@ -109,6 +126,7 @@ class FullReport:
             spectrum = _fr.spectrum_device(eng, batch, sr, s.frequency_response, "spectrum", want_phase=share,
                                            unwrap=bool(s.filter.unwrap_phase), degrees=s.filter.phase_mode == "degrees")
             res["spectrum"] = spectrum
+            fut["spectrum_stats"] = eng.fetch(spectrum["stats"])
         filt = None
         if s.run_filter:
             if spectrum is not None and spectrum["phase"] is not None:
@@ -117,6 +135,7 @@ class FullReport:
                 filt = _fr.spectrum_device(eng, batch, sr, s.filter, "filter response", want_phase=True,
                                            unwrap=bool(s.filter.unwrap_phase), degrees=s.filter.phase_mode == "degrees")
                 res["filter"] = filt
+                fut["filter_stats"] = eng.fetch(filt["stats"])
         if s.run_spectrogram:
             sp = _spec.spectrogram_device(eng, batch, sr, s.spectrogram)
             res["spectrogram"] = sp
@@ -129,11 +148,18 @@ class FullReport:
         if s.run_modal_cloud:
             mc = _modal.modal_cloud_device(eng, batch, sr, s.modal_cloud)
             res["modal"] = mc
+            fut["modal_fits"] = eng.fetch(mc["fits"])
         if s.run_zplane:
             res["zplane"] = dict(finish=_zp.zplane_device(eng, batch, sr, s.zplane, defer=True))
+        done = t.cuda.Event()
+        done.record(t.cuda.current_stream(eng.device))
+        return dict(n=n, m=m, res=res, fut=fut, done=done, spectrum=spectrum, filt=filt)
 
-        # ---- small device -> host copies (fit records, statistics), then the fixed-width record -----------------
-        # (everything above only ENQUEUED work; the first .cpu() below is where the host waits for the GPU)
+    def finish(self, h: dict) -> np.ndarray:
+        s = self.s
+        n, m, res, fut, spectrum, filt = h["n"], h["m"], h["res"], h["fut"], h["spectrum"], h["filt"]
+        h["done"].synchronize()                            # the only wait of the step
+        # ---- the fixed-width record from the small result records (already in pinned host memory) ---------------
         if s.run_rt60_bands:
             bands = res["rt60bands"]["bands"]
             values = res["rt60bands"]["values"]
@@ -158,8 +184,8 @@ class FullReport:
                         m[i, M_AR_UNSTABLE] = int(np.sum(rad >= 1.0))
         if s.run_decay:
             d = res["decay"]
-            fits = d["fits"].cpu().numpy()
-            cross = d["cross"].cpu().numpy()
+            fits = fut["decay_fits"].get()
+            cross = fut["decay_cross"].get()
             m[:, M_START] = d["starts"]
             ok = ~np.isnan(cross[:, 0]) & ~np.isnan(cross[:, 1]) & (cross[:, 1] >= cross[:, 0])
             m[ok, M_EARLY10] = cross[ok, 1] - cross[ok, 0]
@@ -167,17 +193,17 @@ class FullReport:
             for j, (name, _) in enumerate(d["specs"]):
                 m[:, slot[name] : slot[name] + 8] = fits[:, j, :]
         if spectrum is not None:
-            st = spectrum["stats"].cpu().numpy()
+            st = fut["spectrum_stats"].get()
             m[:, M_FR_PEAK] = st[:, 2]
             with np.errstate(invalid="ignore", divide="ignore"):
                 m[:, M_FR_CENTROID] = np.where(st[:, 4] > 0.0, st[:, 3] / st[:, 4], st[:, 5])
             m[st[:, 0] < 1.0, M_STATUS] = 1.0
         if filt is not None:
-            st = filt["stats"].cpu().numpy() if filt is not spectrum else st
+            st = fut["filter_stats"].get() if filt is not spectrum else st
             m[:, M_FILT_PEAK] = st[:, 2]
             m[:, M_FILT_1K] = st[:, 7]
         if s.run_modal_cloud:
-            rec = res["modal"]["fits"].cpu().numpy().reshape(n, res["modal"]["nbins"], 8)
+            rec = fut["modal_fits"].get().reshape(n, res["modal"]["nbins"], 8)
             valid = rec[:, :, 0] == 1.0
             m[:, M_MODAL_POINTS] = valid.sum(axis=1)
             rt = np.where(valid, rec[:, :, 6], np.nan)

@@ -6,6 +6,7 @@ bench.py -- IRs/sec of the metrics-only full report (BASELINE.json metric) on MI
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+Steps are software-pipelined (submit k+1 before finishing k); all K steps complete inside the timed region.
 One "step" = one pass of the full report (decay + rt60bands[three] + fr + filter + spectrogram + waterfall +
 modalcloud + zplane AR(64); PNG rendering, group delay and diffusion excluded -- SURVEY.md section 8d) over
 one batch of B synthetic 48 kHz, S-second mono IRs per GPU that is already resident in HBM, ending with the
@@ -109,19 +110,26 @@ def main():
                      np.full(a.batch, n, dtype=np.int64))
     del host
 
-    def step():
-        batch.peak = None                      # the peak pick is part of the step
-        m = report.run(batch)
-        return D.gather_metrics(m, eng.device)
+    # Software pipeline over steps: step k+1 is ENQUEUED (FullReport.submit) before step k's results are read back
+    # and gathered (FullReport.finish), so the GPU works on k+1 while the host post-processes k.  Every one of the
+    # K timed steps is submitted, finished and gathered inside the timed region.
+    def run_steps(count):
+        out, pending = None, None
+        for _ in range(count):
+            batch.peak = None                  # the peak pick is part of every step
+            h = report.submit(batch)
+            if pending is not None:
+                out = D.gather_metrics(report.finish(pending), eng.device, eng.side_stream())
+            pending = h
+        if pending is not None:
+            out = D.gather_metrics(report.finish(pending), eng.device, eng.side_stream())
+        return out
 
-    for _ in range(a.warmup):
-        step()
+    run_steps(a.warmup)
     D.barrier(); torch.cuda.synchronize()
     eng.events = []
     t0 = time.perf_counter()
-    gathered = None
-    for _ in range(a.steps):
-        gathered = step()
+    gathered = run_steps(a.steps)
     D.barrier(); torch.cuda.synchronize()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, eng.device)
     ev = eng.collect_events()
