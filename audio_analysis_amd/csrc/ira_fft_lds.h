@@ -50,12 +50,7 @@ __device__ __forceinline__ void lds_fft_dif(cplx<T>* buf, int log2m, const cplx<
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = p[base + r * q];
       dft_dif<T, 16>(v);
-      if (j != 0) {
-        cplx<T> pw[16];
-        powers16<T>(tw[j * step], pw);                 // W_S^(j k), k < 16  (j*step < half/8)
-#pragma unroll
-        for (int i = 1; i < 16; ++i) v[i] = cmul(v[i], pw[brev_bits(i, 4)]);
-      }
+      if (j != 0) twiddle16<T, true>(v, tw[j * step]);     // W_S^(j k), k < 16  (j*step < half/8)
 #pragma unroll
       for (int i = 0; i < 16; ++i) p[base + i * q] = v[i];
     }
@@ -175,12 +170,9 @@ __device__ __forceinline__ void lds_fft_dit(cplx<T>* buf, int log2m, const cplx<
 #pragma unroll
       for (int k = 0; k < 16; ++k) u[k] = p[base + brev_bits(k, 4) * q];
       if (j != 0) {
-        cplx<T> pw[16];
         cplx<T> w = tw[j * step];
         if (conj_tw) w.im = -w.im;
-        powers16<T>(w, pw);
-#pragma unroll
-        for (int k = 1; k < 16; ++k) u[k] = cmul(u[k], pw[k]);
+        twiddle16<T, false>(u, w);
       }
       if (conj_tw) {
         // inverse 16-point DFT = conj(DFT(conj(.)))

@@ -75,4 +75,34 @@ __device__ __forceinline__ void powers16(cplx<T> w, cplx<T> (&p)[16]) {
   for (int k = 9; k < 16; ++k) p[k] = ira::cmul(p[8], p[k - 8]);
 }
 
+// v[idx(k)] *= w^k for k = 1..15, idx = bit reversal (BREV: v[i] holds index brev4(i), the order dft_dif leaves) or
+// identity.  Same products as powers16, but only w^1..w^7 and w^8 are ever live together: 36 registers of
+// twiddles instead of 64 beside the 64 of v in float64, which is what keeps the radix-16 LDS passes at 4 waves/SIMD.
+template <typename T, bool BREV>
+__device__ __forceinline__ void twiddle16(cplx<T> (&v)[16], cplx<T> w) {
+  cplx<T> p[8];
+  p[1] = w;
+  p[2] = ira::cmul(w, w);
+  p[3] = ira::cmul(p[2], w);
+  p[4] = ira::cmul(p[2], p[2]);
+  p[5] = ira::cmul(p[4], w);
+  p[6] = ira::cmul(p[4], p[2]);
+  p[7] = ira::cmul(p[4], p[3]);
+#pragma unroll
+  for (int k = 1; k < 8; ++k) {
+    const int i = BREV ? brev_bits(k, 4) : k;
+    v[i] = ira::cmul(v[i], p[k]);
+  }
+  const cplx<T> w8 = ira::cmul(p[4], p[4]);
+  {
+    const int i = BREV ? brev_bits(8, 4) : 8;
+    v[i] = ira::cmul(v[i], w8);
+  }
+#pragma unroll
+  for (int k = 1; k < 8; ++k) {
+    const int i = BREV ? brev_bits(8 + k, 4) : 8 + k;
+    v[i] = ira::cmul(v[i], ira::cmul(w8, p[k]));
+  }
+}
+
 }  // namespace ira

@@ -35,6 +35,8 @@ struct Geom {
   const cd* t1;  // exp(-2 pi i k / N1), k < N1   (full circle; first half doubles as the N1 sub-FFT table)
   const cd* t2;  // exp(-2 pi i k / N2), k < N2
   const cd* tf;  // exp(-2 pi i k / M),  k < N2
+  int ablate;    // diagnostics (IRA_FFT_ABLATE): 1 K1 plain input, 2 K1 no FFT, 4 K1 no store, 8 K2 no FFTs,
+                 // 16 K2 no filter multiply, 32 K3 no FFT, 64 K3 plain epilogue, 128 K2 no store, 256 K3 no load
 };
 
 // W_M^p for p < M as a product of a coarse (N1-entry) and a fine (N2-entry) table value.
@@ -67,6 +69,10 @@ __device__ __forceinline__ float ramp_f32(float f, double x0, double x1) {
   if (x1 <= x0) return f >= (float)x1 ? 1.0f : 0.0f;
   float t = (f - (float)x0) / (float)(x1 - x0);
   t = fminf(fmaxf(t, 0.0f), 1.0f);
+  // outside the transition band (almost every bin) the float32 formula below gives exactly 0 and 1:
+  // cos(0) = 1 -> 0.5 - 0.5 = 0;  float32(cos(float32(pi))) = -1 -> 0.5 + 0.5 = 1.  Skip the float64 cosine there.
+  if (t <= 0.0f) return 0.0f;
+  if (t >= 1.0f) return 1.0f;
   const float arg = (float)kPi * t;
   const float cs = (float)cos((double)arg);  // correctly rounded float32 cosine
   return 0.5f - 0.5f * cs;
@@ -182,7 +188,7 @@ __device__ __forceinline__ void remap_xcd(unsigned& bx, unsigned& by) {
 // K1: columns forward.  grid (N2 / C, nb); LDS C * (N1 + 1) complex.
 // ---------------------------------------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(FL_THREADS) void cols_fwd_kernel(Geom g, Jobs J, cd* __restrict__ work, int C) {
+__global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void cols_fwd_kernel(Geom g, Jobs J, cd* __restrict__ work, int C) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   cd* lds = reinterpret_cast<cd*>(smem_raw);
   unsigned bx, by;
@@ -197,16 +203,17 @@ __global__ __launch_bounds__(FL_THREADS) void cols_fwd_kernel(Geom g, Jobs J, cd
   for (unsigned i = tid; i < N1 * (unsigned)C; i += FL_THREADS) {
     const unsigned c = i % C, n1 = i / C;
     const long long n = (long long)n1 * N2 + n2_0 + c;
-    lds[c * stride + n1] = gen_input<MODE>(J, e, n, L, M);
+    lds[c * stride + n1] = (g.ablate & 1) ? cd{(double)n, 1.0} : gen_input<MODE>(J, e, n, L, M);
   }
   __syncthreads();
-  ira::lds_fft_dif<double>(lds, g.log2n1, g.t1, 1u, tid, FL_THREADS, C, stride);
+  if (!(g.ablate & 2)) ira::lds_fft_dif<double>(lds, g.log2n1, g.t1, 1u, tid, FL_THREADS, C, stride);
   cd* w = work + (long long)e * M;
   for (unsigned i = tid; i < N1 * (unsigned)C; i += FL_THREADS) {
     const unsigned c = i % C, r = i / C;
     const unsigned k1 = ira::lds_brev(r, g.log2n1);
     const unsigned n2 = n2_0 + c;
     const cd v = ira::cmul(lds[c * stride + r], twiddle_m(g, n2 * k1));
+    if ((g.ablate & 4) && v.re != 12345.678) continue;
     w[(long long)r * N2 + n2] = v;
   }
 }
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(FL_THREADS) void cols_fwd_kernel(Geom g, Jobs J, cd
 // K2: rows.  grid (N1 / R, nb); LDS R * N2 complex.
 // ---------------------------------------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(FL_THREADS) void rows_kernel(Geom g, Jobs J, cd* __restrict__ work, int R) {
+__global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void rows_kernel(Geom g, Jobs J, cd* __restrict__ work, int R) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   cd* lds = reinterpret_cast<cd*>(smem_raw);
   unsigned bx, by;
@@ -228,18 +235,21 @@ __global__ __launch_bounds__(FL_THREADS) void rows_kernel(Geom g, Jobs J, cd* __
   cd* w = work + (long long)e * M + (long long)r0 * N2;
   for (unsigned i = tid; i < N2 * (unsigned)R; i += FL_THREADS) lds[i] = w[i];
   __syncthreads();
-  ira::lds_fft_dif<double>(lds, g.log2n2, g.t2, 1u, tid, FL_THREADS, R, N2);
+  if (!(g.ablate & 8)) ira::lds_fft_dif<double>(lds, g.log2n2, g.t2, 1u, tid, FL_THREADS, R, N2);
   if (MODE == ROW_CONV) {
     const cd* b = J.bfilt + (long long)J.bidx[e] * M + (long long)r0 * N2;
-    for (unsigned i = tid; i < N2 * (unsigned)R; i += FL_THREADS) lds[i] = ira::cmul(lds[i], b[i]);
+    if (!(g.ablate & 16))
+      for (unsigned i = tid; i < N2 * (unsigned)R; i += FL_THREADS) lds[i] = ira::cmul(lds[i], b[i]);
     __syncthreads();
-    ira::lds_fft_dit<double>(lds, g.log2n2, g.t2, 1u, true, tid, FL_THREADS, R, N2);
+    if (!(g.ablate & 8)) ira::lds_fft_dit<double>(lds, g.log2n2, g.t2, 1u, true, tid, FL_THREADS, R, N2);
     for (unsigned i = tid; i < N2 * (unsigned)R; i += FL_THREADS) {
       const unsigned rr = i >> g.log2n2, n2 = i & (N2 - 1);
       const unsigned k1 = ira::lds_brev(r0 + rr, g.log2n1);
       cd t = twiddle_m(g, n2 * k1);
       t.im = -t.im;
-      w[i] = ira::cmul(lds[i], t);
+      const cd v = ira::cmul(lds[i], t);
+      if ((g.ablate & 128) && v.re != 12345.678) continue;
+      w[i] = v;
     }
   } else {
     for (unsigned i = tid; i < N2 * (unsigned)R; i += FL_THREADS) w[i] = lds[i];
@@ -250,7 +260,7 @@ __global__ __launch_bounds__(FL_THREADS) void rows_kernel(Geom g, Jobs J, cd* __
 // K3: columns inverse + epilogue.  grid (N2 / C, nb).
 // ---------------------------------------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(FL_THREADS) void cols_inv_kernel(Geom g, Jobs J, const cd* __restrict__ work, int C) {
+__global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void cols_inv_kernel(Geom g, Jobs J, const cd* __restrict__ work, int C) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   cd* lds = reinterpret_cast<cd*>(smem_raw);
   unsigned bx, by;
@@ -268,17 +278,17 @@ __global__ __launch_bounds__(FL_THREADS) void cols_inv_kernel(Geom g, Jobs J, co
   const cd* w = work + (long long)e * M;
   for (unsigned i = tid; i < N1 * (unsigned)C; i += FL_THREADS) {
     const unsigned c = i % C, r = i / C;
-    lds[c * stride + r] = w[(long long)r * N2 + n2_0 + c];
+    lds[c * stride + r] = (g.ablate & 256) ? cd{(double)i, 1.0} : w[(long long)r * N2 + n2_0 + c];
   }
   __syncthreads();
-  ira::lds_fft_dit<double>(lds, g.log2n1, g.t1, 1u, true, tid, FL_THREADS, C, stride);
+  if (!(g.ablate & 32)) ira::lds_fft_dit<double>(lds, g.log2n1, g.t1, 1u, true, tid, FL_THREADS, C, stride);
   const double inv_m = 1.0 / (double)M;
   for (unsigned i = tid; i < N1 * (unsigned)C; i += FL_THREADS) {
     const unsigned c = i % C, n1 = i / C;
     const long long n = (long long)n1 * N2 + n2_0 + c;
     if (n >= n_need) continue;
     cd v = lds[c * stride + n1];
-    v = ira::cmul(v, chirp(n, L));
+    if (!(g.ablate & 64)) v = ira::cmul(v, chirp(n, L));
     if (MODE == OUT_SPECTRUM) {
       v.re *= inv_m; v.im *= inv_m;
       if (paired) {
@@ -339,6 +349,7 @@ int32_t make_plan(int log2m, const void* t1, const void* t2, const void* tf, Pla
   p->g.t1 = static_cast<const cd*>(t1);
   p->g.t2 = static_cast<const cd*>(t2);
   p->g.tf = static_cast<const cd*>(tf);
+  p->g.ablate = std::getenv("IRA_FFT_ABLATE") ? std::atoi(std::getenv("IRA_FFT_ABLATE")) : 0;
   const int N1 = 1 << p->g.log2n1, N2 = 1 << p->g.log2n2;
   // ~32 KB of LDS per workgroup (C = R = 2 at N1 = N2 = 1024): measured fastest on MI355X -- 4 workgroups per CU
   // hide each other's barriers (rfft_any, 64 x 2^20: C/R = 4/4 2.75 ms, 2/2 2.39 ms, 1/1 2.92 ms)

@@ -20,3 +20,13 @@ for _ in range(3):
 torch.cuda.synchronize(); pr.disable()
 print(f"wall per step {1e3*(time.perf_counter()-t0)/3:.2f} ms")
 pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+
+# ---- host cost of the two halves of a step with the GPU out of the way -------------------------------------
+ts, tf = [], []
+for _ in range(5):
+    torch.cuda.synchronize(); batch.peak = None
+    t0 = time.perf_counter(); h = rep.submit(batch); t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter(); rep.finish(h); t3 = time.perf_counter()
+    ts.append(1e3 * (t1 - t0)); tf.append(1e3 * (t3 - t2))
+print(f"host: submit {np.median(ts):.2f} ms (enqueue only, includes the peak round trip), finish {np.median(tf):.2f} ms (results already on the host)")
