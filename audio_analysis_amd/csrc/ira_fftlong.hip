@@ -53,6 +53,14 @@ __device__ __forceinline__ cd chirp(long long n, long long L) {
   return {c, -s};
 }
 
+// exp(-i*pi*q/L) for an integer phase numerator q >= 0 (reduced exactly mod 2L first)
+__device__ __forceinline__ cd unit_q(long long q, long long L) {
+  q %= 2 * L;
+  double s, c;
+  sincospi((double)q / (double)L, &s, &c);
+  return {c, -s};
+}
+
 // numpy.hanning(L)[i] = 0.5 + 0.5*cos(pi*(2i + 1 - L)/(L - 1)); hanning(1) = 1
 __device__ __forceinline__ double hann_at(long long i, long long L) {
   if (L <= 1) return 1.0;
@@ -129,18 +137,18 @@ enum InMode { IN_SIGNAL = 0, IN_FILTER = 1, IN_SPECTRUM = 2 };
 enum RowMode { ROW_FWD = 0, ROW_CONV = 1 };
 enum OutMode { OUT_SPECTRUM = 0, OUT_BANDS = 1 };
 
+// w = chirp(n, L) and h = hann_at(n, L) come from the caller (recurrences along a thread's elements, see
+// cols_fwd_kernel); IN_FILTER evaluates its mirrored chirp directly (filters are plan data, built once and cached).
 template <int MODE>
-__device__ __forceinline__ cd gen_input(const Jobs& J, int e, long long n, long long L, long long M) {
+__device__ __forceinline__ cd gen_input(const Jobs& J, int e, long long n, long long L, long long M, cd w, double h) {
   if (MODE == IN_SIGNAL) {
     if (n >= L) return {0.0, 0.0};
     double v = (double)J.x[J.xoff[e] + n];
     const long long o2 = J.x2off ? J.x2off[e] : -1;
     double v2 = o2 >= 0 ? (double)J.x[o2 + n] : 0.0;
     if (J.use_hann) {
-      const double h = hann_at(n, L);
       v *= h; v2 *= h;
     }
-    const cd w = chirp(n, L);
     if (o2 < 0) return {v * w.re, v * w.im};
     return {v * w.re - v2 * w.im, v * w.im + v2 * w.re};
   } else if (MODE == IN_FILTER) {
@@ -149,8 +157,8 @@ __device__ __forceinline__ cd gen_input(const Jobs& J, int e, long long n, long 
       m = M - n;
       if (m >= L) return {0.0, 0.0};
     }
-    const cd w = chirp(m, L);
-    return {w.re, -w.im};  // conj(w)
+    const cd wm = chirp(m, L);
+    return {wm.re, -wm.im};  // conj(w)
   } else {
     if (n >= L) return {0.0, 0.0};
     // Hermitian extension of X * (m1 + i m2); the inverse DFT is conj(DFT(conj(.)))/L, so feed conj(W) * chirp
@@ -170,7 +178,7 @@ __device__ __forceinline__ cd gen_input(const Jobs& J, int e, long long n, long 
       wk = {xk.re * m1 - x2.im * m2, xk.im * m1 + x2.re * m2};
     }
     const cd cw = {wk.re, -wk.im};
-    return ira::cmul(cw, chirp(n, L));
+    return ira::cmul(cw, w);
   }
 }
 
@@ -200,10 +208,36 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   const unsigned n2_0 = bx * C;
   const unsigned stride = N1 + 1;
   const int tid = threadIdx.x;
-  for (unsigned i = tid; i < N1 * (unsigned)C; i += FL_THREADS) {
-    const unsigned c = i % C, n1 = i / C;
-    const long long n = (long long)n1 * N2 + n2_0 + c;
-    lds[c * stride + n1] = (g.ablate & 1) ? cd{(double)n, 1.0} : gen_input<MODE>(J, e, n, L, M);
+  // A thread's elements are n_k = n_0 + k*dn (same column, rows FL_THREADS/C apart).  The chirp exp(-i pi n^2/L) along
+  // them obeys  w_{k+1} = w_k d_k,  d_{k+1} = d_k e2  with  d_k = exp(-i pi (2 n_k dn + dn^2)/L),  e2 = exp(-i pi 2 dn^2/L):
+  // three exactly reduced sincospi per thread instead of one per element; the Hann window is a plain rotation.
+  // (<= N1*C/FL_THREADS = 8 steps, so the recurrences add a few 1e-16.)
+  {
+    const unsigned c = tid % C, n1_0 = tid / C;
+    const long long dn = (long long)(FL_THREADS / C) * N2;
+    const long long n0 = (long long)n1_0 * N2 + n2_0 + c;
+    cd w = {1.0, 0.0}, d = {1.0, 0.0}, e2 = {1.0, 0.0};
+    double hc = 1.0, hs = 0.0, rc = 1.0, rs = 0.0;
+    if (MODE != IN_FILTER) {
+      w = unit_q(n0 * n0, L);
+      d = unit_q(2 * n0 * dn + dn * dn, L);
+      e2 = unit_q(2 * dn * dn, L);
+      if (MODE == IN_SIGNAL && J.use_hann && L > 1) {
+        sincospi((double)(2 * n0 + 1 - L) / (double)(L - 1), &hs, &hc);
+        sincospi((double)(2 * dn) / (double)(L - 1), &rs, &rc);
+      }
+    }
+    long long n = n0;
+    for (unsigned i = tid; i < N1 * (unsigned)C; i += FL_THREADS, n += dn) {
+      const unsigned n1 = i / C;
+      const double h = (L > 1) ? 0.5 + 0.5 * hc : 1.0;
+      lds[c * stride + n1] = (g.ablate & 1) ? cd{(double)n, 1.0} : gen_input<MODE>(J, e, n, L, M, w, h);
+      w = ira::cmul(w, d);
+      d = ira::cmul(d, e2);
+      const double nc = hc * rc - hs * rs;
+      hs = hs * rc + hc * rs;
+      hc = nc;
+    }
   }
   __syncthreads();
   if (!(g.ablate & 2)) ira::lds_fft_dif<double>(lds, g.log2n1, g.t1, 1u, tid, FL_THREADS, C, stride);
@@ -358,7 +392,7 @@ int32_t make_plan(int log2m, const void* t1, const void* t2, const void* tf, Pla
   if (C > N2) C = N2;
   int R = 1;
   while (R * 2 * N2 * (int)sizeof(cd) <= 32 * 1024 && R * 2 <= N1 && R < 16) R <<= 1;
-  if (const char* ev = std::getenv("IRA_FFT_C")) { const int v = std::atoi(ev); if (v >= 1 && v <= N2) C = v; }   // tuning
+  if (const char* ev = std::getenv("IRA_FFT_C")) { const int v = std::atoi(ev); if (v >= 1 && v <= N2 && v <= 64 && (v & (v - 1)) == 0) C = v; }   // tuning (power of two: K1 relies on FL_THREADS % C == 0)
   if (const char* ev = std::getenv("IRA_FFT_R")) { const int v = std::atoi(ev); if (v >= 1 && v <= N1) R = v; }
   p->C = C;
   p->R = R;
