@@ -31,7 +31,6 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix peak (not listed in the microarch guide)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -162,42 +161,42 @@ def main():
         return None if t is None else t["hbm_bytes_per_channel"] * a.batch
 
     def roof(name):
-        avg_ms = tot[name] / len(ev[name])
-        if name.startswith("ira_ar_gram"):
-            p = settings.zplane.ar_order
-            flops = float(np.sum((L - p) * p * (p + 1)))          # symmetric half of 2(L-p)p(p+1)
-            ach = flops / (avg_ms * 1e-3) / 1e12
-            return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic_of(name),
-                    "avg_launch_ms": avg_ms, "algorithmic": "(L-p)*p*(p+1) fp64 flop per channel (lower triangle)",
-                    "measured_mfma_f64_ceiling_tflops": 49.2,
-                    "ceiling_source": "profiles/r01_mfma_f64_peak.txt (tools/mfma_f64_peak.hip on the same GPU)"}
+        """Roofline of one ABI call over the timed region.  Bytes (or flops) and time are both PER STEP: a call that is
+        launched twice in a step (ira_rfft_any, ira_edc_db) is charged the sum of its launches."""
+        step_ms = tot[name] / a.steps
+        launches = len(ev[name]) / a.steps
+        nb3 = 3 if settings.rt60_bands.band_mode == "three" else None
         if name.startswith("ira_stft_mag_db[f32"):
             b = stft_bytes(settings.spectrogram.n_fft, settings.spectrogram.hop_length)
             what = "4L in + 4*F*T out bytes per channel"
         elif name.startswith("ira_stft_mag_db[f64,n%d]" % settings.modal_cloud.n_fft):
             b = stft_bytes(settings.modal_cloud.n_fft, settings.modal_cloud.hop_length)
             what = "4L in + 4*F*T out bytes per channel"
-        elif name.startswith("ira_rfft_any") or name.startswith("ira_band_irfft"):
-            # compulsory traffic of one launch: samples in + half spectrum out (forward) / half spectrum in + two
-            # float32 band signals out (inverse); the three Bluestein passes move ~20x that through L2/HBM today
-            if name.startswith("ira_rfft_any"):
-                b = float(np.sum(4.0 * L + 16.0 * (L // 2 + 1)))
-                what = "4L in + 16(L/2+1) out bytes per channel (3-pass float64 Bluestein moves ~112 MB per channel)"
-            else:
-                b = float(a.batch * 2 * (16.0 * (n // 2 + 1) + 8.0 * n))
-                what = "16(n/2+1) in + 2*4n out bytes per band pair, 2 pairs per channel"
-        elif name.startswith("ira_edc_db"):
-
-            b = float(np.sum(8.0 * L)) * (len(ev[name]) and 1)
-            what = "4L in + 4L out bytes per segment (decay launch; band launches carry 3 segments per channel)"
+        elif name.startswith("ira_rfft_any"):
+            # compulsory traffic: samples in + half spectra out, for the RT60 full-file transform and the windowed
+            # fr/filter transform.  The three float64 Bluestein passes over M = 2^20 move ~15x that through
+            # L2/MALL/HBM (see "traffic"); that working-set traffic is what bounds these kernels.
+            b = float(np.sum(4.0 * L + 16.0 * (L // 2 + 1))) + float(a.batch) * (4.0 * n + 16.0 * (n // 2 + 1))
+            what = "per channel: 4n + 16(n/2+1) (RT60 forward) + 4L + 16(L/2+1) (fr/filter) bytes"
+        elif name.startswith("ira_band_irfft") and nb3:
+            b = float(a.batch) * (16.0 * (n // 2 + 1) + nb3 * 4.0 * n)
+            what = f"per channel: 16(n/2+1) spectrum in + {nb3} band signals x 4n out bytes"
+        elif name.startswith("ira_edc_db") and nb3:
+            b = float(np.sum(8.0 * L)) * (1 + nb3)
+            what = f"4L in + 4L out bytes per segment; 1 decay + {nb3} band segments per channel"
+        elif name.startswith("ira_ar_gram"):
+            b = float(np.sum(4.0 * L))
+            what = "4L bytes per channel (samples read once; p+1 lag sums)"
         else:
             return {"kernel": name, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": None, "traffic": None, "avg_launch_ms": avg_ms, "algorithmic": "not modelled"}
-        ach = b / (avg_ms * 1e-3) / 1e9
+                    "frac": None, "traffic": None, "avg_launch_ms": step_ms / launches, "algorithmic": "not modelled"}
+        ach = b / (step_ms * 1e-3) / 1e9
+        tr = traffic_of(name)
         return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": traffic_of(name), "algorithmic_bytes": b,
-                "avg_launch_ms": avg_ms, "algorithmic": what}
+                "frac": ach / HBM_PEAK_GBS, "traffic": tr, "algorithmic_bytes": b, "launches_per_step": launches,
+                "avg_launch_ms": step_ms / launches, "ms_per_step": step_ms, "algorithmic": what,
+                # measured L2<->fabric traffic of the call divided by its time (what the memory system actually moved)
+                "traffic_GBps": None if tr is None else tr / (step_ms * 1e-3) / 1e9}
 
     stft_name = next((k for k in tot if k.startswith("ira_stft_mag_db[f32")), None)
     out = {
