@@ -2,6 +2,7 @@
 // Compiled with -ffp-contract=off: the f64 interpolation/regression arithmetic must round like
 // NumPy's (no fused multiply-add), see reference analyse/decay.py:173-260.
 #include "ira_common.h"
+#include "ira_log.h"
 
 namespace {
 
@@ -65,29 +66,33 @@ constexpr int EDC_PER_THREAD = 4;
 constexpr int EDC_TILE = EDC_THREADS * EDC_PER_THREAD;
 
 struct EdcShared {
-  float stage[EDC_TILE];
   double wave_tot[EDC_THREADS / IRA_WAVE];
   double total;
 };
 
-// Suffix sums of one tile.  local index i in [0, tile_len); thread t owns i = 4t..4t+3.
+typedef float edc_f4 __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access, 4-byte alignment
+
+// Suffix sums of one tile.  local index i in [0, tile_len); thread t owns i = 4t..4t+3 and reads them with one
+// 16-byte load (consecutive threads = consecutive 16-byte pieces: fully coalesced, no LDS staging).
 // On return s[0..3] hold the inclusive suffix sums (within the tile) at the thread's four positions and the
 // function result is the suffix sum at local index 0 (thread 0's s[0], broadcast), i.e. the tile total in
-// exactly the association order the emit pass uses.
+// exactly the association order the emit pass uses.  Two barriers per tile.
 __device__ __forceinline__ double tile_suffix_scan(const float* __restrict__ src, int tile_len, EdcShared& sh,
                                                    double s[EDC_PER_THREAD]) {
   const int t = threadIdx.x;
-  // coalesced staging (works for any alignment of src)
+  const int i0 = EDC_PER_THREAD * t;
+  float x[EDC_PER_THREAD];
+  if (i0 + EDC_PER_THREAD <= tile_len) {
+    const edc_f4 v = *reinterpret_cast<const edc_f4*>(src + i0);
+    x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+  } else {
 #pragma unroll
-  for (int r = 0; r < EDC_PER_THREAD; ++r) {
-    const int i = t + r * EDC_THREADS;
-    sh.stage[i] = (i < tile_len) ? src[i] : 0.0f;
+    for (int r = 0; r < EDC_PER_THREAD; ++r) x[r] = (i0 + r < tile_len) ? src[i0 + r] : 0.0f;
   }
-  __syncthreads();
   double e[EDC_PER_THREAD];
 #pragma unroll
   for (int r = 0; r < EDC_PER_THREAD; ++r) {
-    const double v = (double)sh.stage[EDC_PER_THREAD * t + r];
+    const double v = (double)x[r];
     e[r] = v * v;
   }
   s[3] = e[3];
@@ -113,9 +118,9 @@ __device__ __forceinline__ double tile_suffix_scan(const float* __restrict__ src
   for (int r = 0; r < EDC_PER_THREAD; ++r) s[r] += excl;
   if (t == 0) sh.total = s[0];
   __syncthreads();
-  const double total = sh.total;
-  __syncthreads();  // stage / wave_tot / total are reused by the next tile
-  return total;
+  // No trailing barrier: the next tile writes wave_tot only after every thread has passed the barrier above (its
+  // wave_tot reads precede it), and rewrites total only after its own first barrier (this read precedes that).
+  return sh.total;
 }
 
 // The scan is split over many workgroups so that a small batch still fills the chip:
@@ -180,11 +185,14 @@ __global__ __launch_bounds__(EDC_THREADS) void edc_emit_kernel(
     double floor_db, float* __restrict__ out, double* __restrict__ out64, const int64_t* __restrict__ out_off,
     const double* __restrict__ scratch) {
   __shared__ EdcShared sh;
+  __shared__ ira::LogTabEntry ltab[ira::LOGTAB_N];
   const int seg = blockIdx.y, chunk = blockIdx.x;
   const int64_t n = len[seg];
   const int64_t ntiles = (n + EDC_TILE - 1) / EDC_TILE;
   const int64_t t0 = (int64_t)chunk * EDC_CHUNK_TILES;
   if (t0 >= ntiles) return;
+  ira::build_log_table(ltab, threadIdx.x);
+  __syncthreads();
   const float* src = x + off[seg];
   float* dst = out ? out + out_off[seg] : nullptr;
   double* dst64 = out64 ? out64 + out_off[seg] : nullptr;
@@ -192,6 +200,10 @@ __global__ __launch_bounds__(EDC_THREADS) void edc_emit_kernel(
   const double* sc = scratch + (int64_t)seg * IRA_EDC_SCRATCH_DOUBLES;
   const double chunk_carry = sc[3 * q + chunk];
   const double norm = sc[4 * q - 1];
+  // 10 log10(v / norm) = 10 log10(2) (log2 v - log2 norm) with the table log2 (ira_log.h): ~30 instructions per sample
+  // instead of ~110 for an f64 divide + log10, same value to ~1e-14 dB.  v == norm at index 0 gives exactly 0 dB.
+  const bool fast = norm > 1e-300 && norm < 1e300;
+  const double lnorm = fast ? ira::log2_table(norm, ltab) : 0.0;
   double run = 0.0;
   double s[EDC_PER_THREAD];
   for (int64_t j = t0; j < t0 + EDC_CHUNK_TILES && j < ntiles; ++j) {
@@ -200,25 +212,28 @@ __global__ __launch_bounds__(EDC_THREADS) void edc_emit_kernel(
     const int tl = (int)(hi - lo);
     const double tot = tile_suffix_scan(src + lo, tl, sh, s);
     const double c = run + chunk_carry;
+    const int i0 = EDC_PER_THREAD * threadIdx.x;
+    float o4[EDC_PER_THREAD];
 #pragma unroll
     for (int r = 0; r < EDC_PER_THREAD; ++r) {
-      const int i = EDC_PER_THREAD * threadIdx.x + r;
-      if (i < tl) {
-        double v = fmax(s[r] + c, eps);
-        v = v / norm;
-        double db = 10.0 * log10(v);
-        if (dst64) dst64[lo + i] = db;  // unfloored f64 (host-side optional smoothing, decay.py:161-164)
-        db = fmax(db, floor_db);
-        sh.stage[i] = (float)db;
+      const int i = i0 + r;
+      const double v = fmax(s[r] + c, eps);
+      double db;
+      if (fast && v > 1e-300 && v < 1e300) db = 3.0102999566398120 * (ira::log2_table(v, ltab) - lnorm);
+      else db = 10.0 * log10(v / norm);
+      if (dst64 && i < tl) dst64[lo + i] = db;  // unfloored f64 (host-side optional smoothing, decay.py:161-164)
+      o4[r] = (float)fmax(db, floor_db);
+    }
+    if (dst) {
+      if (i0 + EDC_PER_THREAD <= tl) {
+        const edc_f4 v = {o4[0], o4[1], o4[2], o4[3]};
+        *reinterpret_cast<edc_f4*>(dst + lo + i0) = v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < EDC_PER_THREAD; ++r)
+          if (i0 + r < tl) dst[lo + i0 + r] = o4[r];
       }
     }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < EDC_PER_THREAD; ++r) {
-      const int i = threadIdx.x + r * EDC_THREADS;
-      if (dst && i < tl) dst[lo + i] = sh.stage[i];
-    }
-    __syncthreads();
     run = tot + run;
   }
 }
@@ -229,6 +244,7 @@ __global__ __launch_bounds__(EDC_THREADS) void edc_emit_kernel(
 constexpr int FIT_MAX_RANGES = 4;
 constexpr int FIT_MAX_CROSS = 4;
 constexpr int FIT_MAX_TARGETS = 2 * FIT_MAX_RANGES + FIT_MAX_CROSS;
+constexpr int FIT_U = 8;   // independent loads in flight per thread in the regression passes
 
 struct FitParams {
   double hi[FIT_MAX_RANGES];
@@ -281,9 +297,70 @@ __device__ __forceinline__ double crossing_time_from_index(const float* y, float
   return t0 + frac * (t1 - t0);
 }
 
+// Long curves (decay / band EDCs of whole files): the first-crossing search is done by MANY workgroups per curve
+// (grid chunks x curves), each taking the minimum crossing index of its chunk into an index slot per target with
+// atomicMin; the per-curve kernel below then starts from those indices.  One workgroup sweeping a 480 k-sample
+// curve whose -35 dB point is never reached (band-limited EDCs flatten on their wrapped pre-ringing) was the
+// latency-bound worst case of curve_fit_kernel.  The slots live in the first ntargets doubles of the curve's
+// fit_out record (cross_out when there are no ranges); they are memset to 0x7f.. (a huge positive int64 = "none").
+constexpr int XS_THREADS = 256;
+constexpr int XS_PER_THREAD = 32;
+constexpr int XS_CHUNK = XS_THREADS * XS_PER_THREAD;
+
+__global__ __launch_bounds__(XS_THREADS) void crossing_search_kernel(const float* __restrict__ ybase,
+                                                                     const int64_t* __restrict__ off,
+                                                                     const int64_t* __restrict__ len, FitParams P,
+                                                                     unsigned long long* __restrict__ slots,
+                                                                     int slot_stride) {
+  const int c = blockIdx.y;
+  const long long n = len[c];
+  const long long base = (long long)blockIdx.x * XS_CHUNK;
+  if (base >= n) return;
+  const float* y = ybase + off[c];
+  const int tid = threadIdx.x;
+  const int ntargets = 2 * P.nranges + P.ncross;
+  float targets[FIT_MAX_TARGETS];
+#pragma unroll
+  for (int k = 0; k < FIT_MAX_TARGETS; ++k) {
+    double tv = 0.0;
+    if (k < 2 * P.nranges) tv = (k & 1) ? P.lo[k >> 1] : P.hi[k >> 1];
+    else if (k < ntargets) tv = P.cross[k - 2 * P.nranges];
+    targets[k] = (float)tv;
+  }
+  long long first[FIT_MAX_TARGETS];
+#pragma unroll
+  for (int k = 0; k < FIT_MAX_TARGETS; ++k) first[k] = n;
+  float v[XS_PER_THREAD];
+#pragma unroll
+  for (int u = 0; u < XS_PER_THREAD; ++u) {
+    const long long i = base + tid + (long long)XS_THREADS * u;
+    v[u] = i < n ? y[i] : INFINITY;
+  }
+#pragma unroll
+  for (int u = XS_PER_THREAD - 1; u >= 0; --u) {        // descending: the smallest index wins without a compare
+    const long long i = base + tid + (long long)XS_THREADS * u;
+#pragma unroll
+    for (int k = 0; k < FIT_MAX_TARGETS; ++k)
+      if (k < ntargets && v[u] <= targets[k]) first[k] = i;
+  }
+  unsigned long long* sl = slots + (long long)c * slot_stride;
+#pragma unroll
+  for (int k = 0; k < FIT_MAX_TARGETS; ++k) {
+    if (k < ntargets && __any(first[k] < n)) {          // wave-uniform: crossings are rare events
+      long long f = first[k];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const long long other = __shfl_xor(f, o, 64);
+        f = other < f ? other : f;
+      }
+      if ((tid & 63) == 0) atomicMin(&sl[k], (unsigned long long)f);
+    }
+  }
+}
+
 __global__ void curve_fit_kernel(const float* __restrict__ ybase, const int64_t* __restrict__ off,
                                  const int64_t* __restrict__ len, FitParams P, double* __restrict__ fit_out,
-                                 double* __restrict__ cross_out) {
+                                 double* __restrict__ cross_out, int pre_searched) {
   __shared__ FitShared sh;
   const int c = blockIdx.x;
   const long long n = len[c];
@@ -337,7 +414,14 @@ __global__ void curve_fit_kernel(const float* __restrict__ ybase, const int64_t*
     if (tid < 2 * P.nranges) tv = (tid & 1) ? P.lo[tid >> 1] : P.hi[tid >> 1];
     else if (tid < ntargets) tv = P.cross[tid - 2 * P.nranges];
     sh.tgt[tid] = tv;
-    sh.idx[tid] = n;
+    long long start = n;
+    if (pre_searched && tid < ntargets) {
+      // indices found by crossing_search_kernel (slots alias the head of this curve's output record)
+      const unsigned long long* sl = reinterpret_cast<const unsigned long long*>(P.nranges > 0 ? fo : co);
+      const unsigned long long f = sl[tid];
+      start = f < (unsigned long long)n ? (long long)f : n;
+    }
+    sh.idx[tid] = start;
   }
   __syncthreads();
   float targets[FIT_MAX_TARGETS];
@@ -347,7 +431,7 @@ __global__ void curve_fit_kernel(const float* __restrict__ ybase, const int64_t*
   // crossing index, so the rest of the curve need not be read (for an EDC the -35 dB point sits in the first
   // few percent of a 10 s curve).  A target that is never reached still scans to the end, like the reference.
   constexpr int SWEEP_U = 8;
-  for (long long base = 0; base < n; base += (long long)nt * SWEEP_U) {
+  for (long long base = 0; base < n && !pre_searched; base += (long long)nt * SWEEP_U) {
     long long first[FIT_MAX_TARGETS];
 #pragma unroll
     for (int k = 0; k < FIT_MAX_TARGETS; ++k) first[k] = n;
@@ -403,10 +487,23 @@ __global__ void curve_fit_kernel(const float* __restrict__ ybase, const int64_t*
     long long a0 = i_hi - 2; if (a0 < 0) a0 = 0;
     long long a1 = i_lo + 2; if (a1 > n - 1) a1 = n - 1;
     // pass 1: count, sum t, sum y
+    // The three passes read y in batches of FIT_U independent loads per thread: with one load per iteration a single
+    // workgroup streaming a long range is bound by one memory latency per element.
     double cnt = 0.0, st = 0.0, sy = 0.0;
-    for (long long i = a0 + tid; i <= a1; i += nt) {
-      const float tf = ta.at(i);
-      if (tf >= ts32 && tf <= te32) { cnt += 1.0; st += (double)tf; sy += (double)(y[i] - peak); }
+    for (long long b0 = a0; b0 <= a1; b0 += (long long)nt * FIT_U) {
+      float yv[FIT_U];
+#pragma unroll
+      for (int u = 0; u < FIT_U; ++u) {
+        const long long i = b0 + tid + (long long)nt * u;
+        yv[u] = i <= a1 ? y[i] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < FIT_U; ++u) {
+        const long long i = b0 + tid + (long long)nt * u;
+        if (i > a1) continue;
+        const float tf = ta.at(i);
+        if (tf >= ts32 && tf <= te32) { cnt += 1.0; st += (double)tf; sy += (double)(yv[u] - peak); }
+      }
     }
     block_sum3(cnt, st, sy, sh);
     const long long npts = (long long)cnt;
@@ -417,11 +514,22 @@ __global__ void curve_fit_kernel(const float* __restrict__ ybase, const int64_t*
     const double tm = st / cnt, ym = sy / cnt;
     // pass 2: centred second moments
     double stt = 0.0, sty = 0.0, syy = 0.0;
-    for (long long i = a0 + tid; i <= a1; i += nt) {
-      const float tf = ta.at(i);
-      if (tf >= ts32 && tf <= te32) {
-        const double dt = (double)tf - tm, dy = (double)(y[i] - peak) - ym;
-        stt += dt * dt; sty += dt * dy; syy += dy * dy;
+    for (long long b0 = a0; b0 <= a1; b0 += (long long)nt * FIT_U) {
+      float yv[FIT_U];
+#pragma unroll
+      for (int u = 0; u < FIT_U; ++u) {
+        const long long i = b0 + tid + (long long)nt * u;
+        yv[u] = i <= a1 ? y[i] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < FIT_U; ++u) {
+        const long long i = b0 + tid + (long long)nt * u;
+        if (i > a1) continue;
+        const float tf = ta.at(i);
+        if (tf >= ts32 && tf <= te32) {
+          const double dt = (double)tf - tm, dy = (double)(yv[u] - peak) - ym;
+          stt += dt * dt; sty += dt * dy; syy += dy * dy;
+        }
       }
     }
     block_sum3(stt, sty, syy, sh);
@@ -429,11 +537,22 @@ __global__ void curve_fit_kernel(const float* __restrict__ ybase, const int64_t*
     const double icpt = ym - slope * tm;
     // pass 3: residual sum of squares against the fitted line (decay.py:244-247)
     double sres = 0.0, d1 = 0.0, d2 = 0.0;
-    for (long long i = a0 + tid; i <= a1; i += nt) {
-      const float tf = ta.at(i);
-      if (tf >= ts32 && tf <= te32) {
-        const double e = (double)(y[i] - peak) - (slope * (double)tf + icpt);
-        sres += e * e;
+    for (long long b0 = a0; b0 <= a1; b0 += (long long)nt * FIT_U) {
+      float yv[FIT_U];
+#pragma unroll
+      for (int u = 0; u < FIT_U; ++u) {
+        const long long i = b0 + tid + (long long)nt * u;
+        yv[u] = i <= a1 ? y[i] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < FIT_U; ++u) {
+        const long long i = b0 + tid + (long long)nt * u;
+        if (i > a1) continue;
+        const float tf = ta.at(i);
+        if (tf >= ts32 && tf <= te32) {
+          const double e = (double)(yv[u] - peak) - (slope * (double)tf + icpt);
+          sres += e * e;
+        }
       }
     }
     block_sum3(sres, d1, d2, sh);
@@ -503,7 +622,20 @@ extern "C" int32_t ira_curve_fits(const float* y_dev, const int64_t* off_dev, co
   P.nranges = nranges; P.ncross = ncross; P.min_points = min_points; P.rel_to_peak = rel_to_peak;
   P.floor_db = floor_db; P.min_peak_above_floor = min_peak_above_floor; P.t_mul = t_mul; P.t_div = t_div; P.t_axis = t_axis_dev;
   const int threads = max_len <= 2048 ? 64 : (max_len <= 32768 ? 256 : 1024);
-  curve_fit_kernel<<<ncurves, threads, 0, (hipStream_t)stream>>>(y_dev, off_dev, len_dev, P, fit_out_dev,
-                                                                   ncross > 0 ? cross_out_dev : nullptr);
+  hipStream_t st = (hipStream_t)stream;
+  const int ntargets = 2 * nranges + ncross;
+  int pre = 0;
+  if (max_len > 4 * XS_CHUNK && !rel_to_peak && ntargets > 0 && ncurves <= 65535) {
+    // parallel crossing search for long curves; slots = head of each curve's output record (see the kernel comment)
+    double* slot_base = nranges > 0 ? fit_out_dev : cross_out_dev;
+    const int slot_stride = nranges > 0 ? nranges * IRA_FIT_DOUBLES : ncross;
+    hipError_t e = hipMemsetAsync(slot_base, 0x7f, sizeof(double) * (size_t)slot_stride * (size_t)ncurves, st);
+    if (e != hipSuccess) return ira_hip_status(e);
+    crossing_search_kernel<<<dim3((max_len + XS_CHUNK - 1) / XS_CHUNK, ncurves), XS_THREADS, 0, st>>>(
+        y_dev, off_dev, len_dev, P, reinterpret_cast<unsigned long long*>(slot_base), slot_stride);
+    pre = 1;
+  }
+  curve_fit_kernel<<<ncurves, threads, 0, st>>>(y_dev, off_dev, len_dev, P, fit_out_dev,
+                                               ncross > 0 ? cross_out_dev : nullptr, pre);
   IRA_RETURN_LAUNCH();
 }
