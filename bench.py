@@ -79,8 +79,8 @@ def cpu_baseline(seconds: float, budget_s: float = 20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="IRs per GPU per step")
     ap.add_argument("--seconds", type=float, default=10.0, help="IR length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
