@@ -813,3 +813,211 @@ def analyse_zplane(x: np.ndarray, sr: int = SR, **kw) -> Dict:
         out.update(max_radius=float(np.max(rad)), median_radius=float(np.median(rad)),
                    unstable=int(np.sum(rad >= 1.0)))
     return out
+
+
+# ----------------------------------------------------------------------------------------
+# section 8f  group delay                      (reference group_delay.py:89-137, :159-171, :209-220)
+# ----------------------------------------------------------------------------------------
+GD_DEFAULTS = dict(
+    trim_to_peak=True, ignore_leading_seconds=0.0, analysis_duration_seconds=None, use_hann_window=True,
+    fft_size=None, f_min_hz=20.0, f_max_hz=20000.0, unwrap_phase=True, smoothing_bins=0,
+)
+
+
+def group_delay_segment(n: int, peak: int, sr: int, s: Dict) -> Tuple[int, int]:
+    """(start, length) exactly as group_delay.py:159-171 selects it (note: NOT the select_segment rule -- the
+    ignore time is added to the start without being clipped to the remaining length first, and a duration of 0
+    still takes one sample)."""
+    start = peak if s["trim_to_peak"] else 0
+    start += int(round(float(s["ignore_leading_seconds"]) * sr))
+    start = max(0, min(start, n))
+    if s["analysis_duration_seconds"] is None:
+        return start, n - start
+    want = max(1, int(round(float(s["analysis_duration_seconds"]) * sr)))
+    return start, max(0, min(want, n - start))
+
+
+def group_delay_fft_size(seg_len: int, fft_size: Optional[int]) -> int:
+    """group_delay.py:101-107: next power of two >= segment length, capped at 2^20, unless given."""
+    if fft_size is not None:
+        return int(fft_size)
+    p = 1 << (max(1, int(seg_len)) - 1).bit_length()
+    return min(p, 1 << 20)
+
+
+def analyse_group_delay(x: np.ndarray, sr: int = SR, **kw) -> Dict:
+    """group_delay.py:89-137: windowed segment -> rfft(n_fft) -> angle -> unwrap -> -d(phase)/dw (np.gradient on the
+    rad/sample axis) -> optional moving average ('same' convolution) -> frequency mask."""
+    s = dict(GD_DEFAULTS); s.update(kw)
+    start, length = group_delay_segment(x.size, peak_index(x), sr, s)
+    seg = x[start : start + length].astype(np.float64)
+    if s["use_hann_window"]:
+        seg = seg * np.hanning(seg.size)
+    n_fft = group_delay_fft_size(seg.size, s["fft_size"])
+    H = np.fft.rfft(seg, n=n_fft)
+    freq = np.fft.rfftfreq(n_fft, d=1.0 / float(sr))
+    ph = np.angle(H)
+    if s["unwrap_phase"]:
+        ph = np.unwrap(ph)
+    w = 2.0 * np.pi * (freq / float(sr))
+    gd = -np.gradient(ph, w)
+    sb = int(s["smoothing_bins"] or 0)
+    if sb > 1:
+        gd = np.convolve(gd, np.ones(sb, dtype=np.float64) / float(sb), mode="same")
+    m = (freq >= float(s["f_min_hz"])) & (freq <= float(s["f_max_hz"]))
+    return dict(start=start, length=length, n_fft=n_fft, freq=freq[m], gd=gd[m])
+
+
+def group_delay_summary(names: List[str], gds: List[np.ndarray]) -> str:
+    """group_delay.py:209-220."""
+    lines = []
+    for name, gd in zip(names, gds):
+        if gd.size == 0:
+            continue
+        lines.append(f"- {name}: gd median={float(np.median(gd)):.3f} samples, "
+                     f"p10={float(np.percentile(gd, 10)):.3f}, p90={float(np.percentile(gd, 90)):.3f}")
+    if not lines:
+        return "No group delay results."
+    return "Group delay summary:\n" + "\n".join(lines)
+
+
+# ----------------------------------------------------------------------------------------
+# section 8f  diffusion                        (reference diffusion.py:92-226, :234-376, :457-476)
+# ----------------------------------------------------------------------------------------
+DIFF_DEFAULTS = dict(
+    trim_to_peak=True, ignore_leading_seconds=0.0, window_seconds=0.050, hop_seconds=0.010,
+    max_lag_milliseconds=10.0, echo_density_threshold_rms=1.0, echo_density_normalise_to_gaussian=True,
+)
+
+
+def diffusion_trim(x: np.ndarray, sr: int, trim_to_peak: bool, ignore_leading_seconds: float) -> Tuple[np.ndarray, int]:
+    """diffusion.py:92-117: float64 view -> argmax|x| -> optional ignore -> back to float32."""
+    v = x.astype(np.float64, copy=False)
+    start = 0
+    if trim_to_peak:
+        pk = int(np.argmax(np.abs(v)))
+        start += pk
+        v = v[pk:]
+    if ignore_leading_seconds > 0.0:
+        ig = int(round(ignore_leading_seconds * float(sr)))
+        ig = max(0, min(ig, v.size))
+        start += ig
+        v = v[ig:]
+    return v.astype(np.float32), start
+
+
+def diffusion_geometry(n: int, sr: int, s: Dict) -> Tuple[int, int, int, int]:
+    """(win, hop, frames, max_lag), diffusion.py:246-258."""
+    win = max(16, int(round(s["window_seconds"] * float(sr))))
+    hop = max(1, int(round(s["hop_seconds"] * float(sr))))
+    frames = 0 if n < win else 1 + (n - win) // hop
+    max_lag = max(1, int(round((s["max_lag_milliseconds"] / 1000.0) * float(sr))))
+    return win, hop, frames, max_lag
+
+
+def gaussian_exceedance(k: float) -> float:
+    """diffusion.py:126-136: P(|x| > k sigma) for a Gaussian."""
+    import math
+    phi = 0.5 * (1.0 + math.erf(float(k) / np.sqrt(2.0)))
+    return 2.0 * (1.0 - phi)
+
+
+def window_max_abs_autocorr(w: np.ndarray, max_lag: int) -> float:
+    """diffusion.py:139-159.  float32 arithmetic throughout (float32 mean, float32 dots), like the reference."""
+    if w.size < 4:
+        return float("nan")
+    w0 = w - float(np.mean(w))
+    den = float(np.dot(w0, w0))
+    if den <= 1e-20:
+        return float("nan")
+    best = 0.0
+    for lag in range(1, min(max_lag, w0.size - 2) + 1):
+        best = max(best, abs(float(np.dot(w0[:-lag], w0[lag:]) / den)))
+    return best
+
+
+def window_echo_density(w: np.ndarray, thr_rms: float, normalise: bool) -> float:
+    """diffusion.py:205-226."""
+    if w.size < 4:
+        return float("nan")
+    w0 = w - float(np.mean(w))
+    rms = float(np.sqrt(np.mean(w0 * w0)))
+    if rms <= 1e-20:
+        return float("nan")
+    frac = float(np.mean(np.abs(w0) > float(thr_rms) * rms))
+    if not normalise:
+        return frac
+    ex = gaussian_exceedance(thr_rms)
+    return float("nan") if ex <= 1e-12 else frac / ex
+
+
+def window_corr0(a: np.ndarray, b: np.ndarray) -> float:
+    """diffusion.py:162-174."""
+    if a.size != b.size or a.size < 4:
+        return float("nan")
+    a0 = a - float(np.mean(a)); b0 = b - float(np.mean(b))
+    aa = float(np.dot(a0, a0)); bb = float(np.dot(b0, b0))
+    if aa <= 1e-20 or bb <= 1e-20:
+        return float("nan")
+    return float(np.dot(a0, b0) / np.sqrt(aa * bb))
+
+
+def window_iacc_max(a: np.ndarray, b: np.ndarray, max_lag: int) -> float:
+    """diffusion.py:177-202: max |normalised cross-correlation| over lags -max_lag..+max_lag."""
+    if a.size != b.size or a.size < 4:
+        return float("nan")
+    a0 = a - float(np.mean(a)); b0 = b - float(np.mean(b))
+    den = np.sqrt(float(np.dot(a0, a0)) * float(np.dot(b0, b0)))
+    if den <= 1e-20:
+        return float("nan")
+    L = min(max_lag, a0.size - 2)
+    best = abs(float(np.dot(a0, b0) / den))
+    for lag in range(1, L + 1):
+        best = max(best, abs(float(np.dot(a0[:-lag], b0[lag:]) / den)))
+        best = max(best, abs(float(np.dot(a0[lag:], b0[:-lag]) / den)))
+    return best
+
+
+def analyse_diffusion(x: np.ndarray, sr: int = SR, **kw) -> Dict:
+    """diffusion.py:234-291: per-window max|autocorr| and echo density of one channel (float32 series)."""
+    s = dict(DIFF_DEFAULTS); s.update(kw)
+    v, start = diffusion_trim(x, sr, bool(s["trim_to_peak"]), float(s["ignore_leading_seconds"]))
+    win, hop, frames, max_lag = diffusion_geometry(v.size, sr, s)
+    if frames <= 0:
+        raise ValueError("Not enough samples for diffusion analysis windows.")
+    t = np.zeros(frames, dtype=np.float32); ac = np.zeros(frames, dtype=np.float32); ed = np.zeros(frames, dtype=np.float32)
+    for i in range(frames):
+        w = v[i * hop : i * hop + win]
+        t[i] = (i * hop + win * 0.5) / float(sr)
+        ac[i] = window_max_abs_autocorr(w, max_lag)
+        ed[i] = window_echo_density(w, s["echo_density_threshold_rms"], bool(s["echo_density_normalise_to_gaussian"]))
+    return dict(start=start, time=t, ac=ac, ed=ed, win=win, hop=hop, max_lag=max_lag)
+
+
+def diffusion_stereo(left: np.ndarray, right: np.ndarray, sr: int = SR, **kw) -> Dict:
+    """diffusion.py:323-376: both channels trimmed at the peak of their MEAN; corr0 and IACC per window."""
+    s = dict(DIFF_DEFAULTS); s.update(kw)
+    comb = (left.astype(np.float64) + right.astype(np.float64)) * 0.5
+    ct, start = diffusion_trim(comb.astype(np.float32), sr, bool(s["trim_to_peak"]), float(s["ignore_leading_seconds"]))
+    l = left.astype(np.float32)[start : start + ct.size]
+    r = right.astype(np.float32)[start : start + ct.size]
+    win, hop, frames, max_lag = diffusion_geometry(ct.size, sr, s)
+    c0 = np.zeros(max(frames, 0), dtype=np.float32); ia = np.zeros(max(frames, 0), dtype=np.float32)
+    for i in range(frames):
+        wl, wr = l[i * hop : i * hop + win], r[i * hop : i * hop + win]
+        c0[i] = window_corr0(wl, wr)
+        ia[i] = window_iacc_max(wl, wr, max_lag)
+    return dict(start=start, corr0=c0, iacc=ia)
+
+
+def diffusion_summary(names: List[str], series: List[Dict], stereo: Optional[Dict] = None) -> str:
+    """diffusion.py:457-476."""
+    lines = []
+    for name, d in zip(names, series):
+        lines.append(f"[{name}]")
+        lines.append(f"  median_max_abs_autocorr={float(np.nanmedian(d['ac'])):.3f}")
+        lines.append(f"  median_echo_density={float(np.nanmedian(d['ed'])):.3f}")
+        if stereo is not None:
+            lines.append(f"  median_corr0={float(np.nanmedian(stereo['corr0'])):.3f}")
+            lines.append(f"  median_iacc_max={float(np.nanmedian(stereo['iacc'])):.3f}")
+    return "\n".join(lines)

@@ -47,6 +47,8 @@ import analyse.filterplot as rfilt  # noqa: E402
 import analyse.zplane as rz  # noqa: E402
 import analyse.io as rio  # noqa: E402
 import analyse.report as rreport  # noqa: E402
+import analyse.group_delay as rgd  # noqa: E402
+import analyse.diffusion as rdiff  # noqa: E402
 
 SR = 48000
 ARR = {}
@@ -264,6 +266,53 @@ def main():
                        summary=rz.summarise_zplane_results_text([res]))
     META["cases"]["zplane"] = zc
 
+    # ---------------- section 8f: group delay ----------------------------------------------------
+    # the reference has no per-channel entry for group delay (the selection lives in its plot function,
+    # group_delay.py:159-171); the segment bounds are recomputed here and stored with the case
+    def gd_case(tag, x, **kw):
+        st = rgd.GroupDelayAnalysisSettings(**kw)
+        start = int(np.argmax(np.abs(x))) if st.trim_to_peak else 0
+        start += int(round(float(st.ignore_leading_seconds) * SR))
+        start = max(0, min(start, len(x)))
+        if st.analysis_duration_seconds is None:
+            seg = x[start:]
+        else:
+            seg = x[start : start + max(1, int(round(float(st.analysis_duration_seconds) * SR)))]
+        r = rgd._compute_group_delay_from_ir(seg, SR, st)
+        put(f"{tag}/gd/freq", r.frequency_hz); put(f"{tag}/gd/gd", r.group_delay_samples)
+        res = rgd.ChannelGroupDelayResult("mono", SR, r.frequency_hz, r.group_delay_samples)
+        META["cases"][f"{tag}/gd"] = dict(kw=kw, start=start, length=int(seg.size),
+                                          summary=rgd.summarise_group_delay_results_text([res]))
+
+    gd_case("xa", xa)
+    gd_case("xc", xc)
+    gd_case("xb_sel", xb, ignore_leading_seconds=0.002, analysis_duration_seconds=0.2)
+    gd_case("xa_rect", xa, use_hann_window=False)
+    gd_case("xa_fft", xa, fft_size=16384)                 # n_fft < segment length: rfft truncates the windowed segment
+    gd_case("xa_fft3", xa, fft_size=3 * 5 * 7 * 256)      # not a power of two
+    gd_case("xa_smooth", xa, smoothing_bins=9)
+    gd_case("xa_nounwrap", xa, unwrap_phase=False, f_min_hz=100.0, f_max_hz=5000.0)
+
+    # ---------------- section 8f: diffusion --------------------------------------------------------
+    def diff_case(tag, x, **kw):
+        st = rdiff.DiffusionAnalysisSettings(**kw)
+        r = rdiff.analyse_diffusion_for_channel(x, SR, "mono", st)
+        put(f"{tag}/diff/time", r.series.time_seconds); put(f"{tag}/diff/ac", r.series.max_abs_autocorr)
+        put(f"{tag}/diff/ed", r.series.echo_density)
+        META["cases"][f"{tag}/diff"] = dict(kw=kw, frames=int(r.series.time_seconds.size),
+                                            summary=rdiff.summarise_diffusion_results_text([r]))
+
+    diff_case("xa", xa)
+    diff_case("xb", xb)
+    diff_case("xb16", xb16)
+    diff_case("xc_ign", xc, ignore_leading_seconds=0.0123)
+    diff_case("xa_short", xa, window_seconds=0.012, hop_seconds=0.004, max_lag_milliseconds=20.0)   # lag > window-2
+    diff_case("xa_thr", xa, echo_density_threshold_rms=1.5, echo_density_normalise_to_gaussian=False)
+    diff_case("xa_notrim", xa, trim_to_peak=False, hop_seconds=0.025)
+    xsil = xa.copy(); xsil[6000:] = 0.0                    # digital silence -> NaN frames
+    put("in/xsil", xsil)
+    diff_case("xsil", xsil)
+
     # ---------------- a23: report markdown + full-file command path ---------------------------------
     tmp = Path(tempfile.mkdtemp(prefix="goldens_"))
     rep = {}
@@ -286,8 +335,14 @@ def main():
                             ("monomix", rreport.ReportSettings(run_impulse_response_plots=False, run_group_delay=False,
                                                                run_diffusion=False,
                                                                common_use_mono_downmix_for_stereo=True,
+                                                               common_ignore_leading_seconds=0.003)),
+                            ("full", rreport.ReportSettings(run_impulse_response_plots=False)),
+                            ("fullmix", rreport.ReportSettings(run_impulse_response_plots=False,
+                                                               common_use_mono_downmix_for_stereo=True,
                                                                common_ignore_leading_seconds=0.003))):
-            if name == "mono16" and variant == "monomix":
+            if name == "mono16" and variant in ("monomix", "fullmix"):
+                continue
+            if name == "stereof32" and variant in ("full", "fullmix"):
                 continue
             out = tmp / f"out_{name}_{variant}" / "rep"
             res = rreport.run_report_from_wav_file(wav, out, st)
@@ -300,6 +355,22 @@ def main():
     rep["stereo16/zplane32"] = dict(summary=rz.summarise_zplane_results_text(zres))
     for r_ in zres:
         put(f"report/stereo16/zplane32/{r_.channel_name}", r_.poles)
+    dres = rdiff.analyse_diffusion_from_wav_file(tmp / "stereo16.wav", rdiff.DiffusionAnalysisSettings())
+    rep["stereo16/diffusion"] = dict(summary=rdiff.summarise_diffusion_results_text(dres),
+                                     names=[r_.channel_name for r_ in dres])
+    for r_ in dres:
+        put(f"report/stereo16/diff/{r_.channel_name}/ac", r_.series.max_abs_autocorr)
+        put(f"report/stereo16/diff/{r_.channel_name}/ed", r_.series.echo_density)
+    put("report/stereo16/diff/corr0", dres[0].series.corr0); put("report/stereo16/diff/iacc", dres[0].series.iacc_max)
+    put("report/stereo16/diff/time", dres[0].series.time_seconds)
+    dres = rdiff.analyse_diffusion_from_wav_file(tmp / "stereo16.wav",
+                                                 rdiff.DiffusionAnalysisSettings(ignore_leading_seconds=0.02, max_lag_milliseconds=1.0))
+    put("report/stereo16/diff_ign/corr0", dres[0].series.corr0); put("report/stereo16/diff_ign/iacc", dres[0].series.iacc_max)
+    gres = rgd.plot_group_delay_from_wav_file(str(tmp / "stereo16.wav"), rgd.GroupDelayAnalysisSettings(),
+                                              rgd.GroupDelayPlotSettings(), output_basename=str(tmp / "g"), show_interactive=False)
+    rep["stereo16/groupdelay"] = dict(summary=rgd.summarise_group_delay_results_text(gres))
+    for r_ in gres:
+        put(f"report/stereo16/gd/{r_.channel_name}", r_.group_delay_samples)
     fres = rfilt.analyse_filter_response_from_wav_file(tmp / "stereo16.wav", rfilt.FilterAnalysisSettings())
     rep["stereo16/filter"] = dict(summary=rfilt.summarise_filter_response_results_text(fres))
     META["cases"]["report"] = rep

@@ -180,3 +180,54 @@ def test_zplane(golden, tag, inp):
     np.testing.assert_array_equal(r["poles"], g[f"{tag}/zplane/poles"])
     np.testing.assert_array_equal(r["zeros"], g[f"{tag}/zplane/zeros"])
     assert (r["max_radius"], r["median_radius"], r["unstable"]) == (cs["max_r"], cs["med_r"], cs["unstable"])
+
+
+# ---- section 8f rows: group delay and diffusion ----------------------------------------------------------------
+GD_CASES = [("xa", "xa"), ("xc", "xc"), ("xb_sel", "xb"), ("xa_rect", "xa"), ("xa_fft", "xa"), ("xa_fft3", "xa"),
+            ("xa_smooth", "xa"), ("xa_nounwrap", "xa")]
+DIFF_CASES = [("xa", "xa"), ("xb", "xb"), ("xb16", "xb16"), ("xc_ign", "xc"), ("xa_short", "xa"), ("xa_thr", "xa"),
+              ("xa_notrim", "xa"), ("xsil", "xsil")]
+
+
+@pytest.mark.parametrize("tag,inp", GD_CASES)
+def test_group_delay_oracle_bit_exact(golden, tag, inp):
+    g, c, _ = golden
+    cs = c[f"{tag}/gd"]
+    o = O.analyse_group_delay(g[f"in/{inp}"], SR, **cs["kw"])
+    assert (o["start"], o["length"]) == (cs["start"], cs["length"])
+    np.testing.assert_array_equal(o["freq"], g[f"{tag}/gd/freq"])
+    np.testing.assert_array_equal(o["gd"], g[f"{tag}/gd/gd"])
+    assert O.group_delay_summary(["mono"], [o["gd"]]) == cs["summary"]
+
+
+@pytest.mark.parametrize("tag,inp", DIFF_CASES)
+def test_diffusion_oracle_bit_exact(golden, tag, inp):
+    g, c, _ = golden
+    cs = c[f"{tag}/diff"]
+    o = O.analyse_diffusion(g[f"in/{inp}"], SR, **cs["kw"])
+    assert o["time"].size == cs["frames"]
+    for key, name in (("time", "time"), ("ac", "ac"), ("ed", "ed")):
+        np.testing.assert_array_equal(o[key], g[f"{tag}/diff/{name}"])       # NaN == NaN under assert_array_equal
+    assert O.diffusion_summary(["mono"], [o]) == cs["summary"]
+
+
+def test_diffusion_stereo_oracle_bit_exact(golden):
+    g, c, _ = golden
+    pcm = g["report/stereo16/pcm"]
+    chans = O.analysis_channels(O.pcm_to_float32(pcm), False)
+    (nl, l), (nr, r) = chans
+    st = O.diffusion_stereo(l, r, SR)
+    np.testing.assert_array_equal(st["corr0"], g["report/stereo16/diff/corr0"])
+    np.testing.assert_array_equal(st["iacc"], g["report/stereo16/diff/iacc"])
+    series = [O.analyse_diffusion(l, SR), O.analyse_diffusion(r, SR)]
+    for name, d in zip((nl, nr), series):
+        np.testing.assert_array_equal(d["ac"], g[f"report/stereo16/diff/{name}/ac"])
+        np.testing.assert_array_equal(d["ed"], g[f"report/stereo16/diff/{name}/ed"])
+    assert O.diffusion_summary([nl, nr], series, st) == c["report"]["stereo16/diffusion"]["summary"]
+    st2 = O.diffusion_stereo(l, r, SR, ignore_leading_seconds=0.02, max_lag_milliseconds=1.0)
+    np.testing.assert_array_equal(st2["corr0"], g["report/stereo16/diff_ign/corr0"])
+    np.testing.assert_array_equal(st2["iacc"], g["report/stereo16/diff_ign/iacc"])
+    gd = [O.analyse_group_delay(ch, SR)["gd"] for ch in (l, r)]
+    for name, v in zip((nl, nr), gd):
+        np.testing.assert_array_equal(v, g[f"report/stereo16/gd/{name}"])
+    assert O.group_delay_summary([nl, nr], gd) == c["report"]["stereo16/groupdelay"]["summary"]
