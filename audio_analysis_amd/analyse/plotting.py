@@ -114,6 +114,21 @@ def render_frequency_response(results, settings, plot_settings, title, path, sho
     finish(fig, path, show)
 
 
+def render_group_delay(result, settings, plot_settings, title, path, show):
+    if path is None and not show:
+        return
+    fig, ax = new_axes(title)
+    ax.plot(result.frequency_hz, result.group_delay_samples,
+            alpha=plot_settings.secondary_channel_alpha if result.channel_name != "L" else 1.0)
+    ax.set_xscale("log")
+    ax.set_xlabel("Frequency (Hz)"); ax.set_ylabel("Group delay (samples)")
+    if plot_settings.show_zero_line:
+        ax.axhline(0.0, linestyle="--", linewidth=1.0)
+    if plot_settings.ylim_samples is not None:
+        ax.set_ylim(*plot_settings.ylim_samples)
+    finish(fig, path, show)
+
+
 def render_filter_response(results, settings, plot_settings, title, path, show):
     if path is None and not show:
         return

@@ -113,6 +113,11 @@ struct Jobs {
   const int64_t* xoff;
   const int64_t* x2off;     // optional: second real signal of the same length (-1: none) -> z = x1 + i x2
   int use_hann;
+  // optional (null = the transform length L): samples actually read / Hann window length, per signal of the pair.
+  // numpy.fft.rfft(x * hanning(len(x)), n=P) zero-pads (len < P) or truncates (len > P) a segment whose window was
+  // built for its OWN length (reference group_delay.py:95-109).
+  const int32_t* data_len; const int32_t* win_len;
+  const int32_t* data_len2; const int32_t* win_len2;
   // masked-spectrum input
   const cd* spec;           // half spectra, complex f64
   const int64_t* spec_off;  // element e reads spec + spec_off[e], (L/2+1) bins
@@ -140,14 +145,15 @@ enum OutMode { OUT_SPECTRUM = 0, OUT_BANDS = 1 };
 // w = chirp(n, L) and h = hann_at(n, L) come from the caller (recurrences along a thread's elements, see
 // cols_fwd_kernel); IN_FILTER evaluates its mirrored chirp directly (filters are plan data, built once and cached).
 template <int MODE>
-__device__ __forceinline__ cd gen_input(const Jobs& J, int e, long long n, long long L, long long M, cd w, double h) {
+__device__ __forceinline__ cd gen_input(const Jobs& J, int e, long long n, long long L, long long M, cd w, double h,
+                                        double h2, long long nd1, long long nd2) {
   if (MODE == IN_SIGNAL) {
     if (n >= L) return {0.0, 0.0};
-    double v = (double)J.x[J.xoff[e] + n];
+    double v = n < nd1 ? (double)J.x[J.xoff[e] + n] : 0.0;
     const long long o2 = J.x2off ? J.x2off[e] : -1;
-    double v2 = o2 >= 0 ? (double)J.x[o2 + n] : 0.0;
+    double v2 = (o2 >= 0 && n < nd2) ? (double)J.x[o2 + n] : 0.0;
     if (J.use_hann) {
-      v *= h; v2 *= h;
+      v *= h; v2 *= h2;
     }
     if (o2 < 0) return {v * w.re, v * w.im};
     return {v * w.re - v2 * w.im, v * w.im + v2 * w.re};
@@ -217,26 +223,44 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     const long long dn = (long long)(FL_THREADS / C) * N2;
     const long long n0 = (long long)n1_0 * N2 + n2_0 + c;
     cd w = {1.0, 0.0}, d = {1.0, 0.0}, e2 = {1.0, 0.0};
-    double hc = 1.0, hs = 0.0, rc = 1.0, rs = 0.0;
+    // Hann windows of the (up to) two signals: window length and sample count may differ from the transform length
+    long long lw1 = L, lw2 = L, nd1 = L, nd2 = L;
+    if (MODE == IN_SIGNAL) {
+      if (J.win_len) lw1 = J.win_len[e];
+      if (J.data_len) nd1 = J.data_len[e];
+      lw2 = J.win_len2 ? (long long)J.win_len2[e] : lw1;
+      nd2 = J.data_len2 ? (long long)J.data_len2[e] : nd1;
+    }
+    double hc = 1.0, hs = 0.0, rc = 1.0, rs = 0.0, hc2 = 1.0, hs2 = 0.0, rc2 = 1.0, rs2 = 0.0;
     if (MODE != IN_FILTER) {
       w = unit_q(n0 * n0, L);
       d = unit_q(2 * n0 * dn + dn * dn, L);
       e2 = unit_q(2 * dn * dn, L);
-      if (MODE == IN_SIGNAL && J.use_hann && L > 1) {
-        sincospi((double)(2 * n0 + 1 - L) / (double)(L - 1), &hs, &hc);
-        sincospi((double)(2 * dn) / (double)(L - 1), &rs, &rc);
+      if (MODE == IN_SIGNAL && J.use_hann) {
+        if (lw1 > 1) {
+          sincospi((double)(2 * n0 + 1 - lw1) / (double)(lw1 - 1), &hs, &hc);
+          sincospi((double)(2 * dn) / (double)(lw1 - 1), &rs, &rc);
+        }
+        if (lw2 > 1) {
+          sincospi((double)(2 * n0 + 1 - lw2) / (double)(lw2 - 1), &hs2, &hc2);
+          sincospi((double)(2 * dn) / (double)(lw2 - 1), &rs2, &rc2);
+        }
       }
     }
     long long n = n0;
     for (unsigned i = tid; i < N1 * (unsigned)C; i += FL_THREADS, n += dn) {
       const unsigned n1 = i / C;
-      const double h = (L > 1) ? 0.5 + 0.5 * hc : 1.0;
-      lds[c * stride + n1] = (g.ablate & 1) ? cd{(double)n, 1.0} : gen_input<MODE>(J, e, n, L, M, w, h);
+      const double h = (lw1 > 1) ? 0.5 + 0.5 * hc : 1.0;
+      const double h2 = (lw2 > 1) ? 0.5 + 0.5 * hc2 : 1.0;
+      lds[c * stride + n1] = (g.ablate & 1) ? cd{(double)n, 1.0} : gen_input<MODE>(J, e, n, L, M, w, h, h2, nd1, nd2);
       w = ira::cmul(w, d);
       d = ira::cmul(d, e2);
       const double nc = hc * rc - hs * rs;
       hs = hs * rc + hc * rs;
       hc = nc;
+      const double nc2 = hc2 * rc2 - hs2 * rs2;
+      hs2 = hs2 * rc2 + hc2 * rs2;
+      hc2 = nc2;
     }
   }
   __syncthreads();
@@ -452,7 +476,9 @@ extern "C" int32_t ira_rfft_any(const float* x_dev, const int64_t* xoff_dev, con
                                 const void* tf_dev, const double* bfilt_dev, const int32_t* bidx_dev,
                                 double* work_dev, double* spec_out_dev, const int64_t* spec_off_dev,
                                 const int64_t* x2off_dev, const int64_t* spec_off2_dev, double* zpair_dev,
-                                const int64_t* zpair_off_dev, int32_t max_len, void* stream) {
+                                const int64_t* zpair_off_dev, int32_t max_len, const int32_t* data_len_dev,
+                                const int32_t* win_len_dev, const int32_t* data_len2_dev,
+                                const int32_t* win_len2_dev, void* stream) {
   IRA_CHECK_PTR(x_dev); IRA_CHECK_PTR(xoff_dev); IRA_CHECK_PTR(L_dev); IRA_CHECK_PTR(t1_dev); IRA_CHECK_PTR(t2_dev);
   IRA_CHECK_PTR(tf_dev); IRA_CHECK_PTR(bfilt_dev); IRA_CHECK_PTR(bidx_dev); IRA_CHECK_PTR(work_dev);
   IRA_CHECK_PTR(spec_out_dev); IRA_CHECK_PTR(spec_off_dev);
@@ -464,6 +490,7 @@ extern "C" int32_t ira_rfft_any(const float* x_dev, const int64_t* xoff_dev, con
   J.L = L_dev; J.x = x_dev; J.xoff = xoff_dev; J.use_hann = use_hann;
   J.bfilt = reinterpret_cast<const cd*>(bfilt_dev); J.bidx = bidx_dev;
   J.spec_out = reinterpret_cast<cd*>(spec_out_dev); J.spec_out_off = spec_off_dev;
+  J.data_len = data_len_dev; J.win_len = win_len_dev; J.data_len2 = data_len2_dev; J.win_len2 = win_len2_dev;
   if (x2off_dev != nullptr) {
     if (spec_off2_dev == nullptr || zpair_dev == nullptr || zpair_off_dev == nullptr) return IRA_E_NULL;
     if (max_len <= 0) return IRA_E_SIZE;

@@ -55,13 +55,15 @@ __global__ __launch_bounds__(UW_THREADS) void unwrap_kernel(const double* __rest
                                                             const int64_t* __restrict__ phase_off,
                                                             const int32_t* __restrict__ L, int do_unwrap,
                                                             double out_scale, float* __restrict__ out,
-                                                            const int64_t* __restrict__ out_off) {
+                                                            const int64_t* __restrict__ out_off,
+                                                            double* __restrict__ out64) {
   __shared__ double wave_tot[UW_THREADS / IRA_WAVE];
   __shared__ double tile_total;
   const int e = blockIdx.x;
   const long long n = (long long)L[e] / 2 + 1;
   const double* p = phase + phase_off[e];
-  float* o = out + out_off[e];
+  float* o = out ? out + out_off[e] : nullptr;
+  double* o64 = out64 ? out64 + out_off[e] : nullptr;     // float64 radians (group delay differentiates this)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   double carry = 0.0;
   // One workgroup walks the spectrum tile by tile (the correction prefix is sequential across tiles); the NEXT tile's
@@ -109,7 +111,11 @@ __global__ __launch_bounds__(UW_THREADS) void unwrap_kernel(const double* __rest
 #pragma unroll
     for (int r = 0; r < UW_PER; ++r) {
       const long long i = i0 + r;
-      if (i < n) o[i] = (float)((v[r] + (c[r] + add)) * out_scale);
+      if (i < n) {
+        const double u = v[r] + (c[r] + add);
+        if (o) o[i] = (float)(u * out_scale);
+        if (o64) o64[i] = u;
+      }
     }
     if (t == UW_THREADS - 1) tile_total = c[3] + add;
     __syncthreads();
@@ -117,6 +123,55 @@ __global__ __launch_bounds__(UW_THREADS) void unwrap_kernel(const double* __rest
     // no third barrier: the next tile rewrites wave_tot / tile_total only after barriers every thread must reach
     // after its reads of this tile's values
   }
+}
+
+// ---- group delay: gd = -numpy.gradient(phase, w), w[k] = 2 pi ((k * val) / sr)  (reference group_delay.py:113-124) ------
+// numpy.gradient with a coordinate ARRAY takes the uniform-spacing formula only if every diff(w) is bit-identical and
+// the three-point non-uniform formula otherwise; both are reproduced, the choice is made by gd_uniform_kernel.
+__device__ __forceinline__ double gd_w(long long k, double val, double sr) {
+  return 6.283185307179586 * (((double)k * val) / sr);      // (2.0 * np.pi) * (freq / sr)
+}
+
+__global__ void gd_uniform_kernel(const int32_t* __restrict__ nbins, const double* __restrict__ val, double sr,
+                                  int32_t* __restrict__ nonuniform) {
+  const int e = blockIdx.y;
+  const long long n = nbins[e];
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // diff index, 0 .. n-2
+  if (i + 1 >= n || i == 0) return;
+  const double v = val[e];
+  const double d0 = gd_w(1, v, sr) - gd_w(0, v, sr);
+  const double di = gd_w(i + 1, v, sr) - gd_w(i, v, sr);
+  if (di != d0) nonuniform[e] = 1;                                            // benign race: every writer stores 1
+}
+
+__global__ void gd_gradient_kernel(const double* __restrict__ phase, const int64_t* __restrict__ off,
+                                   const int32_t* __restrict__ nbins, const double* __restrict__ val, double sr,
+                                   const int32_t* __restrict__ nonuniform, double* __restrict__ out) {
+  const int e = blockIdx.y;
+  const long long n = nbins[e];
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* f = phase + off[e];
+  double* o = out + off[e];
+  const double v = val[e];
+  if (n < 2) { o[i] = __longlong_as_double(0x7ff8000000000000ll); return; }   // numpy raises; callers never ask
+  double g;
+  if (i == 0) {
+    g = (f[1] - f[0]) / (gd_w(1, v, sr) - gd_w(0, v, sr));
+  } else if (i == n - 1) {
+    g = (f[n - 1] - f[n - 2]) / (gd_w(n - 1, v, sr) - gd_w(n - 2, v, sr));
+  } else if (!nonuniform[e]) {
+    const double dx = gd_w(1, v, sr) - gd_w(0, v, sr);
+    g = (f[i + 1] - f[i - 1]) / (2.0 * dx);
+  } else {
+    const double dx1 = gd_w(i, v, sr) - gd_w(i - 1, v, sr);
+    const double dx2 = gd_w(i + 1, v, sr) - gd_w(i, v, sr);
+    const double a = -(dx2) / (dx1 * (dx1 + dx2));
+    const double b = (dx2 - dx1) / (dx1 * dx2);
+    const double c = dx1 / (dx2 * (dx1 + dx2));
+    g = a * f[i - 1] + b * f[i] + c * f[i + 1];
+  }
+  o[i] = -g;
 }
 
 // ---- summary statistics ------------------------------------------------------------------------------------------
@@ -217,13 +272,30 @@ extern "C" int32_t ira_spectrum_mag_phase(const double* spec_dev, const int64_t*
 
 extern "C" int32_t ira_phase_unwrap(const double* phase_dev, const int64_t* phase_off_dev, const int32_t* L_dev,
                                     int32_t nb, int32_t do_unwrap, int32_t to_degrees, float* out_dev,
-                                    const int64_t* out_off_dev, void* stream) {
-  IRA_CHECK_PTR(phase_dev); IRA_CHECK_PTR(phase_off_dev); IRA_CHECK_PTR(L_dev); IRA_CHECK_PTR(out_dev);
-  IRA_CHECK_PTR(out_off_dev);
+                                    const int64_t* out_off_dev, double* out64_dev, void* stream) {
+  IRA_CHECK_PTR(phase_dev); IRA_CHECK_PTR(phase_off_dev); IRA_CHECK_PTR(L_dev); IRA_CHECK_PTR(out_off_dev);
+  if (out_dev == nullptr && out64_dev == nullptr) return IRA_E_NULL;
   if (nb <= 0) return nb == 0 ? IRA_OK : IRA_E_SIZE;
   const double scale = to_degrees ? (180.0 / kPi) : 1.0;
   unwrap_kernel<<<nb, UW_THREADS, 0, (hipStream_t)stream>>>(phase_dev, phase_off_dev, L_dev, do_unwrap, scale,
-                                                            out_dev, out_off_dev);
+                                                            out_dev, out_off_dev, out64_dev);
+  IRA_RETURN_LAUNCH();
+}
+
+extern "C" int32_t ira_group_delay(const double* phase_dev, const int64_t* off_dev, const int32_t* nbins_dev,
+                                   int32_t nb, int32_t max_bins, const double* bin_step_dev, double sample_rate_hz,
+                                   int32_t* flags_dev, double* gd_dev, void* stream) {
+  IRA_CHECK_PTR(phase_dev); IRA_CHECK_PTR(off_dev); IRA_CHECK_PTR(nbins_dev); IRA_CHECK_PTR(bin_step_dev);
+  IRA_CHECK_PTR(flags_dev); IRA_CHECK_PTR(gd_dev);
+  if (nb <= 0 || max_bins <= 0) return (nb == 0 || max_bins == 0) ? IRA_OK : IRA_E_SIZE;
+  if (nb > 65535 || !(sample_rate_hz > 0.0)) return IRA_E_SIZE;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(flags_dev, 0, sizeof(int32_t) * (size_t)nb, st);
+  if (e != hipSuccess) return ira_hip_status(e);
+  const dim3 grid((max_bins + 255) / 256, nb);
+  gd_uniform_kernel<<<grid, 256, 0, st>>>(nbins_dev, bin_step_dev, sample_rate_hz, flags_dev);
+  gd_gradient_kernel<<<grid, 256, 0, st>>>(phase_dev, off_dev, nbins_dev, bin_step_dev, sample_rate_hz, flags_dev,
+                                           gd_dev);
   IRA_RETURN_LAUNCH();
 }
 

@@ -448,15 +448,22 @@ class Engine:
                 first.append(order[i]); second.append(-1); i += 1
         return np.asarray(first, dtype=np.int64), np.asarray(second, dtype=np.int64)
 
-    def rfft_any(self, x_dev, xoff: np.ndarray, lengths: np.ndarray, use_hann: bool):
+    def rfft_any(self, x_dev, xoff: np.ndarray, lengths: np.ndarray, use_hann: bool,
+                 data_len: Optional[np.ndarray] = None, win_len: Optional[np.ndarray] = None):
         """
         Half spectra (complex f64) of x[xoff[e] : xoff[e]+L[e]] (* hanning) for every element.
+        data_len / win_len (optional, per element): numpy.fft.rfft(x[:d] * hanning(w)[:d], n=L) -- d samples are read
+        (d < L zero-pads, d > L truncates) under the Hann window of length w (reference group_delay.py:95-109).
         Returns (spec float64 device viewed as (total_bins, 2), spec_off int64 host in complex elements).
         """
         t = self.torch
         n = int(xoff.size)
         lengths = np.ascontiguousarray(lengths, dtype=np.int32)
         xoff = np.ascontiguousarray(xoff, dtype=np.int64)
+        padded = data_len is not None or win_len is not None
+        if padded:
+            data_len = np.ascontiguousarray(lengths if data_len is None else data_len, dtype=np.int32)
+            win_len = np.ascontiguousarray(lengths if win_len is None else win_len, dtype=np.int32)
         bins = lengths.astype(np.int64) // 2 + 1
         spec_off = np.zeros(n, dtype=np.int64)
         if n > 1:
@@ -474,8 +481,8 @@ class Engine:
             d_xo, d_l = self.to_dev(xoff[j1]), self.to_dev(jl)
             d_bi, d_so = self.to_dev(bidx), self.to_dev(spec_off[j1])
             paired = j2 >= 0
+            safe = np.maximum(j2, 0)
             if paired.any():
-                safe = np.maximum(j2, 0)
                 d_x2 = self.to_dev(np.where(paired, xoff[safe], -1).astype(np.int64))
                 d_so2 = self.to_dev(np.where(paired, spec_off[safe], 0).astype(np.int64))
                 zlen = np.where(paired, jl.astype(np.int64), 0)
@@ -485,10 +492,14 @@ class Engine:
                 d_zo = self.to_dev(zoff)
             else:
                 d_x2 = d_so2 = zpair = d_zo = None
+            d_dl = d_wl = d_dl2 = d_wl2 = None
+            if padded:
+                d_dl, d_wl = self.to_dev(data_len[j1]), self.to_dev(win_len[j1])
+                d_dl2, d_wl2 = self.to_dev(data_len[safe]), self.to_dev(win_len[safe])
             check(self.lib.ira_rfft_any(_ptr(x_dev), _ptr(d_xo), _ptr(d_l), int(j1.size), 1 if use_hann else 0, lm,
                                         _ptr(t1), _ptr(t2), _ptr(tf), _ptr(bf), _ptr(d_bi), _ptr(work), _ptr(spec),
                                         _ptr(d_so), _ptr(d_x2), _ptr(d_so2), _ptr(zpair), _ptr(d_zo), int(jl.max()),
-                                        self.stream), "ira_rfft_any")
+                                        _ptr(d_dl), _ptr(d_wl), _ptr(d_dl2), _ptr(d_wl2), self.stream), "ira_rfft_any")
         return spec, spec_off
 
     def band_irfft(self, spec_dev, spec_off: np.ndarray, lengths: np.ndarray, band_params: np.ndarray,
@@ -550,14 +561,31 @@ class Engine:
                                               self.stream), "ira_spectrum_mag_phase")
         return mag, ph
 
-    def phase_unwrap(self, phase_dev, off: np.ndarray, lengths: np.ndarray, unwrap: bool, degrees: bool):
+    def phase_unwrap(self, phase_dev, off: np.ndarray, lengths: np.ndarray, unwrap: bool, degrees: bool,
+                     as_float64: bool = False):
+        """float32 (optionally degrees) unwrapped phase, or with as_float64 the float64 radians."""
         t = self.torch
         lengths = np.ascontiguousarray(lengths, dtype=np.int32)
-        out = self.empty(int((lengths.astype(np.int64) // 2 + 1).sum()), t.float32)
+        total = int((lengths.astype(np.int64) // 2 + 1).sum())
+        out = self.empty(total, t.float64 if as_float64 else t.float32)
         d_o, d_l = self.to_dev(off), self.to_dev(lengths)
         check(self.lib.ira_phase_unwrap(_ptr(phase_dev), _ptr(d_o), _ptr(d_l), int(off.size), 1 if unwrap else 0,
-                                        1 if degrees else 0, _ptr(out), _ptr(d_o), self.stream), "ira_phase_unwrap")
+                                        1 if degrees else 0, 0 if as_float64 else _ptr(out), _ptr(d_o),
+                                        _ptr(out) if as_float64 else 0, self.stream), "ira_phase_unwrap")
         return out
+
+    def group_delay(self, phase64_dev, off: np.ndarray, n_fft: np.ndarray, bin_step: np.ndarray, sample_rate_hz: float):
+        """-numpy.gradient(phase, w) on the rad/sample axis of an n_fft-point rFFT (see ira_group_delay)."""
+        t = self.torch
+        n = int(off.size)
+        nbins = (np.ascontiguousarray(n_fft, dtype=np.int64) // 2 + 1).astype(np.int32)
+        gd = self.empty(int(nbins.astype(np.int64).sum()), t.float64)
+        flags = self.empty(n, t.int32)
+        d_o, d_n = self.to_dev(np.ascontiguousarray(off, np.int64)), self.to_dev(nbins)
+        d_v = self.to_dev(np.ascontiguousarray(bin_step, np.float64))
+        check(self.lib.ira_group_delay(_ptr(phase64_dev), _ptr(d_o), _ptr(d_n), n, int(nbins.max()), _ptr(d_v),
+                                       float(sample_rate_hz), _ptr(flags), _ptr(gd), self.stream), "ira_group_delay")
+        return gd
 
     def spectrum_stats(self, mag_dev, off: np.ndarray, lengths: np.ndarray, freq_val: np.ndarray, f_min: float,
                        f_max: float, probe_hz: float = 1000.0):

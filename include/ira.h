@@ -128,13 +128,19 @@ int32_t ira_bluestein_filter(const int32_t* L_dev, int32_t nfilt, int32_t log2m,
  * x2off_dev (may be NULL = no pairs) gives the second signal of element e or -1; its spectrum goes to
  * spec_off2_dev[e]; zpair_dev/zpair_off_dev is scratch for the full-length complex DFT (L[e] complex f64 per
  * paired element) and max_len >= max L[e].  Cross-talk between the two signals is at the 1e-16 level of the
- * larger one. */
+ * larger one.
+ * Zero-padded / truncated transforms, numpy.fft.rfft(x * hanning(len(x)), n=L) (reference
+ * analyse/group_delay.py:95-109): data_len_dev[e] (may be NULL = L[e]) samples are read, the rest of the L[e]
+ * inputs are zero (data_len > L truncates), and the Hann window is the one of length win_len_dev[e] (NULL =
+ * L[e]); data_len2_dev / win_len2_dev (NULL = same as the first) apply to the second signal of a pair. */
 int32_t ira_rfft_any(const float* x_dev, const int64_t* xoff_dev, const int32_t* L_dev, int32_t nb,
                      int32_t use_hann, int32_t log2m, const void* t1_dev, const void* t2_dev,
                      const void* tf_dev, const double* bfilt_dev, const int32_t* bidx_dev,
                      double* work_dev, double* spec_out_dev, const int64_t* spec_off_dev,
                      const int64_t* x2off_dev, const int64_t* spec_off2_dev, double* zpair_dev,
-                     const int64_t* zpair_off_dev, int32_t max_len, void* stream);
+                     const int64_t* zpair_off_dev, int32_t max_len, const int32_t* data_len_dev,
+                     const int32_t* win_len_dev, const int32_t* data_len2_dev, const int32_t* win_len2_dev,
+                     void* stream);
 
 /* Band filter bank: element e takes the half spectrum at spec_dev + 2*spec_off_dev[e] (length L[e]/2+1),
  * multiplies it by TWO real masks (band_params_dev: 2 records of IRA_BAND_DOUBLES doubles per element:
@@ -161,10 +167,21 @@ int32_t ira_spectrum_mag_phase(const double* spec_dev, const int64_t* spec_off_d
                                const int64_t* mag_off_dev, double* phase_dev,
                                const int64_t* phase_off_dev, void* stream);
 
-/* numpy.unwrap (optional) + rad2deg (optional) -> float32.  Reference analyse/filterplot.py:162-168. */
+/* numpy.unwrap (optional) + rad2deg (optional) -> float32 (out_dev, may be NULL), and/or the unwrapped phase in
+ * float64 radians (out64_dev, may be NULL; same offsets).  Reference analyse/filterplot.py:162-168 and
+ * analyse/group_delay.py:113-115. */
 int32_t ira_phase_unwrap(const double* phase_dev, const int64_t* phase_off_dev, const int32_t* L_dev,
                          int32_t nb, int32_t do_unwrap, int32_t to_degrees, float* out_dev,
-                         const int64_t* out_off_dev, void* stream);
+                         const int64_t* out_off_dev, double* out64_dev, void* stream);
+
+/* Section 8f, group delay: gd[e][k] = -numpy.gradient(phase[e], w)[k] with w[k] = 2 pi ((k * bin_step[e]) /
+ * sample_rate) in rad/sample, k < nbins[e]; numpy's rule "uniform formula only if every diff(w) is bit-identical,
+ * three-point non-uniform formula otherwise" is reproduced (flags_dev: nb int32 of scratch, 1 = non-uniform).
+ * phase/gd share off_dev (float64 elements).  Replaces the gradient step of _compute_group_delay_from_ir,
+ * reference analyse/group_delay.py:117-124. */
+int32_t ira_group_delay(const double* phase_dev, const int64_t* off_dev, const int32_t* nbins_dev, int32_t nb,
+                        int32_t max_bins, const double* bin_step_dev, double sample_rate_hz, int32_t* flags_dev,
+                        double* gd_dev, void* stream);
 
 /* Statistics over bins with f_min <= float32(k*freq_val[e]) <= f_max (float32 compares): out_dev[e*8..]:
  * [0] bin count [1] argmax bin of mag_db (first max) [2] its frequency [3] sum f*10^(dB/20) [4] sum 10^(dB/20)
