@@ -114,6 +114,26 @@ def render_frequency_response(results, settings, plot_settings, title, path, sho
     finish(fig, path, show)
 
 
+def render_diffusion(results, title, path, show):
+    if path is None and not show:
+        return
+    fig, ax = new_axes(title)
+    ax.set_xlabel("Time (s)"); ax.set_ylabel("Metric (unitless)")
+    ax.set_ylim(-0.05, 1.25)
+    for i, r in enumerate(results):
+        a = 1.0 if i == 0 else 0.7
+        ax.plot(r.series.time_seconds, r.series.max_abs_autocorr, alpha=a, label=f"max|autocorr| {r.channel_name}")
+        ax.plot(r.series.time_seconds, r.series.echo_density, alpha=a, linestyle="--",
+                label=f"echo_density {r.channel_name}")
+    if results and results[0].series.corr0 is not None and results[0].series.iacc_max is not None:
+        n = min(results[0].series.time_seconds.size, results[0].series.corr0.size)
+        ax.plot(results[0].series.time_seconds[:n], results[0].series.corr0[:n], linestyle=":", label="corr0 (L,R)")
+        ax.plot(results[0].series.time_seconds[:n], results[0].series.iacc_max[:n], linestyle="-.",
+                label="IACC max (±lag)")
+    ax.grid(True, which="both", linestyle=":", linewidth=0.5); ax.legend(loc="best")
+    finish(fig, path, show)
+
+
 def render_group_delay(result, settings, plot_settings, title, path, show):
     if path is None and not show:
         return

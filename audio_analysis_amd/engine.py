@@ -574,6 +574,41 @@ class Engine:
                                         _ptr(out) if as_float64 else 0, self.stream), "ira_phase_unwrap")
         return out
 
+    def diffusion(self, x_dev, xoff: np.ndarray, nframes: np.ndarray, win: int, hop: int, max_lag: int,
+                  thr_rms: float, gauss_expected: float):
+        """Per-window max|autocorr| and echo density (float32 device, flat) + host offsets (see ira_diffusion)."""
+        t = self.torch
+        n = int(xoff.size)
+        nframes = np.ascontiguousarray(nframes, dtype=np.int32)
+        out_off = np.zeros(n, dtype=np.int64)
+        if n > 1:
+            out_off[1:] = np.cumsum(nframes[:-1].astype(np.int64))
+        total = int(nframes.astype(np.int64).sum())
+        ac, ed = self.empty(total, t.float32), self.empty(total, t.float32)
+        d_xo, d_nf, d_oo = self.to_dev(np.ascontiguousarray(xoff, np.int64)), self.to_dev(nframes), self.to_dev(out_off)
+        check(self.lib.ira_diffusion(_ptr(x_dev), _ptr(d_xo), _ptr(d_nf), n, int(nframes.max()), int(win), int(hop),
+                                     int(max_lag), float(thr_rms), float(gauss_expected), _ptr(ac), _ptr(ed),
+                                     _ptr(d_oo), self.stream), "ira_diffusion")
+        return ac, ed, out_off
+
+    def diffusion_stereo(self, x_dev, loff: np.ndarray, roff: np.ndarray, nframes: np.ndarray, win: int, hop: int,
+                         max_lag: int):
+        """Per-window corr0 and IACC max of channel pairs (see ira_diffusion_stereo)."""
+        t = self.torch
+        n = int(loff.size)
+        nframes = np.ascontiguousarray(nframes, dtype=np.int32)
+        out_off = np.zeros(n, dtype=np.int64)
+        if n > 1:
+            out_off[1:] = np.cumsum(nframes[:-1].astype(np.int64))
+        total = int(nframes.astype(np.int64).sum())
+        c0, ia = self.empty(total, t.float32), self.empty(total, t.float32)
+        d_lo, d_ro = self.to_dev(np.ascontiguousarray(loff, np.int64)), self.to_dev(np.ascontiguousarray(roff, np.int64))
+        d_nf, d_oo = self.to_dev(nframes), self.to_dev(out_off)
+        check(self.lib.ira_diffusion_stereo(_ptr(x_dev), _ptr(d_lo), _ptr(d_ro), _ptr(d_nf), n, int(nframes.max()),
+                                            int(win), int(hop), int(max_lag), _ptr(c0), _ptr(ia), _ptr(d_oo),
+                                            self.stream), "ira_diffusion_stereo")
+        return c0, ia, out_off
+
     def group_delay(self, phase64_dev, off: np.ndarray, n_fft: np.ndarray, bin_step: np.ndarray, sample_rate_hz: float):
         """-numpy.gradient(phase, w) on the rad/sample axis of an n_fft-point rFFT (see ira_group_delay)."""
         t = self.torch

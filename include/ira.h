@@ -246,6 +246,28 @@ int32_t ira_fir_numerator(const double* coeffs_dev, int32_t order, const float* 
                           const int64_t* xoff_dev, const int32_t* len_dev, const double* divisor_dev,
                           int32_t nb, int32_t zero_order, double* b_dev, void* stream);
 
+/* ---- Section 8f: diffusion / decorrelation per time window ----------------------------------------------------------
+ * Element e: float32 signal at x_dev + xoff_dev[e] (already trimmed), nframes_dev[e] windows of `win` samples every
+ * `hop` (16 <= win <= 8192, 1 <= max_lag <= 4096).  Per window, with w0 = w - mean(w) in float32 exactly as numpy
+ * computes it (pairwise float32 sum):
+ *   ac[e][f] = max_{lag=1..min(max_lag, win-2)} |sum_k w0[k] w0[k+lag]| / sum w0^2     (NaN if the energy <= 1e-20)
+ *   ed[e][f] = fraction(|w0| > float32(thr_rms * rms)) [/ gauss_expected if gauss_expected >= 0], rms = float32
+ *              sqrt(mean(w0*w0));  NaN if rms <= 1e-20 or 0 <= gauss_expected <= 1e-12.
+ * Outputs float32 at out_off_dev[e] + f.  Replaces _windowed_max_abs_autocorr / _windowed_echo_density and the frame
+ * loop of analyse_diffusion_for_channel, reference analyse/diffusion.py:139-159, :205-226, :264-276. */
+int32_t ira_diffusion(const float* x_dev, const int64_t* xoff_dev, const int32_t* nframes_dev, int32_t nb,
+                      int32_t max_frames, int32_t win, int32_t hop, int32_t max_lag, double thr_rms,
+                      double gauss_expected, float* ac_dev, float* ed_dev, const int64_t* out_off_dev,
+                      void* stream);
+
+/* Stereo pair per element (left at loff_dev[e], right at roff_dev[e], same geometry): zero-lag Pearson correlation
+ * and max |normalised cross-correlation| over lags -max_lag..+max_lag per window.  Replaces _windowed_corr0 /
+ * _windowed_iacc_max and the frame loop of reference analyse/diffusion.py:162-202, :346-358. */
+int32_t ira_diffusion_stereo(const float* x_dev, const int64_t* loff_dev, const int64_t* roff_dev,
+                             const int32_t* nframes_dev, int32_t nb, int32_t max_frames, int32_t win, int32_t hop,
+                             int32_t max_lag, float* corr0_dev, float* iacc_dev, const int64_t* out_off_dev,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif
