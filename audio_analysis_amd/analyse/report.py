@@ -7,8 +7,8 @@ reference's hard-coded _left/_right links and the un-suffixed group-delay link),
 header block.  Differences, all outside the accelerated path:
   * the WAV is read ONCE and uploaded ONCE; every block runs on that one device-resident batch (the reference
     re-reads and re-converts the file ten times);
-  * the impulse-response plots, group delay and diffusion blocks ("next" rows
-    of section 8f) are not implemented: when requested they are skipped and listed at the end of the Markdown;
+  * the impulse-response waveform plots are not implemented: when requested they are
+    skipped and listed at the end of the Markdown.  Group delay and diffusion (section 8f rows) run on the GPU;
   * `render_plots=False` (extra field, default True) skips the CPU-side PNG rendering.
 """
 from __future__ import annotations
@@ -20,7 +20,9 @@ from typing import Any, Dict, List, Optional
 
 from ..engine import get_engine
 from . import decay as _decay
+from . import diffusion as _diff
 from . import frequency_response as _fr
+from . import group_delay as _gd
 from . import modalcloud as _modal
 from . import plotting
 from . import rt60bands as _bands
@@ -28,7 +30,9 @@ from . import spectrogram as _spec
 from . import waterfall as _wf
 from .io import DEFAULT_EXPECTED_SAMPLE_RATE_HZ, get_analysis_channels, load_wav_file
 from .decay import DecayAnalysisSettings, DecayPlotSettings
+from .diffusion import DiffusionAnalysisSettings
 from .frequency_response import FrequencyResponseAnalysisSettings, FrequencyResponsePlotSettings
+from .group_delay import GroupDelayAnalysisSettings, GroupDelayPlotSettings
 from .modalcloud import ModalCloudAnalysisSettings, ModalCloudPlotSettings
 from .rt60bands import Rt60BandsAnalysisSettings, Rt60BandsPlotSettings
 from .spectrogram import SpectrogramAnalysisSettings, SpectrogramPlotSettings
@@ -143,6 +147,7 @@ def run_report_from_wav_file(
     header_view = loaded.samples if loaded.samples.shape[1] == 2 else loaded.samples.repeat(2, axis=1)
     eng = get_engine()
     views: Dict[bool, Any] = {}
+    host_channels: Dict[bool, Any] = {}
 
     def view(mono_downmix: bool):
         """(channel names, device batch) for a channel policy; built once per policy."""
@@ -150,6 +155,7 @@ def run_report_from_wav_file(
         if key not in views:
             ch = get_analysis_channels(loaded, key)
             views[key] = ([n for n, _ in ch], eng.upload([c for _, c in ch]))
+            host_channels[key] = [c for _, c in ch]
         return views[key]
 
     names, batch = view(settings.common_use_mono_downmix_for_stereo)
@@ -200,7 +206,16 @@ def run_report_from_wav_file(
                _code(_fr.summarise_frequency_response_results_text(res))]
 
     if settings.run_group_delay:
-        skipped.append("group delay")
+        s = _apply_common_overrides(settings.group_delay_analysis_settings or GroupDelayAnalysisSettings(), settings)
+        g_names, g_batch = view(s.use_mono_downmix_for_stereo)
+        res = _gd.group_delay_results(_gd.group_delay_device(eng, g_batch, sr, s), sr, g_names, s)
+        if draw:
+            ps = settings.group_delay_plot_settings or GroupDelayPlotSettings()
+            for r in res:
+                plotting.render_group_delay(r, s, ps, f"Group delay ({r.channel_name})",
+                                            plotting.png_path(base, f"_groupdelay_{r.channel_name}"), show)
+        md += [_section("Group delay"), _image(base, "_groupdelay", "Group delay vs frequency"),
+               _code(_gd.summarise_group_delay_results_text(res))]
 
     mono_mix = settings.common_use_mono_downmix_for_stereo
     if settings.run_spectrogram:
@@ -230,7 +245,20 @@ def run_report_from_wav_file(
         md.append(_code(_wf.summarise_waterfall_results_text(res)))
 
     if settings.run_diffusion:
-        skipped.append("diffusion / echo density proxy")
+        s = _apply_common_overrides(settings.diffusion_analysis_settings
+                                    or DiffusionAnalysisSettings(hop_seconds=0.05, max_lag_milliseconds=5.0), settings)
+        d_names, d_batch = view(s.use_mono_downmix_for_stereo)
+        res = _diff.diffusion_results(_diff.diffusion_device(eng, d_batch, sr, s), sr, d_names)
+        hc = host_channels[bool(s.use_mono_downmix_for_stereo)]
+        if (not s.use_mono_downmix_for_stereo) and len(hc) == 2:
+            corr0, iacc = _diff.stereo_series(hc[0], hc[1], sr, s)
+            res = [_diff.DiffusionChannelResult(
+                channel_name=r.channel_name, sample_rate_hz=r.sample_rate_hz,
+                series=dataclasses.replace(r.series, corr0=corr0, iacc_max=iacc)) for r in res]
+        if draw:
+            plotting.render_diffusion(res, f"Diffusion — {wav}", plotting.png_path(base, "_diffusion"), show)
+        md += [_section("Diffusion / echo density proxy"), _image(base, "_diffusion", "Diffusion metrics over time"),
+               _code(_diff.summarise_diffusion_results_text(res))]
 
     if settings.run_modal_cloud:
         s = _apply_common_overrides(settings.modal_cloud_analysis_settings or ModalCloudAnalysisSettings(), settings)

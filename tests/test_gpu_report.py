@@ -21,13 +21,17 @@ def _write(tmp_path, golden, name):
 
 
 @pytest.mark.parametrize("name,variant", [("stereo16", "default"), ("stereo16", "monomix"), ("mono16", "default"),
-                                          ("stereof32", "default"), ("stereof32", "monomix")])
+                                          ("stereof32", "default"), ("stereof32", "monomix"),
+                                          ("stereo16", "full"), ("stereo16", "fullmix"), ("mono16", "full")])
 def test_report_markdown_matches_reference(tmp_path, golden, name, variant):
+    """`full*` = the reference's literal default report minus the IR waveform plots: group delay and diffusion on."""
     from audio_analysis_amd.analyse import report as rp
     _, c, _ = golden
     wav = _write(tmp_path, golden, name)
-    kw = dict(run_impulse_response_plots=False, run_group_delay=False, run_diffusion=False, render_plots=False)
-    if variant == "monomix":
+    kw = dict(run_impulse_response_plots=False, render_plots=False)
+    if variant in ("default", "monomix"):
+        kw.update(run_group_delay=False, run_diffusion=False)
+    if variant in ("monomix", "fullmix"):
         kw.update(common_use_mono_downmix_for_stereo=True, common_ignore_leading_seconds=0.003)
     res = rp.run_report_from_wav_file(wav, tmp_path / f"out_{variant}" / "rep", rp.ReportSettings(**kw))
     want = c["report"][f"{name}/{variant}"]["markdown"].replace("{WAV}", str(wav))
@@ -39,8 +43,9 @@ def test_report_lists_skipped_blocks_and_renders_pngs(tmp_path, golden):
     from audio_analysis_amd.analyse import report as rp
     wav = _write(tmp_path, golden, "mono16")
     res = rp.run_report_from_wav_file(wav, tmp_path / "o" / "r", rp.ReportSettings(run_waterfall=False, run_modal_cloud=False))
-    assert "## Skipped blocks" in res.summary_markdown and "group delay" in res.summary_markdown
-    for suffix in ("_decay", "_rt60bands", "_fr", "_spectrogram_mono"):
+    assert "## Skipped blocks" in res.summary_markdown and "impulse response plots" in res.summary_markdown
+    assert "## Group delay" in res.summary_markdown and "## Diffusion / echo density proxy" in res.summary_markdown
+    for suffix in ("_decay", "_rt60bands", "_fr", "_spectrogram_mono", "_groupdelay_mono", "_diffusion"):
         assert (tmp_path / "o" / f"r{suffix}.png").stat().st_size > 1000
 
 
