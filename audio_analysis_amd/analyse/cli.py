@@ -5,7 +5,7 @@ analyse/cli.py (:110-1186 parser, :1210-1662 dispatch) for the commands on the a
 zplane, bundle, decay, rt60bands, fr, filter, spectrogram, waterfall, modalcloud, report.
 The reference's inconsistent spellings are kept verbatim (--no_show vs --no-show, --ignore-leading vs
 --ignore_leading_seconds, rt60bands --trim_to_peak being store_true with default True).
-ir / groupdelay / diffusion / deconvolve are outside the accelerated path and exit with a message.
+ir / deconvolve are outside the accelerated path and exit with a message.
 
 The parser is table driven: one row per flag.
 """
@@ -47,6 +47,18 @@ COMMANDS = {
         I("--ar-order", 256, dest="ar_order"), ("--zeros", dict(dest="derive_zeros", action="store_true")),
         I("--zero-order", 64, dest="zero_order"), F("--radius", 1.2, dest="limit_radius"),
         F("--ridge", 0.0, dest="ridge_lambda"),
+    ],
+    "groupdelay": [
+        INPUT, OUTPUT, ("--no-show", dict(dest="no_show", action="store_true")),
+        ("--mono", dict(dest="use_mono_downmix_for_stereo", action="store_true")),
+        ("--no-trim", dict(dest="trim_to_peak", action="store_false")), IGNORE, DURATION,
+        I("--fft", None, dest="fft_size"), I("--smooth", 0, dest="smoothing_bins"),
+        F("--fmin", 20.0, dest="f_min_hz"), F("--fmax", 20000.0, dest="f_max_hz"),
+    ],
+    "diffusion": [
+        INPUT, OUTPUT, NO_SHOW, MONO, TRIM, IGNORE, F("--window_seconds", 0.05), F("--hop_seconds", 0.01),
+        F("--max_lag_milliseconds", 10.0), F("--echo_density_threshold_rms", 1.0),
+        ("--echo_density_normalise_to_gaussian", dict(action=BOOL, default=True)),
     ],
     "bundle": [("--input", dict(dest="bundle_root", type=str, required=True)),
                S("--reports-subdir", "reports", dest="reports_subdir")],
@@ -100,7 +112,7 @@ COMMANDS = {
          for k in ("ir", "decay", "rt60bands", "fr", "gd", "spectrogram", "waterfall", "diffusion", "modalcloud",
                    "echodensity")],
 }
-OUT_OF_SCOPE = ("ir", "groupdelay", "diffusion", "deconvolve")
+OUT_OF_SCOPE = ("ir", "deconvolve")
 
 
 def build_parser() -> argparse.ArgumentParser:
@@ -240,6 +252,27 @@ def main(argv=None) -> None:
         r = plot_zplane_from_wav_file(str(a.input_wav_file_path), s, ZPlanePlotSettings(limit_radius=float(a.limit_radius)),
                                       _basename(a), not bool(a.no_show))
         print(summarise_zplane_results_text(r))
+    elif cmd == "groupdelay":
+        from .group_delay import (GroupDelayAnalysisSettings, GroupDelayPlotSettings, plot_group_delay_from_wav_file,
+                                  summarise_group_delay_results_text)
+        s = GroupDelayAnalysisSettings(
+            use_mono_downmix_for_stereo=bool(a.use_mono_downmix_for_stereo), trim_to_peak=bool(a.trim_to_peak),
+            ignore_leading_seconds=float(a.ignore_leading_seconds), analysis_duration_seconds=a.analysis_duration_seconds,
+            fft_size=a.fft_size, smoothing_bins=int(a.smoothing_bins), f_min_hz=float(a.f_min_hz),
+            f_max_hz=float(a.f_max_hz))
+        r = plot_group_delay_from_wav_file(str(a.input_wav_file_path), s, GroupDelayPlotSettings(), _basename(a),
+                                           not bool(a.no_show))
+        print(summarise_group_delay_results_text(r))
+    elif cmd == "diffusion":
+        from .diffusion import DiffusionAnalysisSettings, plot_diffusion_from_wav_file, summarise_diffusion_results_text
+        s = DiffusionAnalysisSettings(
+            use_mono_downmix_for_stereo=bool(a.use_mono_downmix), trim_to_peak=bool(a.trim_to_peak),
+            ignore_leading_seconds=float(a.ignore_leading_seconds), window_seconds=float(a.window_seconds),
+            hop_seconds=float(a.hop_seconds), max_lag_milliseconds=float(a.max_lag_milliseconds),
+            echo_density_threshold_rms=float(a.echo_density_threshold_rms),
+            echo_density_normalise_to_gaussian=bool(a.echo_density_normalise_to_gaussian))
+        r = plot_diffusion_from_wav_file(str(a.input_wav_file_path), s, _basename(a), not bool(a.no_show))
+        print(summarise_diffusion_results_text(r))
     elif cmd == "report":
         from .report import ReportSettings, run_report_from_wav_file
         rs = ReportSettings(

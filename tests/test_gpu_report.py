@@ -59,6 +59,10 @@ def test_zplane_and_filter_commands_match_reference(tmp_path, golden, capsys):
     cli.main(["filter", "--input", str(wav), "--no_show"])
     out = capsys.readouterr().out
     assert out.strip() == c["report"]["stereo16/filter"]["summary"]
+    cli.main(["groupdelay", "--input", str(wav), "--no-show"])
+    assert capsys.readouterr().out.strip() == c["report"]["stereo16/groupdelay"]["summary"]
+    cli.main(["diffusion", "--input", str(wav), "--no_show"])
+    assert capsys.readouterr().out.strip() == c["report"]["stereo16/diffusion"]["summary"]
     cli.main(["decay", "--input", str(wav), "--no_show"])          # CLI default: compute_edt=True
     out = capsys.readouterr().out
     assert "[left] analysis_start_sample_index=245" in out and "EDT:" in out

@@ -164,7 +164,8 @@ def test_summaries_format_without_gpu(golden):
 
 
 # ---------------------------------------------------------------------------------------- CLI surface
-IN_SCOPE = ("zplane", "bundle", "decay", "rt60bands", "fr", "filter", "spectrogram", "waterfall", "modalcloud", "report")
+IN_SCOPE = ("zplane", "bundle", "decay", "rt60bands", "fr", "filter", "spectrogram", "waterfall", "modalcloud", "report",
+            "groupdelay", "diffusion")
 
 
 def test_cli_surface_matches_reference(golden):
@@ -187,7 +188,7 @@ def test_cli_surface_matches_reference(golden):
             assert bool(act.required) == r["required"]
             assert (list(act.choices) if act.choices else None) == r["choices"]
             assert getattr(act.type, "__name__", None) == r["type"]
-    for name in ("ir", "groupdelay", "diffusion", "deconvolve"):
+    for name in ("ir", "deconvolve"):
         with pytest.raises(SystemExit):
             cli.main([name])
 
