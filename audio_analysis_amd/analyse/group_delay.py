@@ -106,6 +106,72 @@ def group_delay_device(eng, batch, sample_rate_hz: int, settings: GroupDelayAnal
     return dict(gd=gd, off=off, n_fft=n_fft, starts=starts, lens=lens)
 
 
+_MASK_CACHE: dict = {}
+
+
+def mask_range(n_fft: int, sample_rate_hz: int, f_min_hz: float, f_max_hz: float) -> Tuple[int, int]:
+    """(first bin, count) of the contiguous run selected by (freq >= f_min) & (freq <= f_max) on rfftfreq(n_fft)."""
+    key = (int(n_fft), int(sample_rate_hz), float(f_min_hz), float(f_max_hz))
+    if key not in _MASK_CACHE:
+        freq = np.fft.rfftfreq(int(n_fft), d=1.0 / float(sample_rate_hz))
+        idx = np.nonzero((freq >= float(f_min_hz)) & (freq <= float(f_max_hz)))[0]
+        _MASK_CACHE[key] = (int(idx[0]), int(idx.size)) if idx.size else (0, 0)
+    return _MASK_CACHE[key]
+
+
+def _lerp(a: float, b: float, t: float) -> float:
+    """numpy's interpolation between neighbouring order statistics (numpy/lib/_function_base_impl.py, _lerp)."""
+    d = np.float64(b) - np.float64(a)
+    if t >= 0.5:
+        return float(np.float64(b) - d * (1.0 - t))
+    return float(np.float64(a) + d * t)
+
+
+def quantile_ranks(m: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Ranks (6,) and interpolation weights for [median lo, median hi, p10 lo, p10 hi, p90 lo, p90 hi] of m values,
+    following numpy.median (mean of the two middle values) and numpy.percentile(method='linear')."""
+    ranks = np.zeros(6, dtype=np.int64)
+    gam = np.zeros(3, dtype=np.float64)
+    if m > 0:
+        ranks[0], ranks[1] = (m - 1) // 2, m // 2
+        for j, pct in enumerate((10, 90)):
+            virt = (m - 1) * np.true_divide(pct, 100)
+            prev = np.floor(virt)
+            ranks[2 + 2 * j] = int(prev)
+            ranks[3 + 2 * j] = min(int(prev) + 1, m - 1)
+            gam[1 + j] = virt - prev
+    return ranks, gam
+
+
+def summary_statistics_device(eng, dev, sample_rate_hz: int, settings: GroupDelayAnalysisSettings):
+    """(median, p10, p90) of the masked group delay per channel WITHOUT bringing the curves to the host: the six order
+    statistics come from ira_order_stats; returns (HostFuture of (n, 6) values, gammas (n, 3), counts (n,))."""
+    if settings.smoothing_bins and settings.smoothing_bins > 1:
+        raise ValueError("device-side group-delay statistics do not cover the optional smoothing; use the host path.")
+    n = int(dev["n_fft"].size)
+    off = np.empty(n, dtype=np.int64); cnt = np.empty(n, dtype=np.int32)
+    ranks = np.zeros((n, 6), dtype=np.int64); gam = np.zeros((n, 3), dtype=np.float64)
+    for i in range(n):
+        k0, m = mask_range(int(dev["n_fft"][i]), sample_rate_hz, settings.f_min_hz, settings.f_max_hz)
+        off[i], cnt[i] = int(dev["off"][i]) + k0, m
+        ranks[i], gam[i] = quantile_ranks(m)
+    stats = eng.order_stats(dev["gd"], off, cnt, ranks)
+    return eng.fetch(stats), gam, cnt
+
+
+def finish_summary_statistics(values: np.ndarray, gam: np.ndarray, cnt: np.ndarray) -> np.ndarray:
+    """(n, 3) float64 [median, p10, p90] from the order statistics; NaN rows where the mask selected nothing."""
+    out = np.full((values.shape[0], 3), np.nan)
+    for i in range(values.shape[0]):
+        if cnt[i] <= 0:
+            continue
+        v = values[i]
+        out[i, 0] = float(v[0]) if cnt[i] % 2 == 1 else float(np.mean(np.array([v[0], v[1]])))
+        out[i, 1] = _lerp(v[2], v[3], gam[i, 1])
+        out[i, 2] = _lerp(v[4], v[5], gam[i, 2])
+    return out
+
+
 def group_delay_results(dev, sample_rate_hz: int, channel_names: Sequence[str],
                         settings: GroupDelayAnalysisSettings, gd_host: Optional[np.ndarray] = None):
     host = dev["gd"].cpu().numpy() if gd_host is None else gd_host

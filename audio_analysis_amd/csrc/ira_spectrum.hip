@@ -174,6 +174,107 @@ __global__ void gd_gradient_kernel(const double* __restrict__ phase, const int64
   o[i] = -g;
 }
 
+// ---- order statistics (numpy.median / numpy.percentile need the k-th smallest of ~1e5..1e6 float64 values) -----------
+// MSB-first radix select on the order-preserving uint64 image of the doubles, eight 8-bit digits, up to OS_MAX_RANKS
+// ranks per segment in one sweep: every pass histograms the next digit of the values that still match each rank's
+// prefix, then each rank descends into the bucket holding it.  One workgroup per segment; the data (<= a few MB)
+// stays in L2 across the eight passes.  -0.0 sorts before +0.0 and NaNs sort last (numpy would propagate NaN; group
+// delay has none).
+constexpr int OS_THREADS = 1024;
+constexpr int OS_MAX_RANKS = 8;
+
+__device__ __forceinline__ unsigned long long os_key(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double os_unkey(unsigned long long k) {
+  const unsigned long long u = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+  return __longlong_as_double((long long)u);
+}
+
+__global__ __launch_bounds__(OS_THREADS) void order_stats_kernel(const double* __restrict__ values,
+                                                                 const int64_t* __restrict__ off,
+                                                                 const int32_t* __restrict__ count,
+                                                                 const int64_t* __restrict__ ranks, int nranks,
+                                                                 double* __restrict__ out) {
+  __shared__ unsigned int hist[OS_MAX_RANKS][256];
+  __shared__ unsigned long long prefix[OS_MAX_RANKS];
+  __shared__ long long remaining[OS_MAX_RANKS];
+  const int e = blockIdx.x, tid = threadIdx.x;
+  const long long n = count[e];
+  const double* v = values + off[e];
+  double* o = out + (long long)e * nranks;
+  if (n <= 0) {
+    if (tid < nranks) o[tid] = __longlong_as_double(0x7ff8000000000000ll);
+    return;
+  }
+  if (tid < nranks) {
+    prefix[tid] = 0ull;
+    long long r = ranks[(long long)e * nranks + tid];
+    remaining[tid] = r < 0 ? 0 : (r > n - 1 ? n - 1 : r);
+  }
+  __shared__ int leader[OS_MAX_RANKS];
+  const int lane = tid & 63;
+  for (int pass = 0; pass < 8; ++pass) {
+    const int shift = 56 - 8 * pass;
+    for (int i = tid; i < nranks * 256; i += OS_THREADS) hist[i >> 8][i & 255] = 0u;
+    if (tid == 0) {
+      // ranks that still share a prefix (all of them in the first passes) share one histogram
+      for (int r = 0; r < nranks; ++r) {
+        int l = r;
+        for (int q = 0; q < r; ++q)
+          if (prefix[q] == prefix[r]) { l = q; break; }
+        leader[r] = l;
+      }
+    }
+    __syncthreads();
+    unsigned long long pf[OS_MAX_RANKS];
+    bool lead[OS_MAX_RANKS];
+#pragma unroll
+    for (int r = 0; r < OS_MAX_RANKS; ++r) {
+      pf[r] = r < nranks ? prefix[r] : 0ull;
+      lead[r] = r < nranks && leader[r] == r;
+    }
+    const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
+    // uniform trip count (ballots below need every lane of the wave in the loop)
+    const long long trips = (n + OS_THREADS - 1) / OS_THREADS;
+    for (long long it = 0; it < trips; ++it) {
+      const long long i = it * OS_THREADS + tid;
+      const bool valid = i < n;
+      const unsigned long long k = valid ? os_key(v[i]) : 0ull;
+      const unsigned int digit = (unsigned int)(k >> shift) & 255u;
+#pragma unroll
+      for (int r = 0; r < OS_MAX_RANKS; ++r) {
+        if (!lead[r]) continue;                                      // wave-uniform
+        const bool m = valid && (k & himask) == pf[r];
+        const unsigned long long act = __ballot(m);
+        if (act == 0ull) continue;
+        // the early digits are the same for almost every value (sign / exponent): one atomic for the whole group
+        const int first = __ffsll((long long)act) - 1;
+        const unsigned int d0 = (unsigned int)__shfl((int)digit, first, 64);
+        const unsigned long long same = __ballot(m && digit == d0);
+        if (lane == first) atomicAdd(&hist[r][d0], (unsigned int)__popcll(same));
+        if (m && digit != d0) atomicAdd(&hist[r][digit], 1u);
+      }
+    }
+    __syncthreads();
+    if (tid < nranks) {
+      long long rem = remaining[tid];
+      const int l = leader[tid];
+      unsigned int d = 0;
+      for (; d < 255; ++d) {
+        const long long c = hist[l][d];
+        if (rem < c) break;
+        rem -= c;
+      }
+      remaining[tid] = rem;
+      prefix[tid] = prefix[tid] | ((unsigned long long)d << shift);
+    }
+    __syncthreads();
+  }
+  if (tid < nranks) o[tid] = os_unkey(prefix[tid]);
+}
+
 // ---- summary statistics ------------------------------------------------------------------------------------------
 // out record (8 doubles): [0] bins in range [1] peak bin (absolute index) [2] peak frequency (float32 value)
 // [3] sum(f*lin) [4] sum(lin) [5] first in-range frequency [6] index nearest 1 kHz [7] magnitude_db there
@@ -307,5 +408,17 @@ extern "C" int32_t ira_spectrum_stats(const float* mag_db_dev, const int64_t* ma
   if (nb <= 0) return nb == 0 ? IRA_OK : IRA_E_SIZE;
   stats_kernel<<<nb, ST_THREADS, 0, (hipStream_t)stream>>>(mag_db_dev, mag_off_dev, L_dev, freq_val_dev,
                                                            (float)f_min_hz, (float)f_max_hz, (float)probe_hz, out_dev);
+  IRA_RETURN_LAUNCH();
+}
+
+extern "C" int32_t ira_order_stats(const double* values_dev, const int64_t* off_dev, const int32_t* count_dev,
+                                   int32_t nseg, const int64_t* ranks_dev, int32_t nranks, double* out_dev,
+                                   void* stream) {
+  IRA_CHECK_PTR(values_dev); IRA_CHECK_PTR(off_dev); IRA_CHECK_PTR(count_dev); IRA_CHECK_PTR(ranks_dev);
+  IRA_CHECK_PTR(out_dev);
+  if (nranks < 1 || nranks > OS_MAX_RANKS) return IRA_E_SIZE;
+  if (nseg <= 0) return nseg == 0 ? IRA_OK : IRA_E_SIZE;
+  order_stats_kernel<<<nseg, OS_THREADS, 0, (hipStream_t)stream>>>(values_dev, off_dev, count_dev, ranks_dev, nranks,
+                                                                    out_dev);
   IRA_RETURN_LAUNCH();
 }

@@ -574,6 +574,18 @@ class Engine:
                                         _ptr(out) if as_float64 else 0, self.stream), "ira_phase_unwrap")
         return out
 
+    def order_stats(self, values_dev, off: np.ndarray, count: np.ndarray, ranks: np.ndarray):
+        """sorted(segment)[rank] for every (segment, rank): float64 device tensor (nseg, nranks); ranks is (nseg, nranks)."""
+        t = self.torch
+        ranks = np.ascontiguousarray(ranks, dtype=np.int64)
+        nseg, nr = ranks.shape
+        out = self.empty(nseg * nr, t.float64)
+        d_o, d_c = self.to_dev(np.ascontiguousarray(off, np.int64)), self.to_dev(np.ascontiguousarray(count, np.int32))
+        d_r = self.to_dev(ranks.reshape(-1))
+        check(self.lib.ira_order_stats(_ptr(values_dev), _ptr(d_o), _ptr(d_c), int(nseg), _ptr(d_r), int(nr), _ptr(out),
+                                       self.stream), "ira_order_stats")
+        return out[: nseg * nr].view(nseg, nr)
+
     def diffusion(self, x_dev, xoff: np.ndarray, nframes: np.ndarray, win: int, hop: int, max_lag: int,
                   thr_rms: float, gauss_expected: float):
         """Per-window max|autocorr| and echo density (float32 device, flat) + host offsets (see ira_diffusion)."""

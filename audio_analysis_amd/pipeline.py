@@ -18,6 +18,8 @@ from typing import Dict, List, Optional
 import numpy as np
 
 from .analyse import decay as _decay
+from .analyse import diffusion as _diff
+from .analyse import group_delay as _gd
 from .analyse import filterplot as _filter
 from .analyse import frequency_response as _fr
 from .analyse import modalcloud as _modal
@@ -37,6 +39,8 @@ M_SPEC_FRAMES, M_WF_SLICES, M_WF_BINS = 110, 111, 112
 M_MODAL_POINTS, M_MODAL_MEDIAN, M_MODAL_P90, M_MODAL_MAX = 113, 114, 115, 116
 M_AR_POLES, M_AR_MAX_R, M_AR_MEDIAN_R, M_AR_UNSTABLE = 117, 118, 119, 120
 M_NBANDS = 121
+M_GD_MEDIAN, M_GD_P10, M_GD_P90 = 122, 123, 124        # section 8f blocks (off by default)
+M_DIFF_AC_MEDIAN, M_DIFF_ED_MEDIAN = 125, 126
 METRICS_WIDTH = 128
 
 
@@ -51,6 +55,11 @@ class FullReportSettings:
     run_waterfall: bool = True
     run_modal_cloud: bool = True
     run_zplane: bool = True
+    # section 8f rows: default-on blocks of the reference's `report`, off in the headline metric
+    run_group_delay: bool = False
+    run_diffusion: bool = False
+    group_delay: _gd.GroupDelayAnalysisSettings = _gd.GroupDelayAnalysisSettings()
+    diffusion: _diff.DiffusionAnalysisSettings = _diff.DiffusionAnalysisSettings(hop_seconds=0.05, max_lag_milliseconds=5.0)
     decay: _decay.DecayAnalysisSettings = _decay.DecayAnalysisSettings()
     rt60_bands: _bands.Rt60BandsAnalysisSettings = _bands.Rt60BandsAnalysisSettings()
     frequency_response: _fr.FrequencyResponseAnalysisSettings = _fr.FrequencyResponseAnalysisSettings()
@@ -67,7 +76,9 @@ class FullReportSettings:
                             ("run_spectrogram", f"spectrogram[{self.spectrogram.n_fft}/{self.spectrogram.hop_length}]"),
                             ("run_waterfall", "waterfall"),
                             ("run_modal_cloud", f"modalcloud[{self.modal_cloud.n_fft}/{self.modal_cloud.hop_length}]"),
-                            ("run_zplane", f"zplane[ar{self.zplane.ar_order}]")):
+                            ("run_zplane", f"zplane[ar{self.zplane.ar_order}]"), ("run_group_delay", "groupdelay"),
+                            ("run_diffusion", f"diffusion[hop{self.diffusion.hop_seconds * 1e3:g}ms/lag"
+                                              f"{self.diffusion.max_lag_milliseconds:g}ms]")):
             if getattr(self, flag):
                 names.append(label)
         return names
@@ -151,6 +162,14 @@ class FullReport:
             fut["modal_fits"] = eng.fetch(mc["fits"])
         if s.run_zplane:
             res["zplane"] = dict(finish=_zp.zplane_device(eng, batch, sr, s.zplane, defer=True))
+        if s.run_group_delay:
+            gdev = _gd.group_delay_device(eng, batch, sr, s.group_delay)
+            res["groupdelay"] = gdev
+            fut["gd_stats"] = _gd.summary_statistics_device(eng, gdev, sr, s.group_delay)
+        if s.run_diffusion:
+            ddev = _diff.diffusion_device(eng, batch, sr, s.diffusion)
+            res["diffusion"] = ddev
+            fut["diff_ac"], fut["diff_ed"] = eng.fetch(ddev["ac"]), eng.fetch(ddev["ed"])
         done = t.cuda.Event()
         done.record(t.cuda.current_stream(eng.device))
         return dict(n=n, m=m, res=res, fut=fut, done=done, spectrum=spectrum, filt=filt)
@@ -215,5 +234,17 @@ class FullReport:
                     m[some, M_MODAL_MEDIAN] = np.nanmedian(rt[some], axis=1)
                     m[some, M_MODAL_P90] = np.nanpercentile(rt[some], 90, axis=1)
                     m[some, M_MODAL_MAX] = np.nanmax(rt[some], axis=1)
+        if s.run_group_delay:
+            vals, gam, cnt = fut["gd_stats"]
+            m[:, M_GD_MEDIAN : M_GD_P90 + 1] = _gd.finish_summary_statistics(vals.get(), gam, cnt)
+        if s.run_diffusion:
+            import warnings
+            ac, ed, dd = fut["diff_ac"].get(), fut["diff_ed"].get(), res["diffusion"]
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", category=RuntimeWarning)          # all-NaN series stay NaN
+                for i in range(n):
+                    o, f = int(dd["off"][i]), int(dd["frames"][i])
+                    m[i, M_DIFF_AC_MEDIAN] = float(np.nanmedian(ac[o : o + f]))
+                    m[i, M_DIFF_ED_MEDIAN] = float(np.nanmedian(ed[o : o + f]))
         self.device_results = res
         return m

@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="IRs per GPU per step")
     ap.add_argument("--seconds", type=float, default=10.0, help="IR length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--literal-steps", type=int, default=5,
+                    help="extra steps with the reference's default-on group-delay and diffusion blocks added "
+                         "(reported as literal_full_report; 0 = skip)")
     a = ap.parse_args()
 
     import numpy as np
@@ -112,16 +115,17 @@ def main():
     # Software pipeline over steps: step k+1 is ENQUEUED (FullReport.submit) before step k's results are read back
     # and gathered (FullReport.finish), so the GPU works on k+1 while the host post-processes k.  Every one of the
     # K timed steps is submitted, finished and gathered inside the timed region.
-    def run_steps(count):
+    def run_steps(count, rep=None):
+        rep = rep or report
         out, pending = None, None
         for _ in range(count):
             batch.peak = None                  # the peak pick is part of every step
-            h = report.submit(batch)
+            h = rep.submit(batch)
             if pending is not None:
-                out = D.gather_metrics(report.finish(pending), eng.device, eng.side_stream())
+                out = D.gather_metrics(rep.finish(pending), eng.device, eng.side_stream())
             pending = h
         if pending is not None:
-            out = D.gather_metrics(report.finish(pending), eng.device, eng.side_stream())
+            out = D.gather_metrics(rep.finish(pending), eng.device, eng.side_stream())
         return out
 
     run_steps(a.warmup)
@@ -133,6 +137,22 @@ def main():
     elapsed = D.max_over_ranks(time.perf_counter() - t0, eng.device)
     ev = eng.collect_events()
     eng.events = None
+
+    # ---- second, shorter measurement: the LITERAL default report (group delay + diffusion blocks added) ------------------
+    literal = None
+    if a.literal_steps > 0:
+        from dataclasses import replace as _replace
+        rep2 = FullReport(eng, _replace(settings, run_group_delay=True, run_diffusion=True))
+        run_steps(2, rep2)
+        D.barrier(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(a.literal_steps, rep2)
+        D.barrier(); torch.cuda.synchronize()
+        el2 = D.max_over_ranks(time.perf_counter() - t1, eng.device)
+        literal = {"value": a.batch * world * a.literal_steps / el2, "unit": "IRs/s", "steps": a.literal_steps,
+                   "ms_per_step": 1e3 * el2 / a.literal_steps, "blocks": rep2.s.blocks(),
+                   "note": "same step plus the reference's default-on group-delay and diffusion blocks (SURVEY.md 8f); "
+                           "only the IR waveform plots and PNG rendering remain excluded"}
 
     if rank != 0:
         return
@@ -225,6 +245,7 @@ def main():
         "roofline_stft": roof(stft_name) if stft_name else None,
         "device_ms_per_step_by_call": {k: v / a.steps for k, v in sorted(tot.items(), key=lambda kv: -kv[1])},
         "device_ms_per_step": dev_ms / a.steps,
+        "literal_full_report": literal,
     }
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.seconds)

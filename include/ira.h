@@ -246,6 +246,13 @@ int32_t ira_fir_numerator(const double* coeffs_dev, int32_t order, const float* 
                           const int64_t* xoff_dev, const int32_t* len_dev, const double* divisor_dev,
                           int32_t nb, int32_t zero_order, double* b_dev, void* stream);
 
+/* k-th smallest values (0-based ranks, clipped to the segment) of float64 segments values_dev + off_dev[e], count_dev[e]
+ * long: out_dev[e*nranks + j] = sorted(segment)[ranks_dev[e*nranks + j]], 1 <= nranks <= 8 (radix select, exact).
+ * The building block of numpy.median / numpy.percentile in summarise_group_delay_results_text, reference
+ * analyse/group_delay.py:209-220 (the interpolation between neighbouring ranks stays on the host). */
+int32_t ira_order_stats(const double* values_dev, const int64_t* off_dev, const int32_t* count_dev, int32_t nseg,
+                        const int64_t* ranks_dev, int32_t nranks, double* out_dev, void* stream);
+
 /* ---- Section 8f: diffusion / decorrelation per time window ----------------------------------------------------------
  * Element e: float32 signal at x_dev + xoff_dev[e] (already trimmed), nframes_dev[e] windows of `win` samples every
  * `hop` (16 <= win <= 8192, 1 <= max_lag <= 4096).  Per window, with w0 = w - mean(w) in float32 exactly as numpy

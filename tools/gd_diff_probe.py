@@ -11,7 +11,14 @@ eng = Engine("cuda:0"); n = 480000
 host = np.stack([synth_ir(i, 0, n) for i in range(B)])
 batch = eng.wrap(eng.to_dev(host.reshape(-1)), np.arange(B, dtype=np.int64) * n, np.full(B, n, np.int64))
 eng.peaks(batch)
+def gd_with_stats():
+    st = gdm.GroupDelayAnalysisSettings()
+    dev = gdm.group_delay_device(eng, batch, 48000, st)
+    return gdm.summary_statistics_device(eng, dev, 48000, st)
+
+
 for name, fn in (("group delay", lambda: gdm.group_delay_device(eng, batch, 48000, gdm.GroupDelayAnalysisSettings())),
+                 ("group delay + device quantiles", gd_with_stats),
                  ("diffusion (report defaults: hop 50 ms, lag 5 ms)", lambda: dm.diffusion_device(eng, batch, 48000, dm.DiffusionAnalysisSettings(hop_seconds=0.05, max_lag_milliseconds=5.0))),
                  ("diffusion (module defaults: hop 10 ms, lag 10 ms)", lambda: dm.diffusion_device(eng, batch, 48000, dm.DiffusionAnalysisSettings()))):
     for _ in range(2):
