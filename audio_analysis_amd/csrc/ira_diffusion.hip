@@ -146,7 +146,7 @@ __device__ __forceinline__ void lag_group(const double* cur, const double* lagsr
   for (int j = 0; j < LG; ++j) acc[j] = a[j];
 }
 
-// max over lags lag_lo..lag_hi of |sum_n cur[n] lagsrc[n-lag]| (all threads call; `red` holds nsub * 4 * ngroups doubles)
+// max over lags lag_lo..lag_hi of |sum_n cur[n] lagsrc[n-lag]| (all threads call; `red` holds nsub * LG * ngroups doubles)
 __device__ double max_abs_lag_sum(const double* cur, const double* lagsrc, int n, int lag_lo, int lag_hi, double* red,
                                   double* wave_max) {
   const int tid = threadIdx.x;

@@ -61,11 +61,8 @@ __device__ __forceinline__ cd unit_q(long long q, long long L) {
   return {c, -s};
 }
 
-// numpy.hanning(L)[i] = 0.5 + 0.5*cos(pi*(2i + 1 - L)/(L - 1)); hanning(1) = 1
-__device__ __forceinline__ double hann_at(long long i, long long L) {
-  if (L <= 1) return 1.0;
-  return 0.5 + 0.5 * cospi((double)(2 * i + 1 - L) / (double)(L - 1));
-}
+// numpy.hanning(L)[i] = 0.5 + 0.5*cos(pi*(2i + 1 - L)/(L - 1)), hanning(1) = 1: evaluated in cols_fwd_kernel as a rotation
+// along each thread's elements (exact sincospi start, then one complex multiply per element).
 
 // ---- band masks (reference rt60bands.py:116-167), float32 arithmetic on a float32 frequency axis ------------
 struct BandMask {
