@@ -31,6 +31,7 @@ SOURCES = {
     "ira_stft2.hip": ["-fno-slp-vectorize"],
     "ira_stft3.hip": ["-fno-slp-vectorize"],
     "ira_fftlong.hip": [],
+    "ira_fftsmooth.hip": [],
     "ira_spectrum.hip": ["-ffp-contract=off"],
     "ira_modal.hip": ["-ffp-contract=off"],
     "ira_ar.hip": [],

@@ -1,0 +1,497 @@
+// Direct float64 DFTs of SMOOTH lengths n = 2^a 3^b 5^c (e.g. 480 000 = 10 s at 48 kHz): a four-step n = N1 x N2
+// transform with mixed-radix (5, 4, 3, 2) Stockham sub-FFTs in LDS -- two passes over n complex values instead of
+// Bluestein's three passes over M = 2^ceil(log2(2n)) (ira_fftlong.hip), i.e. ~2.3x less memory traffic and ~4x fewer
+// flops for the RT60 filter bank (reference analyse/rt60bands.py:170-175) and every other whole-file transform whose
+// length happens to be smooth.  Same inputs, outputs and pairing conventions as the Bluestein entry points.
+//
+//   x[n1*N2 + n2]  --P1 (columns: N1-point FFT over n1, twiddle W_n^(k1 n2))-->  work[n2*N1 + k1]   (stored TRANSPOSED:
+//                     each workgroup owns C columns and writes C contiguous runs of N1 values)
+//   work           --P2 (N2-point FFT over n2 for C adjacent k1)-->  X[k1 + N1*k2]                  (runs of C values)
+// Inverse transforms run the same forward machinery on the conjugated input (conj(DFT(conj .)) / n).
+#include <cmath>
+#include <cstdlib>
+
+#include "ira_fft_reg.h"
+
+namespace {
+
+using ira::cplx;
+typedef cplx<double> cd;
+
+constexpr int SM_THREADS = 256;
+constexpr int SM_MAX_N = 1024;     // largest sub-transform (LDS: 2 buffers x C x N x 16 B)
+constexpr int SM_MAX_RADICES = 12;
+constexpr double kPiS = 3.14159265358979323846;
+
+struct SmoothPlan {
+  int n, n1, n2;
+  int c1, c2;                       // columns per workgroup in pass 1 / pass 2
+  int r1[SM_MAX_RADICES], nr1;      // radices of the N1-point transform
+  int r2[SM_MAX_RADICES], nr2;
+  const cd* t1;                     // exp(-2 pi i k / N1), k < N1
+  const cd* t2;                     // exp(-2 pi i k / N2), k < N2
+  const cd* tf;                     // exp(-2 pi i k / n),  k < N2
+};
+
+// ---- radix butterflies, forward sign (W = exp(-2 pi i / r)), natural order in and out, registers only -------------------
+__device__ __forceinline__ cd mul_mi(cd z) { return {z.im, -z.re}; }      // -i z
+
+template <int R>
+__device__ __forceinline__ void bfly(cd (&a)[R]);
+
+template <>
+__device__ __forceinline__ void bfly<2>(cd (&a)[2]) {
+  const cd t = a[1];
+  a[1] = ira::csub(a[0], t);
+  a[0] = ira::cadd(a[0], t);
+}
+template <>
+__device__ __forceinline__ void bfly<3>(cd (&a)[3]) {
+  const cd t1 = ira::cadd(a[1], a[2]);
+  const cd t2 = {a[0].re - 0.5 * t1.re, a[0].im - 0.5 * t1.im};
+  const cd d = ira::csub(a[1], a[2]);
+  const cd r = mul_mi(cd{0.86602540378443864676 * d.re, 0.86602540378443864676 * d.im});
+  a[0] = ira::cadd(a[0], t1);
+  a[1] = ira::cadd(t2, r);
+  a[2] = ira::csub(t2, r);
+}
+template <>
+__device__ __forceinline__ void bfly<4>(cd (&a)[4]) {
+  const cd p02 = ira::cadd(a[0], a[2]), m02 = ira::csub(a[0], a[2]);
+  const cd p13 = ira::cadd(a[1], a[3]), m13 = mul_mi(ira::csub(a[1], a[3]));
+  a[0] = ira::cadd(p02, p13);
+  a[2] = ira::csub(p02, p13);
+  a[1] = ira::cadd(m02, m13);
+  a[3] = ira::csub(m02, m13);
+}
+template <>
+__device__ __forceinline__ void bfly<5>(cd (&a)[5]) {
+  constexpr double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;
+  constexpr double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;
+  const cd t1 = ira::cadd(a[1], a[4]), t2 = ira::cadd(a[2], a[3]);
+  const cd t3 = ira::csub(a[1], a[4]), t4 = ira::csub(a[2], a[3]);
+  const cd m1 = {a[0].re + c1 * t1.re + c2 * t2.re, a[0].im + c1 * t1.im + c2 * t2.im};
+  const cd m2 = {a[0].re + c2 * t1.re + c1 * t2.re, a[0].im + c2 * t1.im + c1 * t2.im};
+  const cd n1 = mul_mi(cd{s1 * t3.re + s2 * t4.re, s1 * t3.im + s2 * t4.im});
+  const cd n2 = mul_mi(cd{s2 * t3.re - s1 * t4.re, s2 * t3.im - s1 * t4.im});
+  a[0] = {a[0].re + t1.re + t2.re, a[0].im + t1.im + t2.im};
+  a[1] = ira::cadd(m1, n1);
+  a[4] = ira::csub(m1, n1);
+  a[2] = ira::cadd(m2, n2);
+  a[3] = ira::csub(m2, n2);
+}
+// 6 = 2 x 3 (Cooley-Tukey inside the registers): n = 2a + b, k = k1 + 3 k2
+template <>
+__device__ __forceinline__ void bfly<6>(cd (&a)[6]) {
+  cd e[3] = {a[0], a[2], a[4]}, o[3] = {a[1], a[3], a[5]};
+  bfly<3>(e);
+  bfly<3>(o);
+  o[1] = ira::cmul(o[1], cd{0.5, -0.86602540378443864676});      // W6^1
+  o[2] = ira::cmul(o[2], cd{-0.5, -0.86602540378443864676});     // W6^2
+#pragma unroll
+  for (int k1 = 0; k1 < 3; ++k1) {
+    a[k1] = ira::cadd(e[k1], o[k1]);
+    a[k1 + 3] = ira::csub(e[k1], o[k1]);
+  }
+}
+// powers of two through the shared decimation-in-frequency kernel (it leaves X[k] in slot bitrev(k))
+template <>
+__device__ __forceinline__ void bfly<8>(cd (&a)[8]) {
+  ira::dft_dif<double, 8>(a);
+  cd t;
+  t = a[1]; a[1] = a[4]; a[4] = t;
+  t = a[3]; a[3] = a[6]; a[6] = t;
+}
+template <>
+__device__ __forceinline__ void bfly<16>(cd (&a)[16]) {
+  ira::dft_dif<double, 16>(a);
+  cd t;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int j = ira::brev_bits(i, 4);
+    if (j > i) { t = a[i]; a[i] = a[j]; a[j] = t; }
+  }
+}
+
+// One Stockham pass of radix R on sub-length m*R with stride s (= product of the previous radices), nbat transforms:
+//   y[q + s (R p + k)] = W_N^(s p k) * sum_j x[q + s (p + m j)] W_R^(j k),   p < m, q < s.
+// p = bf / s by a multiply-high with magic = floor(2^32 / s) + 1 (exact for bf < 2^16); the R-1 twiddles of a butterfly
+// are powers of ONE table value.
+template <int R>
+__device__ __forceinline__ void stockham_pass(const cd* x, cd* y, int N, int m, int s, unsigned magic,
+                                              const cd* __restrict__ tw, int tid, int nbat) {
+  const int per = N / R;
+  for (int t = 0; t < nbat; ++t) {
+    const cd* xt = x + t * N;
+    cd* yt = y + t * N;
+    for (int bf = tid; bf < per; bf += SM_THREADS) {
+      const int p = s == 1 ? bf : (int)__umulhi((unsigned)bf, magic);
+      const int q = bf - p * s;
+      cd v[R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) v[j] = xt[bf + s * m * j];           // q + s p = bf
+      bfly<R>(v);
+      cd* yo = yt + q + s * R * p;
+      yo[0] = v[0];
+      if (p == 0) {
+#pragma unroll
+        for (int k = 1; k < R; ++k) yo[s * k] = v[k];
+      } else {
+        const cd w1 = tw[s * p];                                         // W_N^(s p), s p < N / R
+        cd w = w1;
+#pragma unroll
+        for (int k = 1; k < R; ++k) {
+          yo[s * k] = ira::cmul(v[k], w);
+          if (k + 1 < R) w = ira::cmul(w, w1);
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// Stockham autosort FFT of `nbat` transforms of N points each (buffers a/b, transform t at offset t*N), natural order in,
+// natural order out.  Returns the buffer holding the result.  All threads call.
+__device__ cd* lds_fft_stockham(cd* a, cd* b, int N, const int* radices, int nrad, const cd* __restrict__ tw, int tid,
+                                int nbat) {
+  int s = 1, len = N;
+  cd* x = a;
+  cd* y = b;
+  for (int pass = 0; pass < nrad; ++pass) {
+    const int r = radices[pass];
+    const int m = len / r;
+    const unsigned magic = (unsigned)(0x100000000ull / (unsigned)s) + 1u;
+    switch (r) {
+      case 16: stockham_pass<16>(x, y, N, m, s, magic, tw, tid, nbat); break;
+      case 8: stockham_pass<8>(x, y, N, m, s, magic, tw, tid, nbat); break;
+      case 6: stockham_pass<6>(x, y, N, m, s, magic, tw, tid, nbat); break;
+      case 5: stockham_pass<5>(x, y, N, m, s, magic, tw, tid, nbat); break;
+      case 4: stockham_pass<4>(x, y, N, m, s, magic, tw, tid, nbat); break;
+      case 3: stockham_pass<3>(x, y, N, m, s, magic, tw, tid, nbat); break;
+      default: stockham_pass<2>(x, y, N, m, s, magic, tw, tid, nbat); break;
+    }
+    cd* tmp = x; x = y; y = tmp;
+    s *= r;
+    len = m;
+  }
+  return x;
+}
+
+// W_n^p for p < n = N1*N2 as a coarse (N1 entries) times a fine (N2 entries) table value.
+__device__ __forceinline__ cd twiddle_n(const SmoothPlan& P, unsigned p) {      // p < n <= 2^20
+  const unsigned hi = p / (unsigned)P.n2, lo = p - hi * (unsigned)P.n2;
+  return ira::cmul(P.t1[hi], P.tf[lo]);
+}
+
+// ---- band masks: same float32 arithmetic as ira_fftlong.hip (reference rt60bands.py:116-167) ------------------------
+struct BandMaskS { double kind, hp_x0, hp_x1, lp_x0, lp_x1, pad0, pad1, pad2; };
+
+__device__ __forceinline__ float ramp_s(float f, double x0, double x1) {
+  if (x1 <= x0) return f >= (float)x1 ? 1.0f : 0.0f;
+  float t = (f - (float)x0) / (float)(x1 - x0);
+  t = fminf(fmaxf(t, 0.0f), 1.0f);
+  if (t <= 0.0f) return 0.0f;
+  if (t >= 1.0f) return 1.0f;
+  const float arg = (float)kPiS * t;
+  return 0.5f - 0.5f * (float)cos((double)arg);
+}
+__device__ __forceinline__ float lowpass_s(float f, double pass, double stop) {
+  float m = 1.0f - ramp_s(f, pass, stop);
+  if (f <= (float)pass) m = 1.0f;
+  if (f >= (float)stop) m = 0.0f;
+  return m;
+}
+__device__ __forceinline__ float highpass_s(float f, double stop, double pass) {
+  float m = ramp_s(f, stop, pass);
+  if (f <= (float)stop) m = 0.0f;
+  if (f >= (float)pass) m = 1.0f;
+  return m;
+}
+__device__ __forceinline__ float mask_s(const BandMaskS& b, float f) {
+  const int kind = (int)b.kind;
+  if (kind == 1) return lowpass_s(f, b.lp_x0, b.lp_x1);
+  if (kind == 2) return highpass_s(f, b.hp_x0, b.hp_x1);
+  if (kind == 3) return highpass_s(f, b.hp_x0, b.hp_x1) * lowpass_s(f, b.lp_x0, b.lp_x1);
+  return 0.0f;
+}
+
+struct SJobs {
+  // forward: one or two real signals per job
+  const float* x;
+  const int64_t* xoff;
+  const int64_t* x2off;          // null or -1: single
+  int use_hann;
+  const int32_t* data_len; const int32_t* win_len; const int32_t* data_len2; const int32_t* win_len2;   // optional
+  cd* spec_out;
+  const int64_t* spec_off; const int64_t* spec_off2;
+  cd* zpair; const int64_t* zpair_off;
+  // inverse: masked spectra -> band signals
+  const cd* spec;
+  const int64_t* sp_off; const int64_t* sp_off2;
+  const BandMaskS* bands;
+  const double* freq_val;
+  float* y;
+  const int64_t* y1_off; const int64_t* y2_off;
+};
+
+enum { SM_SIGNAL = 0, SM_SPECTRUM = 1 };
+enum { SM_OUT_SPEC = 0, SM_OUT_BANDS = 1 };
+
+__device__ __forceinline__ double hann_s(long long i, long long L) {
+  if (L <= 1) return 1.0;
+  return 0.5 + 0.5 * cospi((double)(2 * i + 1 - L) / (double)(L - 1));
+}
+
+template <int MODE>
+__device__ __forceinline__ cd smooth_input(const SmoothPlan& P, const SJobs& J, int e, long long i) {
+  const long long n = P.n;
+  if (MODE == SM_SIGNAL) {
+    const long long nd1 = J.data_len ? (long long)J.data_len[e] : n;
+    const long long lw1 = J.win_len ? (long long)J.win_len[e] : n;
+    double v = i < nd1 ? (double)J.x[J.xoff[e] + i] : 0.0;
+    if (J.use_hann) v *= hann_s(i, lw1);
+    const long long o2 = J.x2off ? J.x2off[e] : -1;
+    double v2 = 0.0;
+    if (o2 >= 0) {
+      const long long nd2 = J.data_len2 ? (long long)J.data_len2[e] : nd1;
+      const long long lw2 = J.win_len2 ? (long long)J.win_len2[e] : lw1;
+      v2 = i < nd2 ? (double)J.x[o2 + i] : 0.0;
+      if (J.use_hann) v2 *= hann_s(i, lw2);
+    }
+    return {v, v2};
+  } else {
+    // conj of the Hermitian extension of X1 m1 + i X2 m2  (inverse = conj(DFT(conj .)) / n)
+    const bool upper = i > n / 2;
+    const long long k = upper ? n - i : i;
+    cd x1 = J.spec[J.sp_off[e] + k];
+    if (upper) x1.im = -x1.im;
+    const float f = (float)((double)k * J.freq_val[e]);
+    const double m1 = (double)mask_s(J.bands[2 * e], f);
+    const double m2 = (double)mask_s(J.bands[2 * e + 1], f);
+    cd w;
+    if (J.sp_off2 == nullptr || J.sp_off2[e] == J.sp_off[e]) {
+      w = ira::cmul(x1, cd{m1, m2});
+    } else {
+      cd x2 = J.spec[J.sp_off2[e] + k];
+      if (upper) x2.im = -x2.im;
+      w = {x1.re * m1 - x2.im * m2, x1.im * m1 + x2.re * m2};
+    }
+    return {w.re, -w.im};
+  }
+}
+
+// ---- pass 1: columns.  grid (N2 / C, jobs) ------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(SM_THREADS) void smooth_cols_kernel(SmoothPlan P, SJobs J, cd* __restrict__ work) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  cd* a = reinterpret_cast<cd*>(smem);
+  const int C = P.c1, N1 = P.n1, N2 = P.n2;
+  cd* b = a + (size_t)C * N1;
+  const int e = blockIdx.y, tid = threadIdx.x;
+  const int n2_0 = blockIdx.x * C;
+  for (int i = tid; i < N1 * C; i += SM_THREADS) {
+    const int c = i % C, n1 = i / C;
+    a[c * N1 + n1] = smooth_input<MODE>(P, J, e, (long long)n1 * N2 + n2_0 + c);
+  }
+  __syncthreads();
+  const cd* r = lds_fft_stockham(a, b, N1, P.r1, P.nr1, P.t1, tid, C);
+  cd* w = work + (long long)e * P.n;
+  for (int i = tid; i < N1 * C; i += SM_THREADS) {
+    const int c = i / N1, k1 = i - c * N1;
+    const int n2 = n2_0 + c;
+    w[(long long)n2 * N1 + k1] = ira::cmul(r[c * N1 + k1], twiddle_n(P, (unsigned)k1 * (unsigned)n2));
+  }
+}
+
+// ---- pass 2: N2-point transforms for C adjacent k1.  grid (N1 / C, jobs) --------------------------------------------------
+template <int OUT>
+__global__ __launch_bounds__(SM_THREADS) void smooth_rows_kernel(SmoothPlan P, SJobs J, const cd* __restrict__ work) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  cd* a = reinterpret_cast<cd*>(smem);
+  const int C = P.c2, N1 = P.n1, N2 = P.n2;
+  cd* b = a + (size_t)C * N2;
+  const int e = blockIdx.y, tid = threadIdx.x;
+  const int k1_0 = blockIdx.x * C;
+  const cd* w = work + (long long)e * P.n;
+  for (int i = tid; i < N2 * C; i += SM_THREADS) {
+    const int c = i % C, n2 = i / C;
+    a[c * N2 + n2] = w[(long long)n2 * N1 + k1_0 + c];
+  }
+  __syncthreads();
+  const cd* r = lds_fft_stockham(a, b, N2, P.r2, P.nr2, P.t2, tid, C);
+  const long long n = P.n;
+  const bool paired = (OUT == SM_OUT_SPEC) && J.x2off != nullptr && J.x2off[e] >= 0;
+  for (int i = tid; i < N2 * C; i += SM_THREADS) {
+    const int c = i % C, k2 = i / C;
+    const long long k = (long long)(k1_0 + c) + (long long)N1 * k2;        // natural output index
+    cd v = r[c * N2 + k2];
+    if (OUT == SM_OUT_SPEC) {
+      if (paired) {
+        J.zpair[J.zpair_off[e] + k] = v;
+      } else if (k <= n / 2) {
+        if (k == 0 || 2 * k == n) v.im = 0.0;
+        J.spec_out[J.spec_off[e] + k] = v;
+      }
+    } else {
+      const double sc = 1.0 / (double)n;
+      J.y[J.y1_off[e] + k] = (float)(v.re * sc);
+      const long long o2 = J.y2_off[e];
+      if (o2 >= 0) J.y[o2 + k] = (float)(-v.im * sc);
+    }
+  }
+}
+
+// split of Z = DFT(x1 + i x2) into the two half spectra (same convention as pair_split_kernel in ira_fftlong.hip)
+__global__ __launch_bounds__(256) void smooth_pair_split_kernel(SmoothPlan P, SJobs J) {
+  const int e = blockIdx.y;
+  if (J.x2off == nullptr || J.x2off[e] < 0) return;
+  const long long L = P.n;
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > L / 2) return;
+  const cd* z = J.zpair + J.zpair_off[e];
+  const cd zk = z[k], zl = z[k == 0 ? 0 : L - k];
+  J.spec_out[J.spec_off[e] + k] = {0.5 * (zk.re + zl.re), 0.5 * (zk.im - zl.im)};
+  J.spec_out[J.spec_off2[e] + k] = {0.5 * (zk.im + zl.im), 0.5 * (zl.re - zk.re)};
+}
+
+// ---- planning ------------------------------------------------------------------------------------------------------------
+int factor_radices(int n, int* out) {
+  // Few, wide passes: 16s, then one of 8 / 4 / 2 for the remaining twos (a lone 2 joins a 3 as a radix-6 pass), 5s, 3s.
+  // Returns the count or -1 if n has another prime factor.
+  int cnt = 0, twos = 0, threes = 0, fives = 0;
+  while (n % 2 == 0) { n /= 2; ++twos; }
+  while (n % 3 == 0) { n /= 3; ++threes; }
+  while (n % 5 == 0) { n /= 5; ++fives; }
+  if (n != 1) return -1;
+  for (; twos >= 4; twos -= 4) out[cnt++] = 16;
+  if (twos == 3) { out[cnt++] = 8; twos = 0; }
+  if (twos == 2) { out[cnt++] = 4; twos = 0; }
+  if (twos == 1) {
+    if (threes > 0) { out[cnt++] = 6; --threes; }
+    else out[cnt++] = 2;
+  }
+  for (; fives > 0; --fives) { if (cnt >= SM_MAX_RADICES) return -1; out[cnt++] = 5; }
+  for (; threes > 0; --threes) { if (cnt >= SM_MAX_RADICES) return -1; out[cnt++] = 3; }
+  return cnt;
+}
+
+bool smooth_split(long long n, int* n1_out, int* n2_out) {
+  if (n < 64 || n > (long long)SM_MAX_N * SM_MAX_N) return false;
+  long long m = n;
+  for (int p : {2, 3, 5}) while (m % p == 0) m /= p;
+  if (m != 1) return false;
+  // most balanced pair n1 <= n2 <= SM_MAX_N with n1 | n
+  int best = 0;
+  for (int d = 2; (long long)d * d <= n; ++d)
+    if (n % d == 0 && n / d <= SM_MAX_N) best = d;
+  if (best < 2) return false;
+  *n1_out = best;
+  *n2_out = (int)(n / best);
+  return true;
+}
+
+int32_t make_smooth_plan(int32_t n, const void* t1, const void* t2, const void* tf, SmoothPlan* P) {
+  int n1, n2;
+  if (!smooth_split(n, &n1, &n2)) return IRA_E_UNSUPPORTED;
+  P->n = n; P->n1 = n1; P->n2 = n2;
+  P->nr1 = factor_radices(n1, P->r1);
+  P->nr2 = factor_radices(n2, P->r2);
+  if (P->nr1 < 0 || P->nr2 < 0) return IRA_E_UNSUPPORTED;
+  // columns per workgroup: as many as keep both LDS buffers within 64 KB, dividing the other dimension
+  auto pick = [](int len, int other) {
+    int c = 8;
+    while (c > 1 && ((size_t)2 * c * len * sizeof(cd) > 64 * 1024 || other % c != 0)) c >>= 1;
+    return c;
+  };
+  P->c1 = pick(n1, n2);
+  P->c2 = pick(n2, n1);
+  if (const char* ev = std::getenv("IRA_SMOOTH_C1")) { const int v = std::atoi(ev); if (v >= 1 && n2 % v == 0) P->c1 = v; }
+  if (const char* ev = std::getenv("IRA_SMOOTH_C2")) { const int v = std::atoi(ev); if (v >= 1 && n1 % v == 0) P->c2 = v; }
+  P->t1 = static_cast<const cd*>(t1); P->t2 = static_cast<const cd*>(t2); P->tf = static_cast<const cd*>(tf);
+  return IRA_OK;
+}
+
+template <typename K>
+hipError_t allow(K kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+#define SM_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return ira_hip_status(_e); } while (0)
+
+}  // namespace
+
+// n = n1 * n2 with both factors <= 1024 and n = 2^a 3^b 5^c: IRA_OK and the split; otherwise IRA_E_UNSUPPORTED (use the
+// Bluestein entry points).  IRA_NO_SMOOTH_FFT in the environment disables the direct path (A/B switch).
+extern "C" int32_t ira_fft_smooth_split(int32_t n, int32_t* n1, int32_t* n2) {
+  IRA_CHECK_PTR(n1); IRA_CHECK_PTR(n2);
+  if (std::getenv("IRA_NO_SMOOTH_FFT") != nullptr) return IRA_E_UNSUPPORTED;
+  int a, b;
+  if (!smooth_split(n, &a, &b)) return IRA_E_UNSUPPORTED;
+  int r[SM_MAX_RADICES];
+  if (factor_radices(a, r) < 0 || factor_radices(b, r) < 0) return IRA_E_UNSUPPORTED;
+  *n1 = a; *n2 = b;
+  return IRA_OK;
+}
+
+extern "C" int32_t ira_rfft_smooth(const float* x_dev, const int64_t* xoff_dev, int32_t n, int32_t nb, int32_t use_hann,
+                                   const void* t1_dev, const void* t2_dev, const void* tf_dev, double* work_dev,
+                                   double* spec_out_dev, const int64_t* spec_off_dev, const int64_t* x2off_dev,
+                                   const int64_t* spec_off2_dev, double* zpair_dev, const int64_t* zpair_off_dev,
+                                   const int32_t* data_len_dev, const int32_t* win_len_dev,
+                                   const int32_t* data_len2_dev, const int32_t* win_len2_dev, void* stream) {
+  IRA_CHECK_PTR(x_dev); IRA_CHECK_PTR(xoff_dev); IRA_CHECK_PTR(t1_dev); IRA_CHECK_PTR(t2_dev); IRA_CHECK_PTR(tf_dev);
+  IRA_CHECK_PTR(work_dev); IRA_CHECK_PTR(spec_out_dev); IRA_CHECK_PTR(spec_off_dev);
+  if (nb <= 0) return nb == 0 ? IRA_OK : IRA_E_SIZE;
+  if (nb > 65535) return IRA_E_SIZE;
+  SmoothPlan P;
+  const int32_t rc = make_smooth_plan(n, t1_dev, t2_dev, tf_dev, &P);
+  if (rc != IRA_OK) return rc;
+  SJobs J{};
+  J.x = x_dev; J.xoff = xoff_dev; J.use_hann = use_hann;
+  J.data_len = data_len_dev; J.win_len = win_len_dev; J.data_len2 = data_len2_dev; J.win_len2 = win_len2_dev;
+  J.spec_out = reinterpret_cast<cd*>(spec_out_dev); J.spec_off = spec_off_dev;
+  if (x2off_dev != nullptr) {
+    if (spec_off2_dev == nullptr || zpair_dev == nullptr || zpair_off_dev == nullptr) return IRA_E_NULL;
+    J.x2off = x2off_dev; J.spec_off2 = spec_off2_dev;
+    J.zpair = reinterpret_cast<cd*>(zpair_dev); J.zpair_off = zpair_off_dev;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const size_t l1 = (size_t)2 * P.c1 * P.n1 * sizeof(cd), l2 = (size_t)2 * P.c2 * P.n2 * sizeof(cd);
+  SM_TRY(allow(smooth_cols_kernel<SM_SIGNAL>, l1));
+  SM_TRY(allow(smooth_rows_kernel<SM_OUT_SPEC>, l2));
+  cd* work = reinterpret_cast<cd*>(work_dev);
+  smooth_cols_kernel<SM_SIGNAL><<<dim3(P.n2 / P.c1, nb), SM_THREADS, l1, st>>>(P, J, work);
+  smooth_rows_kernel<SM_OUT_SPEC><<<dim3(P.n1 / P.c2, nb), SM_THREADS, l2, st>>>(P, J, work);
+  if (x2off_dev != nullptr)
+    smooth_pair_split_kernel<<<dim3((n / 2 + 1 + 255) / 256, nb), 256, 0, st>>>(P, J);
+  IRA_RETURN_LAUNCH();
+}
+
+extern "C" int32_t ira_band_irfft_smooth(const double* spec_dev, const int64_t* spec_off_dev, int32_t n, int32_t nb,
+                                         const double* band_params_dev, const double* freq_val_dev,
+                                         const void* t1_dev, const void* t2_dev, const void* tf_dev, double* work_dev,
+                                         float* y_dev, const int64_t* y1_off_dev, const int64_t* y2_off_dev,
+                                         const int64_t* spec_off2_dev, void* stream) {
+  IRA_CHECK_PTR(spec_dev); IRA_CHECK_PTR(spec_off_dev); IRA_CHECK_PTR(band_params_dev); IRA_CHECK_PTR(freq_val_dev);
+  IRA_CHECK_PTR(t1_dev); IRA_CHECK_PTR(t2_dev); IRA_CHECK_PTR(tf_dev); IRA_CHECK_PTR(work_dev); IRA_CHECK_PTR(y_dev);
+  IRA_CHECK_PTR(y1_off_dev); IRA_CHECK_PTR(y2_off_dev);
+  if (nb <= 0) return nb == 0 ? IRA_OK : IRA_E_SIZE;
+  if (nb > 65535) return IRA_E_SIZE;
+  SmoothPlan P;
+  const int32_t rc = make_smooth_plan(n, t1_dev, t2_dev, tf_dev, &P);
+  if (rc != IRA_OK) return rc;
+  static_assert(sizeof(BandMaskS) == 8 * sizeof(double), "band parameter record is 8 doubles");
+  SJobs J{};
+  J.spec = reinterpret_cast<const cd*>(spec_dev); J.sp_off = spec_off_dev; J.sp_off2 = spec_off2_dev;
+  J.bands = reinterpret_cast<const BandMaskS*>(band_params_dev); J.freq_val = freq_val_dev;
+  J.y = y_dev; J.y1_off = y1_off_dev; J.y2_off = y2_off_dev;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t l1 = (size_t)2 * P.c1 * P.n1 * sizeof(cd), l2 = (size_t)2 * P.c2 * P.n2 * sizeof(cd);
+  SM_TRY(allow(smooth_cols_kernel<SM_SPECTRUM>, l1));
+  SM_TRY(allow(smooth_rows_kernel<SM_OUT_BANDS>, l2));
+  cd* work = reinterpret_cast<cd*>(work_dev);
+  smooth_cols_kernel<SM_SPECTRUM><<<dim3(P.n2 / P.c1, nb), SM_THREADS, l1, st>>>(P, J, work);
+  smooth_rows_kernel<SM_OUT_BANDS><<<dim3(P.n1 / P.c2, nb), SM_THREADS, l2, st>>>(P, J, work);
+  IRA_RETURN_LAUNCH();
+}

@@ -358,6 +358,37 @@ class Engine:
             self._tables[key] = (tab(n1, n1), tab(n2, n2), tab(n2, m))
         return self._tables[key]
 
+    # Lengths of the form 2^a 3^b 5^c that split into two factors <= 1024 (480000, 2^19, ...) take the direct two-pass
+    # mixed-radix transform (ira_rfft_smooth / ira_band_irfft_smooth) instead of Bluestein.  Set False for an A/B.
+    smooth_ffts = True
+
+    def smooth_split(self, n: int):
+        """(n1, n2) if the library has a direct transform for length n, else None (cached)."""
+        key = ("smooth?", int(n))
+        if key not in self._tables:
+            import ctypes
+            a, b = ctypes.c_int32(0), ctypes.c_int32(0)
+            rc = self.lib.ira_fft_smooth_split(int(n), ctypes.byref(a), ctypes.byref(b)) if n < (1 << 31) else -3
+            self._tables[key] = (a.value, b.value) if rc == 0 else None
+        return self._tables[key] if self.smooth_ffts else None
+
+    def smooth_tables(self, n: int):
+        key = ("smooth", int(n))
+        if key not in self._tables:
+            n1, n2 = self.smooth_split(n)
+
+            def tab(count, period):
+                ang = -2.0 * np.pi * np.arange(count, dtype=np.float64) / float(period)
+                return self.to_dev(np.stack([np.cos(ang), np.sin(ang)], axis=1))
+
+            self._tables[key] = (tab(n1, n1), tab(n2, n2), tab(n2, n))
+        return self._tables[key]
+
+    def _chunks_of(self, idx: np.ndarray, bytes_per_job: int):
+        step = max(1, int(self.workspace_budget_bytes // max(1, bytes_per_job)))
+        for i in range(0, idx.size, step):
+            yield idx[i : i + step]
+
     def _chunks_by_log2m(self, lengths: np.ndarray):
         """Group element indices by the FFT size they need, then cut each group to the workspace budget."""
         l2 = np.array([self.log2m_for(int(v)) for v in lengths], dtype=np.int64)
@@ -469,7 +500,45 @@ class Engine:
         if n > 1:
             spec_off[1:] = np.cumsum(bins[:-1])
         spec = self.empty(int(bins.sum()) * 2, t.float64)
-        for lm, idx in self._chunks_by_log2m(lengths):
+        # ---- smooth lengths: direct two-pass transform, one call per distinct length ------------------------------------
+        rest = np.ones(n, dtype=bool)
+        for L in np.unique(lengths):
+            if self.smooth_split(int(L)) is None:
+                continue
+            grp = np.nonzero(lengths == L)[0]
+            rest[grp] = False
+            t1, t2, tf = self.smooth_tables(int(L))
+            for idx in self._chunks_of(grp, 32 * int(L)):
+                if self.pair_real_ffts and idx.size > 1:
+                    j1, j2 = self._pair_by_key(idx, lengths)
+                else:
+                    j1, j2 = idx.astype(np.int64), np.full(idx.size, -1, dtype=np.int64)
+                work = self.empty(int(j1.size) * 2 * int(L), t.float64)
+                d_xo, d_so = self.to_dev(xoff[j1]), self.to_dev(spec_off[j1])
+                paired = j2 >= 0
+                safe = np.maximum(j2, 0)
+                if paired.any():
+                    d_x2 = self.to_dev(np.where(paired, xoff[safe], -1).astype(np.int64))
+                    d_so2 = self.to_dev(np.where(paired, spec_off[safe], 0).astype(np.int64))
+                    zoff = np.cumsum(np.where(paired, int(L), 0)) - np.where(paired, int(L), 0)
+                    zpair = self.empty(int(paired.sum()) * 2 * int(L), t.float64)
+                    d_zo = self.to_dev(zoff.astype(np.int64))
+                else:
+                    d_x2 = d_so2 = zpair = d_zo = None
+                d_dl = d_wl = d_dl2 = d_wl2 = None
+                if padded:
+                    d_dl, d_wl = self.to_dev(data_len[j1]), self.to_dev(win_len[j1])
+                    d_dl2, d_wl2 = self.to_dev(data_len[safe]), self.to_dev(win_len[safe])
+                check(self.lib.ira_rfft_smooth(_ptr(x_dev), _ptr(d_xo), int(L), int(j1.size), 1 if use_hann else 0,
+                                               _ptr(t1), _ptr(t2), _ptr(tf), _ptr(work), _ptr(spec), _ptr(d_so),
+                                               _ptr(d_x2), _ptr(d_so2), _ptr(zpair), _ptr(d_zo), _ptr(d_dl), _ptr(d_wl),
+                                               _ptr(d_dl2), _ptr(d_wl2), self.stream), "ira_rfft_smooth")
+        if not rest.any():
+            return spec, spec_off
+        rest_idx = np.nonzero(rest)[0]
+        # ---- everything else: Bluestein, grouped by the power-of-two convolution size ------------------------------------
+        for lm, sub in self._chunks_by_log2m(lengths[rest_idx]):
+            idx = rest_idx[sub]
             t1, t2, tf = self.long_tables(lm)
             if self.pair_real_ffts and idx.size > 1:
                 j1, j2 = self._pair_by_key(idx, lengths)
@@ -530,7 +599,30 @@ class Engine:
         el_par[has2, 1, :] = band_params[safe[has2]]
         el_so2 = np.where(has2, spec_off[safe], spec_off[j1]).astype(np.int64)
         el_y2 = np.where(has2, y_off[safe], -1).astype(np.int64)
-        for lm, sel in self._chunks_by_log2m(jl):
+        rest = np.ones(j1.size, dtype=bool)
+        for L in np.unique(jl):
+            if self.smooth_split(int(L)) is None:
+                continue
+            grp = np.nonzero(jl == L)[0]
+            rest[grp] = False
+            t1, t2, tf = self.smooth_tables(int(L))
+            for sel in self._chunks_of(grp, 16 * int(L)):
+                work = self.empty(int(sel.size) * 2 * int(L), t.float64)
+                d_so = self.to_dev(spec_off[j1][sel])
+                d_bp = self.to_dev(np.ascontiguousarray(el_par[sel]))
+                d_fv = self.to_dev(np.ascontiguousarray(freq_val[j1][sel]))
+                d_y1 = self.to_dev(np.ascontiguousarray(y_off[j1][sel]))
+                d_y2 = self.to_dev(np.ascontiguousarray(el_y2[sel]))
+                d_so2 = self.to_dev(np.ascontiguousarray(el_so2[sel]))
+                check(self.lib.ira_band_irfft_smooth(_ptr(spec_dev), _ptr(d_so), int(L), int(sel.size), _ptr(d_bp),
+                                                     _ptr(d_fv), _ptr(t1), _ptr(t2), _ptr(tf), _ptr(work), _ptr(y_dev),
+                                                     _ptr(d_y1), _ptr(d_y2), _ptr(d_so2), self.stream),
+                      "ira_band_irfft_smooth")
+        if not rest.any():
+            return
+        rest_idx = np.nonzero(rest)[0]
+        for lm, sub in self._chunks_by_log2m(jl[rest_idx]):
+            sel = rest_idx[sub]
             t1, t2, tf = self.long_tables(lm)
             bf, bidx = self._filters(jl[sel], lm)
             work = self.empty(int(sel.size) * (2 << lm), t.float64)

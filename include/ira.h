@@ -246,6 +246,28 @@ int32_t ira_fir_numerator(const double* coeffs_dev, int32_t order, const float* 
                           const int64_t* xoff_dev, const int32_t* len_dev, const double* divisor_dev,
                           int32_t nb, int32_t zero_order, double* b_dev, void* stream);
 
+/* ---- Direct transforms of smooth lengths -------------------------------------------------------------------------------
+ * For n = 2^a 3^b 5^c that splits as n1*n2 with both factors <= 1024 (480000 = 640*750, 2^19 = 512*1024, ...) a
+ * two-pass mixed-radix four-step transform replaces the three-pass Bluestein of ira_rfft_any / ira_band_irfft; every
+ * job of a call has the same length n.  ira_fft_smooth_split: IRA_OK and the split, or IRA_E_UNSUPPORTED (then use
+ * the Bluestein entry points; also when IRA_NO_SMOOTH_FFT is set in the environment).  Tables for the split:
+ *   t1_dev[k] = exp(-2 pi i k/n1), k < n1;  t2_dev[k] = exp(-2 pi i k/n2), k < n2;  tf_dev[k] = exp(-2 pi i k/n), k < n2.
+ * work_dev: nb * n complex f64.  All other arguments mean what they mean in ira_rfft_any / ira_band_irfft (same
+ * reference call sites: frequency_response.py:204-213, filterplot.py:145-152, rt60bands.py:170-175,
+ * group_delay.py:95-109). */
+int32_t ira_fft_smooth_split(int32_t n, int32_t* n1, int32_t* n2);
+int32_t ira_rfft_smooth(const float* x_dev, const int64_t* xoff_dev, int32_t n, int32_t nb, int32_t use_hann,
+                        const void* t1_dev, const void* t2_dev, const void* tf_dev, double* work_dev,
+                        double* spec_out_dev, const int64_t* spec_off_dev, const int64_t* x2off_dev,
+                        const int64_t* spec_off2_dev, double* zpair_dev, const int64_t* zpair_off_dev,
+                        const int32_t* data_len_dev, const int32_t* win_len_dev, const int32_t* data_len2_dev,
+                        const int32_t* win_len2_dev, void* stream);
+int32_t ira_band_irfft_smooth(const double* spec_dev, const int64_t* spec_off_dev, int32_t n, int32_t nb,
+                              const double* band_params_dev, const double* freq_val_dev, const void* t1_dev,
+                              const void* t2_dev, const void* tf_dev, double* work_dev, float* y_dev,
+                              const int64_t* y1_off_dev, const int64_t* y2_off_dev, const int64_t* spec_off2_dev,
+                              void* stream);
+
 /* k-th smallest values (0-based ranks, clipped to the segment) of float64 segments values_dev + off_dev[e], count_dev[e]
  * long: out_dev[e*nranks + j] = sorted(segment)[ranks_dev[e*nranks + j]], 1 <= nranks <= 8 (radix select, exact).
  * The building block of numpy.median / numpy.percentile in summarise_group_delay_results_text, reference

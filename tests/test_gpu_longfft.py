@@ -81,6 +81,77 @@ def test_rfft_any_pairs_equal_lengths():
     assert np.max(np.abs(a1 - a2)) / np.max(np.abs(a1)) < 1e-14
 
 
+def test_smooth_lengths_take_the_direct_transform_and_match_numpy():
+    """n = 2^a 3^b 5^c: two-pass mixed-radix four-step (ira_rfft_smooth) against numpy and against Bluestein."""
+    from audio_analysis_amd.engine import get_engine
+    eng = get_engine()
+    rng = np.random.default_rng(21)
+    nmax = 480000
+    chans = [(rng.standard_normal(nmax) * np.exp(-np.arange(nmax) / 60000.0) * s).astype(np.float32) for s in (1.0, 0.25, 2.0)]
+    b = eng.upload(chans)
+    lengths = [480000, 96000, 6000, 1 << 15, 15552, 15625, 1000, 64, 3 * 1024 * 128, 2 * 3 * 5 * 7 * 64]
+    for L in lengths:
+        smooth = eng.smooth_split(L)
+        assert (smooth is None) == (L == 2 * 3 * 5 * 7 * 64), (L, smooth)
+        if smooth is not None:
+            assert smooth[0] * smooth[1] == L and max(smooth) <= 1024
+        for hann in (False, True):
+            lens = np.array([L, L, L], np.int32)
+            spec, off = eng.rfft_any(b.x, b.off, lens, hann)          # channels 0,1 paired, channel 2 single
+            h = spec.cpu().numpy()
+            refs = []
+            for c in chans:
+                seg = c[:L].astype(np.float64)
+                refs.append(np.fft.rfft(seg * np.hanning(L) if hann else seg))
+            peak = max(float(np.max(np.abs(r))) for r in refs)
+            for o, ref in zip(off, refs):
+                g = h[2 * o : 2 * (o + L // 2 + 1)].reshape(-1, 2)
+                err = np.max(np.abs(g[:, 0] + 1j * g[:, 1] - ref)) / peak
+                assert err < 5e-14, (L, hann, err)
+                assert g[0, 1] == 0.0 and (L % 2 or g[-1, 1] == 0.0)
+    # A/B against Bluestein on the bench length
+    lens = np.array([480000] * 3, np.int32)
+    s1, _ = eng.rfft_any(b.x, b.off, lens, True)
+    try:
+        eng.smooth_ffts = False
+        s2, _ = eng.rfft_any(b.x, b.off, lens, True)
+    finally:
+        eng.smooth_ffts = True
+    a1, a2 = s1.cpu().numpy(), s2.cpu().numpy()
+    assert np.max(np.abs(a1 - a2)) / np.max(np.abs(a2)) < 1e-13
+
+
+def test_rt60_bands_smooth_vs_bluestein_paths():
+    """The band filter bank on a smooth file length (96000) gives the same RT60s through both transform paths."""
+    from audio_analysis_amd.analyse import rt60bands as rb
+    from audio_analysis_amd.engine import get_engine
+    from audio_analysis_amd.synth import synth_ir
+    eng = get_engine()
+    chans = [synth_ir(60 + i, 0, 96000, rt60_seconds=0.5 + 0.1 * i) for i in range(3)]
+    st = rb.Rt60BandsAnalysisSettings(band_mode="octave", include_t20=True, include_edt=True)
+    assert eng.smooth_split(96000) is not None
+    direct = rb.analyse_rt60_bands_batch(chans, SR, list("abc"), st)
+    try:
+        eng.smooth_ffts = False
+        blue = rb.analyse_rt60_bands_batch(chans, SR, list("abc"), st)
+    finally:
+        eng.smooth_ffts = True
+    o = O.analyse_rt60_bands(chans[0], SR, band_mode="octave", include_t20=True, include_edt=True)
+    for d, bl in zip(direct, blue):
+        for name, md in d.band_metrics_by_name.items():
+            mb = bl.band_metrics_by_name[name]
+            for f in ("rt60_t30_seconds", "rt60_t20_seconds", "edt_seconds"):
+                vd, vb = getattr(md, f), getattr(mb, f)
+                assert (vd is None) == (vb is None)
+                if vd is not None:
+                    assert _rel(vd, vb) < 1e-6, (name, f, vd, vb)
+    for name, md in direct[0].band_metrics_by_name.items():
+        w = o["metrics"][name]["t30"]
+        assert (md.rt60_t30_seconds is None) == (w is None)
+        if w is not None:
+            assert _rel(md.rt60_t30_seconds, w) < 1e-4
+
+
 def test_band_pairs_across_channels_match_unpaired():
     """rt60bands, three bands x two equal-length channels: the odd bands share one inverse transform."""
     from audio_analysis_amd.analyse import rt60bands as rb
