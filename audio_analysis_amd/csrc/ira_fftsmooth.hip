@@ -4,9 +4,10 @@
 // flops for the RT60 filter bank (reference analyse/rt60bands.py:170-175) and every other whole-file transform whose
 // length happens to be smooth.  Same inputs, outputs and pairing conventions as the Bluestein entry points.
 //
-//   x[n1*N2 + n2]  --P1 (columns: N1-point FFT over n1, twiddle W_n^(k1 n2))-->  work[n2*N1 + k1]   (stored TRANSPOSED:
-//                     each workgroup owns C columns and writes C contiguous runs of N1 values)
-//   work           --P2 (N2-point FFT over n2 for C adjacent k1)-->  X[k1 + N1*k2]                  (runs of C values)
+//   x[n1*N2 + n2]  --P1 (columns: N1-point FFT over n1, twiddle W_n^(k1 n2))-->  work, stored in TILES of C2 adjacent k1:
+//                     work[(k1 / C2) * (N2 * C2) + n2 * C2 + k1 % C2]  (scattered 32-byte WRITES, which do not stall)
+//   work           --P2 (N2-point FFT over n2 for the C2 values of k1 of one tile, read as ONE contiguous block)-->
+//                     X[k1 + N1*k2]                                                                 (runs of C2 values)
 // Inverse transforms run the same forward machinery on the conjugated input (conj(DFT(conj .)) / n).
 #include <cmath>
 #include <cstdlib>
@@ -31,6 +32,7 @@ struct SmoothPlan {
   const cd* t1;                     // exp(-2 pi i k / N1), k < N1
   const cd* t2;                     // exp(-2 pi i k / N2), k < N2
   const cd* tf;                     // exp(-2 pi i k / n),  k < N2
+  int stamp;                        // diagnostics (IRA_SMOOTH_STAMP): per-phase cycle counts of one workgroup per kernel
 };
 
 // ---- radix butterflies, forward sign (W = exp(-2 pi i / r)), natural order in and out, registers only -------------------
@@ -117,6 +119,20 @@ __device__ __forceinline__ void bfly<16>(cd (&a)[16]) {
 //   y[q + s (R p + k)] = W_N^(s p k) * sum_j x[q + s (p + m j)] W_R^(j k),   p < m, q < s.
 // p = bf / s by a multiply-high with magic = floor(2^32 / s) + 1 (exact for bf < 2^16); the R-1 twiddles of a butterfly
 // are powers of ONE table value.
+// Sub-FFT twiddles W_N^t, t < N <= 1024, from two 32+33-entry LDS tables: coarse[t >> 5] = W_N^(32 (t >> 5)),
+// fine[t & 31] = W_N^(t & 31): two LDS reads and one complex multiply (a dependent GLOBAL load per butterfly was the
+// critical path of every pass, an in-kernel sincospi costs ~100 instructions).
+constexpr int SM_TW = 66;       // 33 coarse + 33 fine entries
+__device__ __forceinline__ void build_twiddle_lds(cd* tab, const cd* __restrict__ tw, int N, int tid) {
+  if (tid < 33) {
+    const int t = 32 * tid;
+    tab[tid] = t < N ? tw[t] : cd{1.0, 0.0};
+  } else if (tid < 66) {
+    const int t = tid - 33;
+    tab[tid] = t < N ? tw[t] : cd{1.0, 0.0};
+  }
+}
+
 template <int R>
 __device__ __forceinline__ void stockham_pass(const cd* x, cd* y, int N, int m, int s, unsigned magic,
                                               const cd* __restrict__ tw, int tid, int nbat) {
@@ -137,7 +153,8 @@ __device__ __forceinline__ void stockham_pass(const cd* x, cd* y, int N, int m, 
 #pragma unroll
         for (int k = 1; k < R; ++k) yo[s * k] = v[k];
       } else {
-        const cd w1 = tw[s * p];                                         // W_N^(s p), s p < N / R
+        const int t = s * p;                                             // W_N^(s p), s p < N / R; tw = LDS tables
+        const cd w1 = ira::cmul(tw[t >> 5], tw[33 + (t & 31)]);
         cd w = w1;
 #pragma unroll
         for (int k = 1; k < R; ++k) {
@@ -242,29 +259,50 @@ __device__ __forceinline__ double hann_s(long long i, long long L) {
   return 0.5 + 0.5 * cospi((double)(2 * i + 1 - L) / (double)(L - 1));
 }
 
+// Input generation in two phases so that a thread's memory reads are all in flight before the first one is used:
+// smooth_fetch does nothing but the loads, smooth_value the arithmetic (window, masks, Hermitian extension).
+struct RawIn { double a, b, c, d; };
+
 template <int MODE>
-__device__ __forceinline__ cd smooth_input(const SmoothPlan& P, const SJobs& J, int e, long long i) {
+__device__ __forceinline__ RawIn smooth_fetch(const SmoothPlan& P, const SJobs& J, int e, long long i) {
+  RawIn r{0.0, 0.0, 0.0, 0.0};
   const long long n = P.n;
   if (MODE == SM_SIGNAL) {
     const long long nd1 = J.data_len ? (long long)J.data_len[e] : n;
-    const long long lw1 = J.win_len ? (long long)J.win_len[e] : n;
-    double v = i < nd1 ? (double)J.x[J.xoff[e] + i] : 0.0;
-    if (J.use_hann) v *= hann_s(i, lw1);
+    if (i < nd1) r.a = (double)J.x[J.xoff[e] + i];
     const long long o2 = J.x2off ? J.x2off[e] : -1;
-    double v2 = 0.0;
     if (o2 >= 0) {
       const long long nd2 = J.data_len2 ? (long long)J.data_len2[e] : nd1;
-      const long long lw2 = J.win_len2 ? (long long)J.win_len2[e] : lw1;
-      v2 = i < nd2 ? (double)J.x[o2 + i] : 0.0;
-      if (J.use_hann) v2 *= hann_s(i, lw2);
+      if (i < nd2) r.b = (double)J.x[o2 + i];
+    }
+  } else {
+    const long long k = i > n / 2 ? n - i : i;
+    const cd x1 = J.spec[J.sp_off[e] + k];
+    r.a = x1.re; r.b = x1.im;
+    if (J.sp_off2 != nullptr && J.sp_off2[e] != J.sp_off[e]) {
+      const cd x2 = J.spec[J.sp_off2[e] + k];
+      r.c = x2.re; r.d = x2.im;
+    }
+  }
+  return r;
+}
+
+template <int MODE>
+__device__ __forceinline__ cd smooth_value(const SmoothPlan& P, const SJobs& J, int e, long long i, const RawIn& r) {
+  const long long n = P.n;
+  if (MODE == SM_SIGNAL) {
+    double v = r.a, v2 = r.b;
+    if (J.use_hann) {
+      const long long lw1 = J.win_len ? (long long)J.win_len[e] : n;
+      v *= hann_s(i, lw1);
+      if (J.x2off && J.x2off[e] >= 0) v2 *= hann_s(i, J.win_len2 ? (long long)J.win_len2[e] : lw1);
     }
     return {v, v2};
   } else {
     // conj of the Hermitian extension of X1 m1 + i X2 m2  (inverse = conj(DFT(conj .)) / n)
     const bool upper = i > n / 2;
     const long long k = upper ? n - i : i;
-    cd x1 = J.spec[J.sp_off[e] + k];
-    if (upper) x1.im = -x1.im;
+    cd x1 = {r.a, upper ? -r.b : r.b};
     const float f = (float)((double)k * J.freq_val[e]);
     const double m1 = (double)mask_s(J.bands[2 * e], f);
     const double m2 = (double)mask_s(J.bands[2 * e + 1], f);
@@ -272,13 +310,28 @@ __device__ __forceinline__ cd smooth_input(const SmoothPlan& P, const SJobs& J, 
     if (J.sp_off2 == nullptr || J.sp_off2[e] == J.sp_off[e]) {
       w = ira::cmul(x1, cd{m1, m2});
     } else {
-      cd x2 = J.spec[J.sp_off2[e] + k];
-      if (upper) x2.im = -x2.im;
+      const cd x2 = {r.c, upper ? -r.d : r.d};
       w = {x1.re * m1 - x2.im * m2, x1.im * m1 + x2.re * m2};
     }
     return {w.re, -w.im};
   }
 }
+
+constexpr int SM_U = 8;     // independent loads in flight per thread (pass 2)
+constexpr int SM_UC = 4;    // (pass 1: a fetch is up to four doubles)
+
+// XCD-aware remap (speed only): workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  Neighbouring
+// column tiles read/write different 32-byte pieces of the SAME 128-byte lines; give each XCD a contiguous range of
+// (job, tile) pairs so that those pieces meet in one L2.
+__device__ __forceinline__ void smooth_remap(unsigned& bx, unsigned& by) {
+  const unsigned gx = gridDim.x, nwg = gridDim.x * gridDim.y;
+  const unsigned orig = blockIdx.y * gx + blockIdx.x;
+  const unsigned q = nwg / 8, r = nwg % 8, xcd = orig % 8;
+  const unsigned wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+  bx = wg % gx; by = wg / gx;
+}
+
+#define SM_STAMP(var) do { if (P.stamp) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } } while (0)
 
 // ---- pass 1: columns.  grid (N2 / C, jobs) ------------------------------------------------------------------------------
 template <int MODE>
@@ -287,19 +340,48 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_cols_kernel(SmoothPlan P, S
   cd* a = reinterpret_cast<cd*>(smem);
   const int C = P.c1, N1 = P.n1, N2 = P.n2;
   cd* b = a + (size_t)C * N1;
-  const int e = blockIdx.y, tid = threadIdx.x;
-  const int n2_0 = blockIdx.x * C;
-  for (int i = tid; i < N1 * C; i += SM_THREADS) {
-    const int c = i % C, n1 = i / C;
-    a[c * N1 + n1] = smooth_input<MODE>(P, J, e, (long long)n1 * N2 + n2_0 + c);
+  cd* twl = b + (size_t)C * N1;                            // SM_TW entries
+  unsigned bx, by;
+  smooth_remap(bx, by);
+  const int e = (int)by, tid = threadIdx.x;
+  const int n2_0 = (int)bx * C;
+  unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  SM_STAMP(s0);
+  const int total1 = N1 * C;
+  for (int base = 0; base < total1; base += SM_THREADS * SM_UC) {
+    RawIn raw[SM_UC];
+    long long idx[SM_UC];
+#pragma unroll
+    for (int u = 0; u < SM_UC; ++u) {
+      int i = base + tid + SM_THREADS * u;
+      i = i < total1 ? i : total1 - 1;                      // clamp: every fetch is unconditional (stays in registers)
+      idx[u] = (long long)(i / C) * N2 + n2_0 + i % C;
+      raw[u] = smooth_fetch<MODE>(P, J, e, idx[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < SM_UC; ++u) {
+      const int i = base + tid + SM_THREADS * u;
+      const cd v = smooth_value<MODE>(P, J, e, idx[u], raw[u]);
+      if (i < total1) a[(i % C) * N1 + i / C] = v;
+    }
   }
+  build_twiddle_lds(twl, P.t1, N1, tid);
   __syncthreads();
-  const cd* r = lds_fft_stockham(a, b, N1, P.r1, P.nr1, P.t1, tid, C);
+  SM_STAMP(s1);
+  const cd* r = lds_fft_stockham(a, b, N1, P.r1, P.nr1, twl, tid, C);
+  SM_STAMP(s2);
   cd* w = work + (long long)e * P.n;
   for (int i = tid; i < N1 * C; i += SM_THREADS) {
     const int c = i / N1, k1 = i - c * N1;
     const int n2 = n2_0 + c;
-    w[(long long)n2 * N1 + k1] = ira::cmul(r[c * N1 + k1], twiddle_n(P, (unsigned)k1 * (unsigned)n2));
+    const int C2 = P.c2;
+    w[(long long)(k1 / C2) * ((long long)N2 * C2) + (long long)n2 * C2 + k1 % C2] =
+        ira::cmul(r[c * N1 + k1], twiddle_n(P, (unsigned)k1 * (unsigned)n2));
+  }
+  if (P.stamp) {
+    SM_STAMP(s3);
+    if (tid == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2)
+      printf("SMOOTH cols<%d> N1 %d C %d: input %llu  fft %llu  twiddle+store %llu cycles\n", MODE, N1, C, s1 - s0, s2 - s1, s3 - s2);
   }
 }
 
@@ -310,15 +392,34 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_rows_kernel(SmoothPlan P, S
   cd* a = reinterpret_cast<cd*>(smem);
   const int C = P.c2, N1 = P.n1, N2 = P.n2;
   cd* b = a + (size_t)C * N2;
-  const int e = blockIdx.y, tid = threadIdx.x;
-  const int k1_0 = blockIdx.x * C;
+  cd* twl = b + (size_t)C * N2;
+  unsigned bx, by;
+  smooth_remap(bx, by);
+  const int e = (int)by, tid = threadIdx.x;
+  const int k1_0 = (int)bx * C;
   const cd* w = work + (long long)e * P.n;
-  for (int i = tid; i < N2 * C; i += SM_THREADS) {
-    const int c = i % C, n2 = i / C;
-    a[c * N2 + n2] = w[(long long)n2 * N1 + k1_0 + c];
+  unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  SM_STAMP(s0);
+  const int total2 = N2 * C;
+  for (int base = 0; base < total2; base += SM_THREADS * SM_U) {
+    cd raw[SM_U];
+#pragma unroll
+    for (int u = 0; u < SM_U; ++u) {
+      int i = base + tid + SM_THREADS * u;
+      i = i < total2 ? i : total2 - 1;                      // clamp: unconditional loads, conditional stores
+      raw[u] = w[(long long)bx * total2 + i];               // this tile: n2 * C + c, contiguous
+    }
+#pragma unroll
+    for (int u = 0; u < SM_U; ++u) {
+      const int i = base + tid + SM_THREADS * u;
+      if (i < total2) a[(i % C) * N2 + i / C] = raw[u];
+    }
   }
+  build_twiddle_lds(twl, P.t2, N2, tid);
   __syncthreads();
-  const cd* r = lds_fft_stockham(a, b, N2, P.r2, P.nr2, P.t2, tid, C);
+  SM_STAMP(s1);
+  const cd* r = lds_fft_stockham(a, b, N2, P.r2, P.nr2, twl, tid, C);
+  SM_STAMP(s2);
   const long long n = P.n;
   const bool paired = (OUT == SM_OUT_SPEC) && J.x2off != nullptr && J.x2off[e] >= 0;
   for (int i = tid; i < N2 * C; i += SM_THREADS) {
@@ -338,6 +439,11 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_rows_kernel(SmoothPlan P, S
       const long long o2 = J.y2_off[e];
       if (o2 >= 0) J.y[o2 + k] = (float)(-v.im * sc);
     }
+  }
+  if (P.stamp) {
+    SM_STAMP(s3);
+    if (tid == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2)
+      printf("SMOOTH rows<%d> N2 %d C %d: load %llu  fft %llu  output %llu cycles\n", OUT, N2, C, s1 - s0, s2 - s1, s3 - s2);
   }
 }
 
@@ -375,15 +481,32 @@ int factor_radices(int n, int* out) {
   return cnt;
 }
 
+// columns per workgroup for a sub-transform of `len` points (other dimension `other`): as many as keep both LDS buffers
+// within 64 KB, dividing the other dimension
+int pick_columns(int len, int other) {
+  int c = 8;
+  while (c > 1 && (((size_t)2 * c * len + SM_TW) * sizeof(cd) > 64 * 1024 || other % c != 0)) c >>= 1;
+  return c;
+}
+
 bool smooth_split(long long n, int* n1_out, int* n2_out) {
   if (n < 64 || n > (long long)SM_MAX_N * SM_MAX_N) return false;
   long long m = n;
   for (int p : {2, 3, 5}) while (m % p == 0) m /= p;
   if (m != 1) return false;
-  // most balanced pair n1 <= n2 <= SM_MAX_N with n1 | n
+  // Among the pairs n1 * n2 = n with both <= SM_MAX_N take the most balanced one (measured on MI355X for n = 480000:
+  // 640 x 750 beats 960 x 500 and 480 x 1000 although the latter allow more columns per workgroup: the smaller LDS
+  // footprint, i.e. more resident workgroups, matters more).  IRA_SMOOTH_N1 forces n1 (tuning).
+  static const int forced = std::getenv("IRA_SMOOTH_N1") ? std::atoi(std::getenv("IRA_SMOOTH_N1")) : 0;
+  long long best_score = -1;
   int best = 0;
-  for (int d = 2; (long long)d * d <= n; ++d)
-    if (n % d == 0 && n / d <= SM_MAX_N) best = d;
+  for (int d = 2; d <= SM_MAX_N; ++d) {
+    if (n % d != 0 || n / d > SM_MAX_N || n / d < 2) continue;
+    const int n1 = d, n2 = (int)(n / d);
+    if (forced > 0 && n1 != forced) continue;
+    const long long score = 2 * (SM_MAX_N - (n1 > n2 ? n1 - n2 : n2 - n1)) + (n1 <= n2 ? 1 : 0);
+    if (score > best_score) { best_score = score; best = d; }
+  }
   if (best < 2) return false;
   *n1_out = best;
   *n2_out = (int)(n / best);
@@ -397,17 +520,12 @@ int32_t make_smooth_plan(int32_t n, const void* t1, const void* t2, const void* 
   P->nr1 = factor_radices(n1, P->r1);
   P->nr2 = factor_radices(n2, P->r2);
   if (P->nr1 < 0 || P->nr2 < 0) return IRA_E_UNSUPPORTED;
-  // columns per workgroup: as many as keep both LDS buffers within 64 KB, dividing the other dimension
-  auto pick = [](int len, int other) {
-    int c = 8;
-    while (c > 1 && ((size_t)2 * c * len * sizeof(cd) > 64 * 1024 || other % c != 0)) c >>= 1;
-    return c;
-  };
-  P->c1 = pick(n1, n2);
-  P->c2 = pick(n2, n1);
+  P->c1 = pick_columns(n1, n2);
+  P->c2 = pick_columns(n2, n1);
   if (const char* ev = std::getenv("IRA_SMOOTH_C1")) { const int v = std::atoi(ev); if (v >= 1 && n2 % v == 0) P->c1 = v; }
   if (const char* ev = std::getenv("IRA_SMOOTH_C2")) { const int v = std::atoi(ev); if (v >= 1 && n1 % v == 0) P->c2 = v; }
   P->t1 = static_cast<const cd*>(t1); P->t2 = static_cast<const cd*>(t2); P->tf = static_cast<const cd*>(tf);
+  P->stamp = std::getenv("IRA_SMOOTH_STAMP") != nullptr;
   return IRA_OK;
 }
 
@@ -457,7 +575,7 @@ extern "C" int32_t ira_rfft_smooth(const float* x_dev, const int64_t* xoff_dev, 
     J.zpair = reinterpret_cast<cd*>(zpair_dev); J.zpair_off = zpair_off_dev;
   }
   hipStream_t st = (hipStream_t)stream;
-  const size_t l1 = (size_t)2 * P.c1 * P.n1 * sizeof(cd), l2 = (size_t)2 * P.c2 * P.n2 * sizeof(cd);
+  const size_t l1 = ((size_t)2 * P.c1 * P.n1 + SM_TW) * sizeof(cd), l2 = ((size_t)2 * P.c2 * P.n2 + SM_TW) * sizeof(cd);
   SM_TRY(allow(smooth_cols_kernel<SM_SIGNAL>, l1));
   SM_TRY(allow(smooth_rows_kernel<SM_OUT_SPEC>, l2));
   cd* work = reinterpret_cast<cd*>(work_dev);
@@ -487,7 +605,7 @@ extern "C" int32_t ira_band_irfft_smooth(const double* spec_dev, const int64_t* 
   J.bands = reinterpret_cast<const BandMaskS*>(band_params_dev); J.freq_val = freq_val_dev;
   J.y = y_dev; J.y1_off = y1_off_dev; J.y2_off = y2_off_dev;
   hipStream_t st = (hipStream_t)stream;
-  const size_t l1 = (size_t)2 * P.c1 * P.n1 * sizeof(cd), l2 = (size_t)2 * P.c2 * P.n2 * sizeof(cd);
+  const size_t l1 = ((size_t)2 * P.c1 * P.n1 + SM_TW) * sizeof(cd), l2 = ((size_t)2 * P.c2 * P.n2 + SM_TW) * sizeof(cd);
   SM_TRY(allow(smooth_cols_kernel<SM_SPECTRUM>, l1));
   SM_TRY(allow(smooth_rows_kernel<SM_OUT_BANDS>, l2));
   cd* work = reinterpret_cast<cd*>(work_dev);
