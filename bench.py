@@ -193,11 +193,14 @@ def main():
             b = stft_bytes(settings.modal_cloud.n_fft, settings.modal_cloud.hop_length)
             what = "4L in + 4*F*T out bytes per channel"
         elif name.startswith("ira_rfft_any"):
-            # compulsory traffic: samples in + half spectra out, for the RT60 full-file transform and the windowed
-            # fr/filter transform.  The three float64 Bluestein passes over M = 2^20 move ~15x that through
-            # L2/MALL/HBM (see "traffic"); that working-set traffic is what bounds these kernels.
-            b = float(np.sum(4.0 * L + 16.0 * (L // 2 + 1))) + float(a.batch) * (4.0 * n + 16.0 * (n // 2 + 1))
-            what = "per channel: 4n + 16(n/2+1) (RT60 forward) + 4L + 16(L/2+1) (fr/filter) bytes"
+            # compulsory traffic: samples in + half spectra out of the windowed fr/filter transform (arbitrary length ->
+            # Bluestein).  The three float64 passes over M = 2^20 move ~15x that through L2/MALL/HBM (see "traffic");
+            # that working-set traffic is what bounds these kernels.
+            b = float(np.sum(4.0 * L + 16.0 * (L // 2 + 1)))
+            what = "per channel: 4L + 16(L/2+1) bytes (fr/filter spectrum, Bluestein)"
+        elif name.startswith("ira_rfft_smooth"):
+            b = float(a.batch) * (4.0 * n + 16.0 * (n // 2 + 1))
+            what = "per channel: 4n + 16(n/2+1) bytes (RT60 full-file forward transform, direct mixed radix, paired)"
         elif name.startswith("ira_band_irfft") and nb3:
             b = float(a.batch) * (16.0 * (n // 2 + 1) + nb3 * 4.0 * n)
             what = f"per channel: 16(n/2+1) spectrum in + {nb3} band signals x 4n out bytes"

@@ -6,8 +6,8 @@ out=$1; batch=${2:-64}
 R=$GRAFT_REPO_ROOT
 mkdir -p "$R/$out"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$out/stats" -- python3 "$R/bench.py" --steps 3 --warmup 1 --batch $batch --no-cpu-baseline > "$R/$out/stats.log" 2>&1 || echo "stats pass failed" >> "$R/$out/fail.log"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$out/stats" -- python3 "$R/bench.py" --steps 3 --warmup 1 --batch $batch --no-cpu-baseline --literal-steps 0 > "$R/$out/stats.log" 2>&1 || echo "stats pass failed" >> "$R/$out/fail.log"
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$R/$out/$c" -- python3 "$R/bench.py" --steps 2 --warmup 1 --batch $batch --no-cpu-baseline > "$R/$out/$c.log" 2>&1 || echo "$c pass failed" >> "$R/$out/fail.log"
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$R/$out/$c" -- python3 "$R/bench.py" --steps 2 --warmup 1 --batch $batch --no-cpu-baseline --literal-steps 0 > "$R/$out/$c.log" 2>&1 || echo "$c pass failed" >> "$R/$out/fail.log"
 done
 python3 "$R/tools/traffic_from_pmc.py" "$R/$out" $batch

@@ -16,6 +16,9 @@ def call_of(kernel, last_fft):
     if "stft3_kernel" in k: return "ira_stft_mag_db[f32,n4096]", last_fft
     if "stft2_kernel<double, 2" in k: return "ira_stft_mag_db[f64,n8192]", last_fft
     if "stft2_kernel<double, 1" in k: return "ira_stft_mag_db[f64,n4096,sel]", last_fft
+    if "smooth_cols_kernel<0>" in k: return "ira_rfft_smooth", "ira_rfft_smooth"
+    if "smooth_cols_kernel<1>" in k: return "ira_band_irfft_smooth", "ira_band_irfft_smooth"
+    if "smooth_rows_kernel" in k or "smooth_pair_split" in k: return last_fft, last_fft
     if "cols_fwd_kernel<0>" in k: return "ira_rfft_any", "ira_rfft_any"
     if "cols_fwd_kernel<2>" in k: return "ira_band_irfft", "ira_band_irfft"
     if "cols_fwd_kernel<1>" in k: return "ira_bluestein_filter", "ira_bluestein_filter"
@@ -25,6 +28,8 @@ def call_of(kernel, last_fft):
     if "edc_" in k: return "ira_edc_db", last_fft
     if "curve_fit" in k: return "ira_curve_fits", last_fft
     if "logbin" in k: return "ira_logbin_aggregate", last_fft
+    if "diffusion" in k: return "ira_diffusion", last_fft
+    if "order_stats" in k: return "ira_order_stats", last_fft
     return None, last_fft
 
 
