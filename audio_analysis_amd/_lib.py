@@ -33,7 +33,7 @@ PROTOTYPES = {
     "ira_fft_split": (i32, [i32, vp, vp]),
     "ira_bluestein_filter": (i32, [vp, i32, i32, vp, vp, vp, vp, vp]),
     "ira_rfft_any": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp,
-                           vp]),
+                           vp, vp]),
     "ira_band_irfft": (i32, [vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "ira_spectrum_mag_phase": (i32, [vp, vp, vp, i32, i32, f64, vp, vp, vp, vp, vp]),
     "ira_phase_unwrap": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),

@@ -115,6 +115,9 @@ struct Jobs {
   // built for its OWN length (reference group_delay.py:95-109).
   const int32_t* data_len; const int32_t* win_len;
   const int32_t* data_len2; const int32_t* win_len2;
+  // optional: 1 = the two "signals" of element e are the EVEN and ODD samples of ONE real signal (x2off = xoff + 1,
+  // both read with stride 2; Hann index 2n / 2n+1): a real transform of even length 2L as one complex transform of L
+  const int32_t* interleave;
   // masked-spectrum input
   const cd* spec;           // half spectra, complex f64
   const int64_t* spec_off;  // element e reads spec + spec_off[e], (L/2+1) bins
@@ -146,9 +149,10 @@ __device__ __forceinline__ cd gen_input(const Jobs& J, int e, long long n, long 
                                         double h2, long long nd1, long long nd2) {
   if (MODE == IN_SIGNAL) {
     if (n >= L) return {0.0, 0.0};
-    double v = n < nd1 ? (double)J.x[J.xoff[e] + n] : 0.0;
+    const long long st = (J.interleave && J.interleave[e]) ? 2 : 1;
+    double v = n < nd1 ? (double)J.x[J.xoff[e] + st * n] : 0.0;
     const long long o2 = J.x2off ? J.x2off[e] : -1;
-    double v2 = (o2 >= 0 && n < nd2) ? (double)J.x[o2 + n] : 0.0;
+    double v2 = (o2 >= 0 && n < nd2) ? (double)J.x[o2 + st * n] : 0.0;
     if (J.use_hann) {
       v *= h; v2 *= h2;
     }
@@ -234,13 +238,16 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       d = unit_q(2 * n0 * dn + dn * dn, L);
       e2 = unit_q(2 * dn * dn, L);
       if (MODE == IN_SIGNAL && J.use_hann) {
+        // window index of transform index n: n (plain), or 2n / 2n+1 for the even / odd samples of an interleaved job
+        const long long st = (J.interleave && J.interleave[e]) ? 2 : 1;
+        const long long i1 = st * n0, i2 = st * n0 + (st - 1);
         if (lw1 > 1) {
-          sincospi((double)(2 * n0 + 1 - lw1) / (double)(lw1 - 1), &hs, &hc);
-          sincospi((double)(2 * dn) / (double)(lw1 - 1), &rs, &rc);
+          sincospi((double)(2 * i1 + 1 - lw1) / (double)(lw1 - 1), &hs, &hc);
+          sincospi((double)(2 * st * dn) / (double)(lw1 - 1), &rs, &rc);
         }
         if (lw2 > 1) {
-          sincospi((double)(2 * n0 + 1 - lw2) / (double)(lw2 - 1), &hs2, &hc2);
-          sincospi((double)(2 * dn) / (double)(lw2 - 1), &rs2, &rc2);
+          sincospi((double)(2 * i2 + 1 - lw2) / (double)(lw2 - 1), &hs2, &hc2);
+          sincospi((double)(2 * st * dn) / (double)(lw2 - 1), &rs2, &rc2);
         }
       }
     }
@@ -367,7 +374,7 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 // k = 0 and k = L/2 pair a bin with itself, so their imaginary parts come out exactly zero like numpy's rfft.
 __global__ __launch_bounds__(256) void pair_split_kernel(Jobs J) {
   const int e = blockIdx.y;
-  if (J.x2off[e] < 0) return;
+  if (J.x2off[e] < 0 || (J.interleave && J.interleave[e])) return;
   const long long L = J.L[e];
   const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (k > L / 2) return;
@@ -375,6 +382,25 @@ __global__ __launch_bounds__(256) void pair_split_kernel(Jobs J) {
   const cd zk = z[k], zl = z[k == 0 ? 0 : L - k];
   J.spec_out[J.spec_out_off[e] + k] = {0.5 * (zk.re + zl.re), 0.5 * (zk.im - zl.im)};
   J.spec_out[J.spec_out_off2[e] + k] = {0.5 * (zk.im + zl.im), 0.5 * (zl.re - zk.re)};
+}
+
+// Interleaved jobs: z[m] = x[2m] + i x[2m+1], Z = DFT_L(z); the real signal's spectrum of length 2L is
+//   X[k] = E[k] + W_2L^k O[k],  E = (Z[k] + conj Z[L-k]) / 2,  O = (Z[k] - conj Z[L-k]) / (2i),  k = 0 .. L  (Z index mod L)
+__global__ __launch_bounds__(256) void half_split_kernel(Jobs J) {
+  const int e = blockIdx.y;
+  if (!J.interleave[e]) return;
+  const long long L = J.L[e];
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > L) return;
+  const cd* z = J.zpair + J.zpair_off[e];
+  const cd zk = z[k == L ? 0 : k], zl = z[(k == 0 || k == L) ? 0 : L - k];
+  const cd ev = {0.5 * (zk.re + zl.re), 0.5 * (zk.im - zl.im)};
+  const cd od = {0.5 * (zk.im + zl.im), 0.5 * (zl.re - zk.re)};
+  double sn, cs;
+  sincospi(-(double)k / (double)L, &sn, &cs);                 // W_2L^k = exp(-i pi k / L)
+  cd x = {ev.re + (cs * od.re - sn * od.im), ev.im + (cs * od.im + sn * od.re)};
+  if (k == 0 || k == L) x.im = 0.0;                            // DC / Nyquist of a real signal
+  J.spec_out[J.spec_out_off[e] + k] = x;
 }
 
 // M = N1 x N2.  The column passes (K1, K3) touch C adjacent columns of every row, i.e. C*16-byte pieces at a stride
@@ -475,7 +501,7 @@ extern "C" int32_t ira_rfft_any(const float* x_dev, const int64_t* xoff_dev, con
                                 const int64_t* x2off_dev, const int64_t* spec_off2_dev, double* zpair_dev,
                                 const int64_t* zpair_off_dev, int32_t max_len, const int32_t* data_len_dev,
                                 const int32_t* win_len_dev, const int32_t* data_len2_dev,
-                                const int32_t* win_len2_dev, void* stream) {
+                                const int32_t* win_len2_dev, const int32_t* interleave_dev, void* stream) {
   IRA_CHECK_PTR(x_dev); IRA_CHECK_PTR(xoff_dev); IRA_CHECK_PTR(L_dev); IRA_CHECK_PTR(t1_dev); IRA_CHECK_PTR(t2_dev);
   IRA_CHECK_PTR(tf_dev); IRA_CHECK_PTR(bfilt_dev); IRA_CHECK_PTR(bidx_dev); IRA_CHECK_PTR(work_dev);
   IRA_CHECK_PTR(spec_out_dev); IRA_CHECK_PTR(spec_off_dev);
@@ -488,6 +514,8 @@ extern "C" int32_t ira_rfft_any(const float* x_dev, const int64_t* xoff_dev, con
   J.bfilt = reinterpret_cast<const cd*>(bfilt_dev); J.bidx = bidx_dev;
   J.spec_out = reinterpret_cast<cd*>(spec_out_dev); J.spec_out_off = spec_off_dev;
   J.data_len = data_len_dev; J.win_len = win_len_dev; J.data_len2 = data_len2_dev; J.win_len2 = win_len2_dev;
+  if (interleave_dev != nullptr && x2off_dev == nullptr) return IRA_E_NULL;
+  J.interleave = interleave_dev;
   if (x2off_dev != nullptr) {
     if (spec_off2_dev == nullptr || zpair_dev == nullptr || zpair_off_dev == nullptr) return IRA_E_NULL;
     if (max_len <= 0) return IRA_E_SIZE;
@@ -497,6 +525,8 @@ extern "C" int32_t ira_rfft_any(const float* x_dev, const int64_t* xoff_dev, con
   rc = run_convolution<IN_SIGNAL, OUT_SPECTRUM>(p, J, reinterpret_cast<cd*>(work_dev), nb, (hipStream_t)stream);
   if (rc != IRA_OK || x2off_dev == nullptr) return rc;
   pair_split_kernel<<<dim3((max_len / 2 + 1 + 255) / 256, nb), 256, 0, (hipStream_t)stream>>>(J);
+  if (interleave_dev != nullptr)
+    half_split_kernel<<<dim3((max_len + 1 + 255) / 256, nb), 256, 0, (hipStream_t)stream>>>(J);
   IRA_RETURN_LAUNCH();
 }
 

@@ -465,6 +465,9 @@ class Engine:
     # band of one channel shares an inverse transform with the odd band of another.  Set False to force one
     # transform per signal / per channel band pair (A/B switch; results agree to ~1e-16 of the larger signal).
     pair_real_ffts = True
+    # A real signal of EVEN (non-smooth) length L is transformed as the complex sequence x[2m] + i*x[2m+1] of length
+    # L/2 (half the Bluestein convolution size) and split with a twiddle.  Set False for an A/B.
+    half_real_ffts = True
 
     @staticmethod
     def _pair_by_key(idx: np.ndarray, keys: np.ndarray):
@@ -537,38 +540,54 @@ class Engine:
             return spec, spec_off
         rest_idx = np.nonzero(rest)[0]
         # ---- everything else: Bluestein, grouped by the power-of-two convolution size ------------------------------------
-        for lm, sub in self._chunks_by_log2m(lengths[rest_idx]):
-            idx = rest_idx[sub]
+        # Jobs: "half" = one real signal of EVEN length carried as x[2m] + i*x[2m+1] (a complex transform of L/2: half
+        # the convolution size); "pair" = two signals of equal length as x1 + i*x2; "single".
+        use_half = self.half_real_ffts and not padded
+        lr = lengths[rest_idx]
+        is_half = ((lr % 2 == 0) & (lr >= 8)) if use_half else np.zeros(rest_idx.size, dtype=bool)
+        others = rest_idx[~is_half]
+        if self.pair_real_ffts and others.size > 1:
+            p1, p2 = self._pair_by_key(others, lengths)
+        else:
+            p1, p2 = others.astype(np.int64), np.full(others.size, -1, dtype=np.int64)
+        e1 = np.concatenate([rest_idx[is_half].astype(np.int64), p1])
+        e2 = np.concatenate([np.full(int(is_half.sum()), -1, dtype=np.int64), p2])
+        half = np.concatenate([np.ones(int(is_half.sum()), dtype=bool), np.zeros(p1.size, dtype=bool)])
+        jlen = np.where(half, lengths[e1] // 2, lengths[e1]).astype(np.int32)        # transform length of the job
+        for lm, sel in self._chunks_by_log2m(jlen):
             t1, t2, tf = self.long_tables(lm)
-            if self.pair_real_ffts and idx.size > 1:
-                j1, j2 = self._pair_by_key(idx, lengths)
-            else:
-                j1, j2 = idx.astype(np.int64), np.full(idx.size, -1, dtype=np.int64)
-            jl = lengths[j1]
+            j1, j2, jh, jl = e1[sel], e2[sel], half[sel], jlen[sel]
             bf, bidx = self._filters(jl, lm)
-            work = self.empty(int(j1.size) * (2 << lm), t.float64)
+            work = self.empty(int(sel.size) * (2 << lm), t.float64)
             d_xo, d_l = self.to_dev(xoff[j1]), self.to_dev(jl)
             d_bi, d_so = self.to_dev(bidx), self.to_dev(spec_off[j1])
             paired = j2 >= 0
+            two = paired | jh                                   # jobs that carry a second "signal"
             safe = np.maximum(j2, 0)
-            if paired.any():
-                d_x2 = self.to_dev(np.where(paired, xoff[safe], -1).astype(np.int64))
+            if two.any():
+                x2 = np.where(jh, xoff[j1] + 1, np.where(paired, xoff[safe], -1))
+                d_x2 = self.to_dev(x2.astype(np.int64))
                 d_so2 = self.to_dev(np.where(paired, spec_off[safe], 0).astype(np.int64))
-                zlen = np.where(paired, jl.astype(np.int64), 0)
-                zoff = np.zeros(j1.size, dtype=np.int64)
-                zoff[1:] = np.cumsum(zlen[:-1])
+                zlen = np.where(two, jl.astype(np.int64), 0)
+                zoff = np.cumsum(zlen) - zlen
                 zpair = self.empty(int(zlen.sum()) * 2, t.float64)
-                d_zo = self.to_dev(zoff)
+                d_zo = self.to_dev(zoff.astype(np.int64))
             else:
                 d_x2 = d_so2 = zpair = d_zo = None
-            d_dl = d_wl = d_dl2 = d_wl2 = None
+            d_dl = d_wl = d_dl2 = d_wl2 = d_il = None
             if padded:
                 d_dl, d_wl = self.to_dev(data_len[j1]), self.to_dev(win_len[j1])
                 d_dl2, d_wl2 = self.to_dev(data_len[safe]), self.to_dev(win_len[safe])
-            check(self.lib.ira_rfft_any(_ptr(x_dev), _ptr(d_xo), _ptr(d_l), int(j1.size), 1 if use_hann else 0, lm,
+            elif jh.any():
+                wl = np.where(jh, lengths[j1], jl).astype(np.int32)       # the Hann window belongs to the REAL signal
+                d_dl, d_wl = self.to_dev(jl), self.to_dev(wl)
+                d_dl2, d_wl2 = d_dl, d_wl
+                d_il = self.to_dev(jh.astype(np.int32))
+            check(self.lib.ira_rfft_any(_ptr(x_dev), _ptr(d_xo), _ptr(d_l), int(sel.size), 1 if use_hann else 0, lm,
                                         _ptr(t1), _ptr(t2), _ptr(tf), _ptr(bf), _ptr(d_bi), _ptr(work), _ptr(spec),
                                         _ptr(d_so), _ptr(d_x2), _ptr(d_so2), _ptr(zpair), _ptr(d_zo), int(jl.max()),
-                                        _ptr(d_dl), _ptr(d_wl), _ptr(d_dl2), _ptr(d_wl2), self.stream), "ira_rfft_any")
+                                        _ptr(d_dl), _ptr(d_wl), _ptr(d_dl2), _ptr(d_wl2), _ptr(d_il), self.stream),
+                  "ira_rfft_any")
         return spec, spec_off
 
     def band_irfft(self, spec_dev, spec_off: np.ndarray, lengths: np.ndarray, band_params: np.ndarray,

@@ -132,7 +132,11 @@ int32_t ira_bluestein_filter(const int32_t* L_dev, int32_t nfilt, int32_t log2m,
  * Zero-padded / truncated transforms, numpy.fft.rfft(x * hanning(len(x)), n=L) (reference
  * analyse/group_delay.py:95-109): data_len_dev[e] (may be NULL = L[e]) samples are read, the rest of the L[e]
  * inputs are zero (data_len > L truncates), and the Hann window is the one of length win_len_dev[e] (NULL =
- * L[e]); data_len2_dev / win_len2_dev (NULL = same as the first) apply to the second signal of a pair. */
+ * L[e]); data_len2_dev / win_len2_dev (NULL = same as the first) apply to the second signal of a pair.
+ * interleave_dev (may be NULL): interleave[e] = 1 makes element e ONE real signal of even length 2*L[e] carried as the
+ * complex sequence x[2m] + i*x[2m+1] (x2off_dev[e] must be xoff_dev[e] + 1, zpair scratch L[e] complex): half the
+ * transform size; its L[e]+1 spectrum bins go to spec_off_dev[e].  Window lengths then refer to the real signal
+ * (win_len = 2*L[e]). */
 int32_t ira_rfft_any(const float* x_dev, const int64_t* xoff_dev, const int32_t* L_dev, int32_t nb,
                      int32_t use_hann, int32_t log2m, const void* t1_dev, const void* t2_dev,
                      const void* tf_dev, const double* bfilt_dev, const int32_t* bidx_dev,
@@ -140,7 +144,7 @@ int32_t ira_rfft_any(const float* x_dev, const int64_t* xoff_dev, const int32_t*
                      const int64_t* x2off_dev, const int64_t* spec_off2_dev, double* zpair_dev,
                      const int64_t* zpair_off_dev, int32_t max_len, const int32_t* data_len_dev,
                      const int32_t* win_len_dev, const int32_t* data_len2_dev, const int32_t* win_len2_dev,
-                     void* stream);
+                     const int32_t* interleave_dev, void* stream);
 
 /* Band filter bank: element e takes the half spectrum at spec_dev + 2*spec_off_dev[e] (length L[e]/2+1),
  * multiplies it by TWO real masks (band_params_dev: 2 records of IRA_BAND_DOUBLES doubles per element:

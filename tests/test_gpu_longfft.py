@@ -81,6 +81,36 @@ def test_rfft_any_pairs_equal_lengths():
     assert np.max(np.abs(a1 - a2)) / np.max(np.abs(a1)) < 1e-14
 
 
+def test_even_lengths_use_the_half_size_transform_and_match_unpacked():
+    """Even, non-smooth L: one complex transform of L/2 on x[2m] + i*x[2m+1]; same spectrum as the full-size path."""
+    from audio_analysis_amd.engine import get_engine
+    eng = get_engine()
+    rng = np.random.default_rng(8)
+    n = 70000
+    chans = [(rng.standard_normal(n) * np.exp(-np.arange(n) / 9000.0)).astype(np.float32) for _ in range(4)]
+    b = eng.upload(chans)
+    lens = np.array([2 * 34613, 69994, 2 * 34613, 4 * 17 * 1021], np.int32)       # even, none of them smooth
+    assert all(eng.smooth_split(int(v)) is None for v in lens) and eng.half_real_ffts
+    for hann in (False, True):
+        spec, off = eng.rfft_any(b.x, b.off, lens, hann)
+        h = spec.cpu().numpy()
+        try:
+            eng.half_real_ffts = False
+            spec2, _ = eng.rfft_any(b.x, b.off, lens, hann)
+        finally:
+            eng.half_real_ffts = True
+        h2 = spec2.cpu().numpy()
+        for c, o, L in zip(chans, off, lens):
+            seg = c[:L].astype(np.float64)
+            ref = np.fft.rfft(seg * np.hanning(L) if hann else seg)
+            g = h[2 * o : 2 * (o + L // 2 + 1)].reshape(-1, 2)
+            err = np.max(np.abs(g[:, 0] + 1j * g[:, 1] - ref)) / np.max(np.abs(ref))
+            assert err < 5e-14, (L, hann, err)
+            assert g[0, 1] == 0.0 and g[-1, 1] == 0.0
+            g2 = h2[2 * o : 2 * (o + L // 2 + 1)].reshape(-1, 2)
+            assert np.max(np.abs(g - g2)) / np.max(np.abs(ref)) < 1e-13
+
+
 def test_smooth_lengths_take_the_direct_transform_and_match_numpy():
     """n = 2^a 3^b 5^c: two-pass mixed-radix four-step (ira_rfft_smooth) against numpy and against Bluestein."""
     from audio_analysis_amd.engine import get_engine
