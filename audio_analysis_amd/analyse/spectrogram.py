@@ -74,13 +74,16 @@ def select_stft_segments(eng, batch, sample_rate_hz: int, settings, what: str):
     return starts, lens, nframes
 
 
-def spectrogram_device(eng, batch, sample_rate_hz: int, settings: "SpectrogramAnalysisSettings"):
-    """Device-resident spectrograms: flat float32 buffer of C-contiguous (F, T_i) matrices."""
+def spectrogram_device(eng, batch, sample_rate_hz: int, settings: "SpectrogramAnalysisSettings",
+                       frame_major: bool = False):
+    """Device-resident spectrograms: flat float32 buffer of C-contiguous (F, T_i) matrices -- or, with frame_major and
+    a configuration ira_stft_mag_db_tf implements, of their (T_i, F) transposes (dict key "frame_major" says which)."""
     starts, lens, nframes = select_stft_segments(eng, batch, sample_rate_hz, settings, "spectrogram")
+    tf = bool(frame_major) and eng.stft_frame_major_ok(int(settings.n_fft), stft_precision())
     mag, mag_off, cols = eng.stft_mag_db(batch.x, batch.off + starts, nframes, int(settings.n_fft),
                                          int(settings.hop_length), bool(settings.use_hann_window),
-                                         float(settings.floor_db), stft_precision())
-    return dict(mag=mag, mag_off=mag_off, cols=cols, starts=starts, lens=lens)
+                                         float(settings.floor_db), stft_precision(), frame_major=tf)
+    return dict(mag=mag, mag_off=mag_off, cols=cols, starts=starts, lens=lens, frame_major=tf)
 
 
 def analyse_spectrogram_batch(
@@ -108,7 +111,8 @@ def spectrogram_results(dev, sample_rate_hz: int, channel_names, settings) -> Li
     res = []
     for i, name in enumerate(channel_names):
         t = int(cols[i])
-        mag = host[out_off[i] : out_off[i] + f * t].reshape(f, t).copy()
+        flat = host[out_off[i] : out_off[i] + f * t]
+        mag = flat.reshape(t, f).T.copy() if dev.get("frame_major") else flat.reshape(f, t).copy()
         res.append(ChannelSpectrogramResult(
             channel_name=str(name), sample_rate_hz=int(sample_rate_hz), analysis_start_sample_index=int(starts[i]),
             analysis_length_samples=int(lens[i]), time_seconds=frame_time_axis(t, hop, sample_rate_hz),

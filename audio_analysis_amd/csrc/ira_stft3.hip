@@ -53,7 +53,7 @@ __device__ __forceinline__ float db_of(float re, float im, float floor_pow, floa
   return 3.0102999566398120f * __log2f(p);   // 10 log10(p) = 20 log10 |X|
 }
 
-template <int NT3>
+template <int NT3, bool TF>
 __global__ __launch_bounds__(64 * NT3) void stft3_kernel(
     const float* __restrict__ x, const int64_t* __restrict__ off, const int32_t* __restrict__ nframes, int hop,
     const float* __restrict__ window, const cf* __restrict__ tw, float floor_lin, float floor_db,
@@ -227,6 +227,22 @@ __global__ __launch_bounds__(64 * NT3) void stft3_kernel(
   const float mid = db_of(midr, midi, floor_pow, floor_db);
   IRA_STAMP(2);
 
+  if (TF) {
+    // Frame-major output (T, F): the frame's 2049 values are contiguous, so every wave stores its own frame straight
+    // from registers in 256-byte runs -- no tile, no workgroup barrier, no partial-line write requests.
+    if (col < T_out) {
+      float* fo = out + out_off[seg] + (int64_t)col * F3;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int k = q + 64 * i;
+        fo[k] = lo[i];
+        fo[M3 - k] = hi[i];                                   // k = 0 -> bin M (Nyquist)
+      }
+      if (q == 0) fo[M3 / 2] = mid;
+    }
+    return;
+  }
+
   __syncthreads();
   IRA_STAMP(3);   // every team is done with its exchange buffer: the tile may overwrite them
   float* tile = reinterpret_cast<float*>(smem_raw);      // [F][TB + 1]
@@ -271,22 +287,22 @@ __global__ __launch_bounds__(64 * NT3) void stft3_kernel(
 }
 
 // float32 / n_fft 4096 only; anything else returns IRA_E_UNSUPPORTED and the caller falls through to v2 / v1.
-template <int NT3>
+template <int NT3, bool TF>
 int32_t launch3(const float* x, const int64_t* off, const int32_t* nframes, int32_t nseg, int32_t max_frames,
                 int32_t hop, const void* window, const void* tw, double floor_db, float* out, const int64_t* out_off,
                 const int32_t* frame_sel, const int64_t* sel_off, hipStream_t st) {
   constexpr int TB3 = NT3;
   constexpr size_t lds_ex = (size_t)NT3 * EXC * sizeof(cf);
   constexpr size_t lds_tile = (size_t)F3 * (TB3 + 1) * sizeof(float);
-  constexpr size_t lds = lds_ex > lds_tile ? lds_ex : lds_tile;
+  constexpr size_t lds = TF ? lds_ex : (lds_ex > lds_tile ? lds_ex : lds_tile);
   static_assert(lds <= 160 * 1024, "one workgroup must fit the CU's LDS");
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&stft3_kernel<NT3>),
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&stft3_kernel<NT3, TF>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (attr != hipSuccess) return ira_hip_status(attr);
   const double floor_lin = std::pow(10.0, floor_db / 20.0);
   static const int ablate = std::getenv("IRA_STFT3_ABLATE") ? std::atoi(std::getenv("IRA_STFT3_ABLATE")) : 0;   // diagnostics
   dim3 grid((max_frames + TB3 - 1) / TB3, nseg);
-  stft3_kernel<NT3><<<grid, 64 * NT3, lds, st>>>(x, off, nframes, hop, static_cast<const float*>(window),
+  stft3_kernel<NT3, TF><<<grid, 64 * NT3, lds, st>>>(x, off, nframes, hop, static_cast<const float*>(window),
                                             static_cast<const cf*>(tw), (float)floor_lin, (float)floor_db, out,
                                             out_off, frame_sel, sel_off, ablate);
   IRA_RETURN_LAUNCH();
@@ -301,8 +317,17 @@ int32_t ira_stft3_dispatch(const float* x, const int64_t* off, const int32_t* nf
   if (precision != 32 || n_fft != 4096) return IRA_E_UNSUPPORTED;
   static const int nt = std::getenv("IRA_STFT3_NT") ? std::atoi(std::getenv("IRA_STFT3_NT")) : 16;   // tuning
   if (nt == 8)
-    return launch3<8>(x, off, nframes, nseg, max_frames, hop, window, tw, floor_db, out, out_off, frame_sel, sel_off, st);
+    return launch3<8, false>(x, off, nframes, nseg, max_frames, hop, window, tw, floor_db, out, out_off, frame_sel, sel_off, st);
   if (nt == 4)
-    return launch3<4>(x, off, nframes, nseg, max_frames, hop, window, tw, floor_db, out, out_off, frame_sel, sel_off, st);
-  return launch3<16>(x, off, nframes, nseg, max_frames, hop, window, tw, floor_db, out, out_off, frame_sel, sel_off, st);
+    return launch3<4, false>(x, off, nframes, nseg, max_frames, hop, window, tw, floor_db, out, out_off, frame_sel, sel_off, st);
+  return launch3<16, false>(x, off, nframes, nseg, max_frames, hop, window, tw, floor_db, out, out_off, frame_sel, sel_off, st);
+}
+
+// Frame-major variant: out[e] is a (T, F) matrix (each frame's F values contiguous).
+int32_t ira_stft3_dispatch_tf(const float* x, const int64_t* off, const int32_t* nframes, int32_t nseg,
+                              int32_t max_frames, int32_t n_fft, int32_t hop, const void* window, const void* tw,
+                              int32_t precision, double floor_db, float* out, const int64_t* out_off,
+                              const int32_t* frame_sel, const int64_t* sel_off, hipStream_t st) {
+  if (precision != 32 || n_fft != 4096) return IRA_E_UNSUPPORTED;
+  return launch3<16, true>(x, off, nframes, nseg, max_frames, hop, window, tw, floor_db, out, out_off, frame_sel, sel_off, st);
 }

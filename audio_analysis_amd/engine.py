@@ -299,11 +299,13 @@ class Engine:
 
     # ------------------------------------------------------------------ a11
     def stft_mag_db(self, x_dev, seg_off: np.ndarray, nframes: np.ndarray, n_fft: int, hop: int, use_hann: bool,
-                    floor_db: float, precision: int = 32, frame_sel: Optional[List[np.ndarray]] = None):
+                    floor_db: float, precision: int = 32, frame_sel: Optional[List[np.ndarray]] = None,
+                    frame_major: bool = False):
         """
         STFT magnitude (dB) of segments starting at seg_off with nframes[s] valid frames each.
         Returns (out flat f32 device, out_off host int64); out[s] is a C-contiguous (n_fft/2+1, T_s) matrix.
         frame_sel: optional per-segment arrays of frame indices (then T_s = len(frame_sel[s])).
+        frame_major=True asks for the transposed (T_s, n_fft/2+1) layout (ira_stft_mag_db_tf; see stft_frame_major_ok).
         """
         t = self.torch
         n = int(seg_off.size)
@@ -326,14 +328,18 @@ class Engine:
         out = self.empty(int(sizes.sum()), t.float32)
         d_off, d_cols, d_ooff = self.to_dev(seg_off), self.to_dev(cols), self.to_dev(out_off)
         self.event_tag = f"[f{precision},n{n_fft}{',sel' if frame_sel is not None else ''}]"
-        check(self.lib.ira_stft_mag_db(_ptr(x_dev), _ptr(d_off), _ptr(d_cols), n,
-                                       int(cols.max()) if n else 0, int(n_fft), int(hop),
-                                       _ptr(self.window(n_fft, use_hann, precision)),
-                                       _ptr(self.twiddle(n_fft, precision)), int(precision), float(floor_db),
-                                       _ptr(out), _ptr(d_ooff), _ptr(sel), _ptr(sel_off_dev),
-                                       self.stream), "ira_stft_mag_db")
+        fn = self.lib.ira_stft_mag_db_tf if frame_major else self.lib.ira_stft_mag_db
+        check(fn(_ptr(x_dev), _ptr(d_off), _ptr(d_cols), n, int(cols.max()) if n else 0, int(n_fft), int(hop),
+                 _ptr(self.window(n_fft, use_hann, precision)), _ptr(self.twiddle(n_fft, precision)), int(precision),
+                 float(floor_db), _ptr(out), _ptr(d_ooff), _ptr(sel), _ptr(sel_off_dev), self.stream),
+              "ira_stft_mag_db_tf" if frame_major else "ira_stft_mag_db")
         self.event_tag = ""
         return out, out_off, cols
+
+    @staticmethod
+    def stft_frame_major_ok(n_fft: int, precision: int) -> bool:
+        """Configurations ira_stft_mag_db_tf implements."""
+        return int(n_fft) == 4096 and int(precision) == 32
 
     # ------------------------------------------------------------------ a9/a17: arbitrary-length f64 DFTs
     workspace_budget_bytes = 48 << 30   # cap for the Bluestein work + filter arrays of one chunk

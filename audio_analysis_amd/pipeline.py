@@ -148,7 +148,8 @@ class FullReport:
                 res["filter"] = filt
                 fut["filter_stats"] = eng.fetch(filt["stats"])
         if s.run_spectrogram:
-            sp = _spec.spectrogram_device(eng, batch, sr, s.spectrogram)
+            # nothing downstream reads the matrix in this pipeline: take the frame-major layout where the kernel has it
+            sp = _spec.spectrogram_device(eng, batch, sr, s.spectrogram, frame_major=True)
             res["spectrogram"] = sp
             m[:, M_SPEC_FRAMES] = sp["cols"]
         if s.run_waterfall:

@@ -186,7 +186,7 @@ def main():
         step_ms = tot[name] / a.steps
         launches = len(ev[name]) / a.steps
         nb3 = 3 if settings.rt60_bands.band_mode == "three" else None
-        if name.startswith("ira_stft_mag_db[f32"):
+        if name.startswith("ira_stft_mag_db") and "[f32" in name:
             b = stft_bytes(settings.spectrogram.n_fft, settings.spectrogram.hop_length)
             what = "4L in + 4*F*T out bytes per channel"
         elif name.startswith("ira_stft_mag_db[f64,n%d]" % settings.modal_cloud.n_fft):
@@ -221,7 +221,7 @@ def main():
                 # measured L2<->fabric traffic of the call divided by its time (what the memory system actually moved)
                 "traffic_GBps": None if tr is None else tr / (step_ms * 1e-3) / 1e9}
 
-    stft_name = next((k for k in tot if k.startswith("ira_stft_mag_db[f32")), None)
+    stft_name = next((k for k in tot if k.startswith("ira_stft_mag_db") and "[f32" in k), None)
     out = {
         "metric": "IRs/sec full report (STFT+RT60bands+zplane), 48 kHz 10 s IR",
         "value": total_irs / elapsed,

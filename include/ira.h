@@ -104,6 +104,16 @@ int32_t ira_stft_mag_db(const float* x_dev, const int64_t* off_dev, const int32_
                         double floor_db, float* out_dev, const int64_t* out_off_dev,
                         const int32_t* frame_sel_dev, const int64_t* sel_off_dev, void* stream);
 
+/* Same transform, FRAME-MAJOR output: out[e] is a (T_e, n_fft/2+1) matrix, i.e. the transpose of the reference's
+ * (F, T) array -- every frame's bins are contiguous, which lets each wave store its frame directly (no transposing
+ * tile, no partial-line writes).  For device-resident consumers and hosts that take a `.T` view.  Currently
+ * precision 32 / n_fft 4096 only; anything else returns IRA_E_UNSUPPORTED (use ira_stft_mag_db). */
+int32_t ira_stft_mag_db_tf(const float* x_dev, const int64_t* off_dev, const int32_t* nframes_dev,
+                           int32_t nseg, int32_t max_frames, int32_t n_fft, int32_t hop,
+                           const void* window_dev, const void* twiddle_dev, int32_t precision,
+                           double floor_db, float* out_dev, const int64_t* out_off_dev,
+                           const int32_t* frame_sel_dev, const int64_t* sel_off_dev, void* stream);
+
 /* ---- a9/a17: arbitrary-length float64 DFTs (Bluestein over a four-step power-of-two FFT) ---------------
  * Common arguments: log2m with M = 2^log2m >= 2*max(L) - 1 (4 <= log2m <= 22); three caller-provided
  * complex-f64 tables for M = N1*N2 with the split ira_fft_split() reports (N1 = 2^log2n1, N2 = 2^log2n2):

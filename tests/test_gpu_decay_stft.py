@@ -153,3 +153,23 @@ def test_batch_matches_oracle_ragged():
             assert _rel(r.fits[k].rt60_seconds, o["fits"][k]["rt60"]) < 1e-6
         os_ = O.analyse_spectrogram(x, SR)
         _stft_check(s.magnitude_db, os_["magnitude_db"])
+
+
+def test_frame_major_stft_is_the_exact_transpose(golden):
+    """ira_stft_mag_db_tf (f32 / 4096): same arithmetic as the (F, T) kernel, stored frame by frame."""
+    from audio_analysis_amd.analyse import spectrogram as sp
+    from audio_analysis_amd.engine import get_engine
+    from audio_analysis_amd.synth import synth_ir
+    eng = get_engine()
+    chans = [synth_ir(400 + i, 0, 30000 + 777 * i, rt60_seconds=0.3) for i in range(3)]
+    b = eng.upload(chans)
+    st = sp.SpectrogramAnalysisSettings()
+    a = sp.spectrogram_results(sp.spectrogram_device(eng, b, SR, st), SR, list("abc"), st)
+    dev_tf = sp.spectrogram_device(eng, b, SR, st, frame_major=True)
+    assert dev_tf["frame_major"]
+    t = sp.spectrogram_results(dev_tf, SR, list("abc"), st)
+    for ra, rt in zip(a, t):
+        np.testing.assert_array_equal(ra.magnitude_db, rt.magnitude_db)
+    # unsupported configuration falls back to the reference layout
+    st2 = sp.SpectrogramAnalysisSettings(n_fft=2048, hop_length=256)
+    assert not sp.spectrogram_device(eng, b, SR, st2, frame_major=True)["frame_major"]
