@@ -47,7 +47,7 @@ PROTOTYPES = {
     "ira_diffusion_stereo": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
     "ira_spectrum_stats": (i32, [vp, vp, vp, i32, vp, f64, f64, f64, vp, vp]),
     "ira_waterfall_rel": (i32, [vp, vp, vp, i32, i32, i32, i32, f64, vp, vp, vp]),
-    "ira_logbin_aggregate": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp]),
+    "ira_logbin_aggregate": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp]),
     "ira_ar_partial_doubles": (C.c_int64, [i32, i32]),
     "ira_ar_gram": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
     "ira_ar_solve": (i32, [vp, vp, i32, i32, i32, f64, vp, vp, vp, vp]),

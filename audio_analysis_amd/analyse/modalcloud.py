@@ -146,9 +146,12 @@ def modal_cloud_device(eng, batch, sample_rate_hz: int, settings: ModalCloudAnal
     centres, first, count = log_bin_rows(freq[rows], edges)
     nbins = int(centres.size)
 
+    # the STFT matrix is only an intermediate here: take the frame-major layout where the library has it (8192 / f64)
+    tf = eng.stft_frame_major_ok(n_fft, 64)
     mag, mag_off, cols = eng.stft_mag_db(batch.x, batch.off + starts, nframes, n_fft, hop,
-                                         bool(settings.use_hann_window), float(settings.floor_db), 64)
-    curves, cur_off = eng.logbin_aggregate(mag, mag_off, cols, k_base, first, count)
+                                         bool(settings.use_hann_window), float(settings.floor_db), 64, frame_major=tf)
+    curves, cur_off = eng.logbin_aggregate(mag, mag_off, cols, k_base, first, count,
+                                           frame_major_rows=(n_fft // 2 + 1) if tf else 0)
     c_off = np.concatenate([cur_off[i] + np.arange(nbins, dtype=np.int64) * int(cols[i]) for i in range(batch.count)])
     c_len = np.concatenate([np.full(nbins, int(cols[i]), dtype=np.int64) for i in range(batch.count)])
     fits, _ = eng.curve_fits(curves, c_off, c_len, float(hop), float(sample_rate_hz),

@@ -30,6 +30,7 @@ SOURCES = {
     "ira_stft.hip": ["-fno-slp-vectorize"],
     "ira_stft2.hip": ["-fno-slp-vectorize"],
     "ira_stft3.hip": ["-fno-slp-vectorize"],
+    "ira_stft4.hip": [],
     "ira_fftlong.hip": [],
     "ira_fftsmooth.hip": [],
     "ira_spectrum.hip": ["-ffp-contract=off"],

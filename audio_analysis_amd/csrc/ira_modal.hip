@@ -99,6 +99,48 @@ __global__ void logbin_kernel(const float* __restrict__ mag, const int64_t* __re
   o[t] = (float)(20.0 * log10(mean));
 }
 
+// Same aggregation on a FRAME-MAJOR (T, F) matrix (ira_stft_mag_db_tf).  One workgroup per frame: the frame's rows
+// (contiguous) are converted to linear magnitude in parallel into LDS, then thread b adds the rows of log bin b in
+// ascending order (the reference's numpy axis-0 mean adds rows in that order).
+constexpr int LBT_THREADS = 256;
+constexpr int LBT_MAX_ROWS = 8193;            // n_fft <= 16384
+
+__global__ __launch_bounds__(LBT_THREADS) void logbin_tf_kernel(
+    const float* __restrict__ mag, const int64_t* __restrict__ mag_off, const int32_t* __restrict__ nfr, int nrows,
+    int k_base, int k_span, const int32_t* __restrict__ first, const int32_t* __restrict__ count, int nbins,
+    float* __restrict__ out, const int64_t* __restrict__ out_off) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* lin = reinterpret_cast<double*>(smem_raw);        // k_span doubles: rows k_base .. k_base + k_span - 1
+  const int e = blockIdx.y;
+  const int T = nfr[e];
+  const int t = blockIdx.x;
+  if (t >= T) return;
+  const float* m = mag + mag_off[e] + (int64_t)t * nrows + k_base;
+  for (int k = threadIdx.x; k < k_span; k += LBT_THREADS) lin[k] = exp10((double)m[k] * 0.05);
+  __syncthreads();
+  float* o = out + out_off[e];
+  for (int b = threadIdx.x; b < nbins; b += LBT_THREADS) {
+    const int c = count[b];
+    float v = __uint_as_float(0x7fc00000u);
+    if (c > 0) {
+      const double* r = lin + first[b];
+      double acc = r[0];
+      // eight LDS reads in flight, then the adds in row order (one read per add would serialise on the LDS latency)
+      for (int k0 = 1; k0 < c; k0 += 8) {
+        double v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v8[u] = (k0 + u < c) ? r[k0 + u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (k0 + u < c) acc += v8[u];
+      }
+      const double mean = fmax(acc / (double)c, 1e-30);
+      v = (float)(20.0 * log10(mean));
+    }
+    o[(int64_t)b * T + t] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" int32_t ira_waterfall_rel(const float* mag_dev, const int64_t* mag_off_dev, const int32_t* nslices_dev,
@@ -116,11 +158,26 @@ extern "C" int32_t ira_waterfall_rel(const float* mag_dev, const int64_t* mag_of
 extern "C" int32_t ira_logbin_aggregate(const float* mag_dev, const int64_t* mag_off_dev, const int32_t* nframes_dev,
                                         int32_t nb, int32_t max_frames, int32_t k_base, const int32_t* first_dev,
                                         const int32_t* count_dev, int32_t nbins, float* out_dev,
-                                        const int64_t* out_off_dev, void* stream) {
+                                        const int64_t* out_off_dev, int32_t frame_major_rows, void* stream) {
   IRA_CHECK_PTR(mag_dev); IRA_CHECK_PTR(mag_off_dev); IRA_CHECK_PTR(nframes_dev); IRA_CHECK_PTR(first_dev);
   IRA_CHECK_PTR(count_dev); IRA_CHECK_PTR(out_dev); IRA_CHECK_PTR(out_off_dev);
   if (nb <= 0 || nbins <= 0 || max_frames <= 0) return (nb == 0 || nbins == 0 || max_frames == 0) ? IRA_OK : IRA_E_SIZE;
   if (nbins > 65535 || nb > 65535) return IRA_E_SIZE;
+  if (frame_major_rows > 0) {
+    if (frame_major_rows > LBT_MAX_ROWS || k_base < 0 || k_base >= frame_major_rows) return IRA_E_SIZE;
+    // rows the bins can touch: first/count live on the device, so take everything from k_base to the last row
+    const int k_span = frame_major_rows - k_base;
+    const size_t lds = sizeof(double) * (size_t)k_span;
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&logbin_tf_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return ira_hip_status(e);
+    }
+    logbin_tf_kernel<<<dim3(max_frames, nb), LBT_THREADS, lds, (hipStream_t)stream>>>(
+        mag_dev, mag_off_dev, nframes_dev, frame_major_rows, k_base, k_span, first_dev, count_dev, nbins, out_dev,
+        out_off_dev);
+    IRA_RETURN_LAUNCH();
+  }
   const int threads = 64;
   logbin_kernel<<<dim3((max_frames + threads - 1) / threads, nbins, nb), threads, 0, (hipStream_t)stream>>>(
       mag_dev, mag_off_dev, nframes_dev, k_base, first_dev, count_dev, nbins, out_dev, out_off_dev);

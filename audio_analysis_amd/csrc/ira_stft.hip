@@ -172,6 +172,11 @@ int32_t ira_stft3_dispatch_tf(const float* x, const int64_t* off, const int32_t*
                               int32_t precision, double floor_db, float* out, const int64_t* out_off,
                               const int32_t* frame_sel, const int64_t* sel_off, hipStream_t st);
 
+int32_t ira_stft4_dispatch_tf(const float* x, const int64_t* off, const int32_t* nframes, int32_t nseg,
+                              int32_t max_frames, int32_t n_fft, int32_t hop, const void* window, const void* tw,
+                              int32_t precision, double floor_db, float* out, const int64_t* out_off,
+                              const int32_t* frame_sel, const int64_t* sel_off, hipStream_t st);
+
 extern "C" int32_t ira_stft_mag_db_tf(const float* x_dev, const int64_t* off_dev, const int32_t* nframes_dev,
                                       int32_t nseg, int32_t max_frames, int32_t n_fft, int32_t hop,
                                       const void* window_dev, const void* twiddle_dev, int32_t precision,
@@ -182,7 +187,12 @@ extern "C" int32_t ira_stft_mag_db_tf(const float* x_dev, const int64_t* off_dev
   if (frame_sel_dev != nullptr && sel_off_dev == nullptr) return IRA_E_NULL;
   if (nseg < 0 || max_frames < 0 || hop <= 0) return IRA_E_SIZE;
   if (nseg == 0 || max_frames == 0) return IRA_OK;
-  return ira_stft3_dispatch_tf(x_dev, off_dev, nframes_dev, nseg, max_frames, n_fft, hop, window_dev, twiddle_dev,
+  if (nseg > 65535) return IRA_E_SIZE;
+  const int32_t rc = ira_stft3_dispatch_tf(x_dev, off_dev, nframes_dev, nseg, max_frames, n_fft, hop, window_dev,
+                                           twiddle_dev, precision, floor_db, out_dev, out_off_dev, frame_sel_dev,
+                                           sel_off_dev, (hipStream_t)stream);
+  if (rc != IRA_E_UNSUPPORTED) return rc;
+  return ira_stft4_dispatch_tf(x_dev, off_dev, nframes_dev, nseg, max_frames, n_fft, hop, window_dev, twiddle_dev,
                                precision, floor_db, out_dev, out_off_dev, frame_sel_dev, sel_off_dev,
                                (hipStream_t)stream);
 }

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64 * NT3) void stft3_kernel(
     const float* __restrict__ x, const int64_t* __restrict__ off, const int32_t* __restrict__ nframes, int hop,
     const float* __restrict__ window, const cf* __restrict__ tw, float floor_lin, float floor_db,
     float* __restrict__ out, const int64_t* __restrict__ out_off, const int32_t* __restrict__ frame_sel,
-    const int64_t* __restrict__ sel_off, int ablate) {
+    const int64_t* __restrict__ sel_off, int ablate, unsigned win_lds_off) {
   constexpr int TB3 = NT3;   // one frame per team -> NT3 output columns per workgroup
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // XCD-aware bijective remap: each XCD (own L2) gets a contiguous range of (segment, frame group) pairs, so the
@@ -84,6 +84,11 @@ __global__ __launch_bounds__(64 * NT3) void stft3_kernel(
 #define IRA_STAMP(i) do { if (ablate & 128) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); st[i] = t_; } } while (0)
   IRA_STAMP(0);
   float* exf = reinterpret_cast<float*>(ex);
+  // The Hann window (16 KB) is the same for every frame: one copy in LDS per workgroup instead of 16 KB of L1 traffic
+  // per frame (the frame loads were L1-bound).  Lives behind the exchange buffers / tile.
+  float* winl = reinterpret_cast<float*>(smem_raw + win_lds_off);
+  for (int i = tid; i < 2 * M3; i += 64 * NT3) winl[i] = window[i];
+  __syncthreads();
 
   const int col = col0 + team;
   // Columns past the end transform frame 0 and are dropped at the store (a per-load select makes hipcc branch
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(64 * NT3) void stft3_kernel(
     for (int n1 = 0; n1 < 16; ++n1) {
       const int n = n1 * 128 + m;
       if (ablate & 1) { xa[n1] = (float)n; xb[n1] = (float)(n + 1); } else { xa[n1] = fx[2 * n]; xb[n1] = fx[2 * n + 1]; }
-      if (ablate & 2) { wa[n1] = 0.5f; wb[n1] = 0.25f; } else { wa[n1] = window[2 * n]; wb[n1] = window[2 * n + 1]; }
+      if (ablate & 2) { wa[n1] = 0.5f; wb[n1] = 0.25f; } else { wa[n1] = winl[2 * n]; wb[n1] = winl[2 * n + 1]; }
     }
     __builtin_amdgcn_sched_barrier(0);
     cf v[16];
@@ -294,7 +299,8 @@ int32_t launch3(const float* x, const int64_t* off, const int32_t* nframes, int3
   constexpr int TB3 = NT3;
   constexpr size_t lds_ex = (size_t)NT3 * EXC * sizeof(cf);
   constexpr size_t lds_tile = (size_t)F3 * (TB3 + 1) * sizeof(float);
-  constexpr size_t lds = TF ? lds_ex : (lds_ex > lds_tile ? lds_ex : lds_tile);
+  constexpr size_t lds_main = ((TF ? lds_ex : (lds_ex > lds_tile ? lds_ex : lds_tile)) + 15) & ~(size_t)15;
+  constexpr size_t lds = lds_main + (size_t)2 * M3 * sizeof(float);          // + the window copy
   static_assert(lds <= 160 * 1024, "one workgroup must fit the CU's LDS");
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&stft3_kernel<NT3, TF>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -304,7 +310,7 @@ int32_t launch3(const float* x, const int64_t* off, const int32_t* nframes, int3
   dim3 grid((max_frames + TB3 - 1) / TB3, nseg);
   stft3_kernel<NT3, TF><<<grid, 64 * NT3, lds, st>>>(x, off, nframes, hop, static_cast<const float*>(window),
                                             static_cast<const cf*>(tw), (float)floor_lin, (float)floor_db, out,
-                                            out_off, frame_sel, sel_off, ablate);
+                                            out_off, frame_sel, sel_off, ablate, (unsigned)lds_main);
   IRA_RETURN_LAUNCH();
 }
 

@@ -1,0 +1,219 @@
+// STFT v4: float64 / n_fft = 8192 (the reference's modal-cloud default, modalcloud.py:121-158), frame-major output.
+//
+// v2 (ira_stft2.hip) keeps a whole 4096-point float64 exchange (64 KB + padding) per 2-wave team plus the transposing
+// output tile: 143 KB per workgroup, ONE workgroup = 4 waves per CU.  v4 applies the two ideas of the float32 kernel
+// (ira_stft3.hip) to this configuration:
+//   * half-size LDS exchanges (33 KB per team) -> one team per workgroup, four workgroups = 8 waves per CU;
+//   * frame-major (T, F) output -> every lane stores its 32 values of the frame directly, no tile, 512-byte runs.
+// Transform: packed real FFT, z[n] = xw[2n] + i xw[2n+1], M = 4096 = 16 * 16 * 16, DIF, n = n1*256 + n2*16 + n3,
+// k = k1 + 16 k2 + 256 k3, 128 lanes (q), 32 complex values per lane:
+//   step 1  lane m = q + 128 h (h = 0, 1): 16-point DFT over n1 from global memory, twiddle W_M^(k1 m)
+//   E1      half h at a time: [16 k1][128 m'] complex, row stride 129     -> (k1 = q & 15, n3 = (q >> 4) + 8 hb) reads n2
+//   step 2  two 16-point DFTs over n2 (hb = 0, 1), twiddle W_M^(16 k2 n3)
+//   E2      half hb at a time: k1 + 16 k2 + 256 n3' complex               -> row r = q + 128 hh = k1 + 16 k2 reads n3
+//   step 3  two 16-point DFTs over n3 -> lane holds Z[r + 256 k3]
+//   E3      natural order, real parts then imaginary parts through one 4096-double buffer
+//   post    (Z[k], Z[M-k]) -> |X[k]|, |X[N/2-k]| in dB (table log2, ira_log.h), stored at out[t*F + k]
+// 16-byte LDS accesses are served a quarter wave at a time: in every exchange the 16 lanes of a quarter differ in k1
+// (or in consecutive m), which the strides 129 and 1 map to distinct 16-byte bank groups: conflict free.
+#include <cmath>
+#include <cstdlib>
+
+#include "ira_fft_reg.h"
+#include "ira_log.h"
+
+namespace {
+
+using ira::brev_bits;
+using ira::cplx;
+using ira::dft_dif;
+using ira::powers16;
+
+typedef cplx<double> cdd;
+
+constexpr int M4 = 4096, F4 = M4 + 1, TL4 = 128;
+constexpr int ROW4 = 129;                 // E1 half: row stride (complex)
+constexpr int E2N4 = 256;                 // E2 half: n3' stride (complex)
+constexpr int EXC4 = 16 * ROW4;           // complex slots per workgroup: max(16*129, 8*256, 4096 doubles / 2)
+static_assert(EXC4 >= 8 * E2N4 && EXC4 * 2 >= M4, "exchange buffer too small");
+
+__device__ __forceinline__ float db_of4(double re, double im, double floor_pow, float floor_db,
+                                        const ira::LogTabEntry* tab) {
+  const double p = fma(re, re, im * im);
+  if (!(p > floor_pow)) return floor_db;                                       // also catches NaN
+  if (!(p < 1.0e300)) return (float)(20.0 * log10(hypot(re, im)));             // overflow / infinity: slow exact path
+  return (float)(3.0102999566398120 * ira::log2_table(p, tab));
+}
+
+__global__ __launch_bounds__(TL4) void stft4_kernel(
+    const float* __restrict__ x, const int64_t* __restrict__ off, const int32_t* __restrict__ nframes, int hop,
+    const double* __restrict__ window, const cdd* __restrict__ tw, double floor_lin, float floor_db,
+    float* __restrict__ out, const int64_t* __restrict__ out_off, const int32_t* __restrict__ frame_sel,
+    const int64_t* __restrict__ sel_off) {
+  __shared__ __attribute__((aligned(16))) cdd ex[EXC4];
+  __shared__ ira::LogTabEntry ltab[ira::LOGTAB_N];
+  // XCD-aware bijective remap: consecutive frames of a segment (which share 15/16 of their samples) meet in one L2
+  const unsigned gx = gridDim.x, nwg = gridDim.x * gridDim.y;
+  const unsigned orig = blockIdx.y * gx + blockIdx.x;
+  const unsigned xq = nwg / 8, xr = nwg % 8, xcd = orig % 8;
+  const unsigned wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + orig / 8;
+  const int seg = (int)(wg / gx);
+  const int col = (int)(wg % gx);
+  const int T_out = nframes[seg];
+  if (col >= T_out) return;
+  const int q = threadIdx.x;
+  double* exd = reinterpret_cast<double*>(ex);
+  ira::build_log_table(ltab, q);
+
+  const int64_t frame = frame_sel ? (int64_t)frame_sel[sel_off[seg] + col] : (int64_t)col;
+  const float* fx = x + off[seg] + frame * hop;
+  const int k1l = q & 15, n3a = q >> 4;
+
+  // ---- step 1 -------------------------------------------------------------------------------------------------
+  cdd a1[16];   // half h = 1, held in registers until E1 is free again
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int m = q + TL4 * h;
+    float xa[16], xb[16];
+    double wa[16], wb[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+      const int n = n1 * 256 + m;
+      xa[n1] = fx[2 * n]; xb[n1] = fx[2 * n + 1];
+      wa[n1] = window[2 * n]; wb[n1] = window[2 * n + 1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    cdd v[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) v[n1] = {(double)xa[n1] * wa[n1], (double)xb[n1] * wb[n1]};
+    dft_dif<double, 16>(v);
+    cdd p[16];
+    powers16<double>(tw[2 * m], p);                      // W_M^m = W_N^(2m)
+    if (h == 0) {
+#pragma unroll
+      for (int k1 = 0; k1 < 16; ++k1) {
+        const cdd a = v[brev_bits(k1, 4)];
+        ex[k1 * ROW4 + q] = (k1 == 0) ? a : ira::cmul(a, p[k1]);
+      }
+    } else {
+#pragma unroll
+      for (int k1 = 0; k1 < 16; ++k1) {
+        const cdd a = v[brev_bits(k1, 4)];
+        a1[k1] = (k1 == 0) ? a : ira::cmul(a, p[k1]);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- E1 -> step-2 operands: n2 = 0..7 come from half 0, n2 = 8..15 from half 1 ------------------------------------
+  cdd b2[2][16];
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+    for (int n2 = 0; n2 < 8; ++n2) b2[hb][n2] = ex[k1l * ROW4 + n2 * 16 + n3a + 8 * hb];
+  __syncthreads();
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) ex[k1 * ROW4 + q] = a1[k1];
+  __syncthreads();
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+    for (int n2 = 0; n2 < 8; ++n2) b2[hb][8 + n2] = ex[k1l * ROW4 + n2 * 16 + n3a + 8 * hb];
+  __syncthreads();
+
+  // ---- step 2 and E2 (half hb = n3 in [8hb, 8hb + 8)) -> step-3 operands ---------------------------------------------
+  cdd z3[2][16];
+  {
+    cdd p[16];
+    dft_dif<double, 16>(b2[0]);
+    powers16<double>(tw[32 * n3a], p);                   // W_M^(16 n3) = W_N^(32 n3)
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) {
+      const cdd a = b2[0][brev_bits(k2, 4)];
+      ex[k1l + 16 * k2 + E2N4 * n3a] = (k2 == 0) ? a : ira::cmul(a, p[k2]);
+    }
+    dft_dif<double, 16>(b2[1]);
+    powers16<double>(tw[32 * (n3a + 8)], p);
+#pragma unroll
+    for (int k2 = 1; k2 < 16; ++k2) b2[1][brev_bits(k2, 4)] = ira::cmul(b2[1][brev_bits(k2, 4)], p[k2]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+    for (int n3 = 0; n3 < 8; ++n3) z3[hh][n3] = ex[k1l + 16 * (n3a + 8 * hh) + E2N4 * n3];
+  __syncthreads();
+#pragma unroll
+  for (int k2 = 0; k2 < 16; ++k2) ex[k1l + 16 * k2 + E2N4 * n3a] = b2[1][brev_bits(k2, 4)];
+  __syncthreads();
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+    for (int n3 = 0; n3 < 8; ++n3) z3[hh][8 + n3] = ex[k1l + 16 * (n3a + 8 * hh) + E2N4 * n3];
+  __syncthreads();
+
+  // ---- step 3: lane holds Z[r + 256 k3], r = q + 128 hh -----------------------------------------------------------------
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) dft_dif<double, 16>(z3[hh]);
+
+  // ---- E3: real parts, then imaginary parts, natural order ------------------------------------------------------------
+  double zkr[16], zpr[16], zki[16], zpi[16], midr, midi;
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+    for (int k3 = 0; k3 < 16; ++k3) exd[q + TL4 * hh + 256 * k3] = z3[hh][brev_bits(k3, 4)].re;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int k = q + TL4 * i;
+    zkr[i] = exd[k];
+    zpr[i] = exd[(M4 - k) & (M4 - 1)];
+  }
+  midr = exd[M4 / 2];
+  __syncthreads();
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+    for (int k3 = 0; k3 < 16; ++k3) exd[q + TL4 * hh + 256 * k3] = z3[hh][brev_bits(k3, 4)].im;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int k = q + TL4 * i;
+    zki[i] = exd[k];
+    zpi[i] = exd[(M4 - k) & (M4 - 1)];
+  }
+  midi = exd[M4 / 2];
+
+  // ---- post: X[k] = E + P, X[M-k] = conj(E - P) with E = (Zk + conj Zp)/2, P = W_N^k (-i)(Zk - conj Zp)/2 ---------------
+  const double floor_pow = floor_lin * floor_lin;
+  const cdd wlane = tw[q];
+  float* fo = out + out_off[seg] + (int64_t)col * F4;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int k = q + TL4 * i;
+    const cdd e = {0.5 * (zkr[i] + zpr[i]), 0.5 * (zki[i] - zpi[i])};
+    const cdd d = {0.5 * (zkr[i] - zpr[i]), 0.5 * (zki[i] + zpi[i])};
+    const cdd o = {d.im, -d.re};
+    const cdd wk = ira::cmul(wlane, tw[TL4 * i]);        // W_N^k = W_N^q W_N^(128 i); second factor wave-uniform
+    const cdd pp = ira::cmul(wk, o);
+    fo[k] = db_of4(e.re + pp.re, e.im + pp.im, floor_pow, floor_db, ltab);
+    fo[M4 - k] = db_of4(e.re - pp.re, e.im - pp.im, floor_pow, floor_db, ltab);       // k = 0 -> bin M (Nyquist)
+  }
+  if (q == 0) fo[M4 / 2] = db_of4(midr, midi, floor_pow, floor_db, ltab);
+}
+
+}  // namespace
+
+// float64 / n_fft 8192, frame-major output only; anything else returns IRA_E_UNSUPPORTED.
+int32_t ira_stft4_dispatch_tf(const float* x, const int64_t* off, const int32_t* nframes, int32_t nseg,
+                              int32_t max_frames, int32_t n_fft, int32_t hop, const void* window, const void* tw,
+                              int32_t precision, double floor_db, float* out, const int64_t* out_off,
+                              const int32_t* frame_sel, const int64_t* sel_off, hipStream_t st) {
+  if (precision != 64 || n_fft != 8192) return IRA_E_UNSUPPORTED;
+  const double floor_lin = std::pow(10.0, floor_db / 20.0);
+  dim3 grid(max_frames, nseg);
+  stft4_kernel<<<grid, TL4, 0, st>>>(x, off, nframes, hop, static_cast<const double*>(window),
+                                     static_cast<const cdd*>(tw), floor_lin, (float)floor_db, out, out_off, frame_sel,
+                                     sel_off);
+  IRA_RETURN_LAUNCH();
+}

@@ -339,7 +339,7 @@ class Engine:
     @staticmethod
     def stft_frame_major_ok(n_fft: int, precision: int) -> bool:
         """Configurations ira_stft_mag_db_tf implements."""
-        return int(n_fft) == 4096 and int(precision) == 32
+        return (int(n_fft), int(precision)) in ((4096, 32), (8192, 64))
 
     # ------------------------------------------------------------------ a9/a17: arbitrary-length f64 DFTs
     workspace_budget_bytes = 48 << 30   # cap for the Bluestein work + filter arrays of one chunk
@@ -781,8 +781,9 @@ class Engine:
         return out, out_off
 
     def logbin_aggregate(self, mag_dev, mag_off: np.ndarray, nframes: np.ndarray, k_base: int, first: np.ndarray,
-                         count: np.ndarray):
-        """(nbins, T_e) float32 log-bin curves per element; returns (out device, out_off host)."""
+                         count: np.ndarray, frame_major_rows: int = 0):
+        """(nbins, T_e) float32 log-bin curves per element; returns (out device, out_off host).
+        frame_major_rows = F when mag holds the (T, F) matrices of stft_mag_db(..., frame_major=True)."""
         t = self.torch
         n = int(mag_off.size)
         nbins = int(first.size)
@@ -795,8 +796,8 @@ class Engine:
         d_mo, d_nf, d_oo = self.to_dev(mag_off), self.to_dev(nframes), self.to_dev(out_off)
         d_f, d_c = self.to_dev(first.astype(np.int32)), self.to_dev(count.astype(np.int32))
         check(self.lib.ira_logbin_aggregate(_ptr(mag_dev), _ptr(d_mo), _ptr(d_nf), n, int(nframes.max()), int(k_base),
-                                            _ptr(d_f), _ptr(d_c), nbins, _ptr(out), _ptr(d_oo), self.stream),
-              "ira_logbin_aggregate")
+                                            _ptr(d_f), _ptr(d_c), nbins, _ptr(out), _ptr(d_oo), int(frame_major_rows),
+                                            self.stream), "ira_logbin_aggregate")
         return out, out_off
 
     # ------------------------------------------------------------------ a19-a21: AR pole fit

@@ -106,8 +106,9 @@ int32_t ira_stft_mag_db(const float* x_dev, const int64_t* off_dev, const int32_
 
 /* Same transform, FRAME-MAJOR output: out[e] is a (T_e, n_fft/2+1) matrix, i.e. the transpose of the reference's
  * (F, T) array -- every frame's bins are contiguous, which lets each wave store its frame directly (no transposing
- * tile, no partial-line writes).  For device-resident consumers and hosts that take a `.T` view.  Currently
- * precision 32 / n_fft 4096 only; anything else returns IRA_E_UNSUPPORTED (use ira_stft_mag_db). */
+ * tile, no partial-line writes).  For device-resident consumers and hosts that take a `.T` view.  Implemented for
+ * precision 32 / n_fft 4096 and precision 64 / n_fft 8192 (the reference's spectrogram and modal-cloud defaults);
+ * anything else returns IRA_E_UNSUPPORTED (use ira_stft_mag_db). */
 int32_t ira_stft_mag_db_tf(const float* x_dev, const int64_t* off_dev, const int32_t* nframes_dev,
                            int32_t nseg, int32_t max_frames, int32_t n_fft, int32_t hop,
                            const void* window_dev, const void* twiddle_dev, int32_t precision,
@@ -217,12 +218,13 @@ int32_t ira_waterfall_rel(const float* mag_dev, const int64_t* mag_off_dev, cons
 /* ---- a15: modal-cloud log-frequency aggregation -----------------------------------------------------------
  * mag[e] is the (F, T_e) STFT dB matrix; for log bin b rows k_base+first[b] .. +count[b]-1 are averaged as
  * linear magnitude 10^(dB/20) in float64 (rows added in order), then 20 log10(max(mean, 1e-30)) -> float32;
- * count[b] == 0 gives a NaN row.  out[e] is (nbins, T_e).
+ * count[b] == 0 gives a NaN row.  out[e] is (nbins, T_e).  frame_major_rows > 0: mag[e] is the FRAME-MAJOR (T_e, F)
+ * matrix of ira_stft_mag_db_tf with F = frame_major_rows (same results, same row order).
  * Replaces _aggregate_to_log_bins, reference analyse/modalcloud.py:176-207. */
 int32_t ira_logbin_aggregate(const float* mag_dev, const int64_t* mag_off_dev, const int32_t* nframes_dev,
                              int32_t nb, int32_t max_frames, int32_t k_base, const int32_t* first_dev,
                              const int32_t* count_dev, int32_t nbins, float* out_dev,
-                             const int64_t* out_off_dev, void* stream);
+                             const int64_t* out_off_dev, int32_t frame_major_rows, void* stream);
 
 /* ---- a19-a21: z-plane AR pole fit ----------------------------------------------------------------------------
  * Covariance-method AR least squares of order `order` on segments x[xoff[e] .. +len[e]) / divisor[e]

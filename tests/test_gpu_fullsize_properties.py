@@ -108,7 +108,8 @@ def test_baseline_config_batch256_two_second_irs_spectrogram_and_decay():
     sp = O.analyse_spectrogram(chans[101], SR)
     ref = sp["magnitude_db"]
     off, cols = int(out["mag_off"][101]), int(out["cols"][101])
-    got = out["mag"][off : off + ref.shape[0] * cols].cpu().numpy().reshape(ref.shape[0], cols)
+    flat = out["mag"][off : off + ref.shape[0] * cols].cpu().numpy()
+    got = flat.reshape(cols, ref.shape[0]).T if out.get("frame_major") else flat.reshape(ref.shape[0], cols)
     peak = ref.max(axis=0, keepdims=True)
     strong = (ref > peak - 50.0) & (ref > -100.0)
     assert np.max(np.abs(got - ref)[strong]) < 1e-3

@@ -78,6 +78,42 @@ def test_modal_curves_vs_golden(golden):
     assert np.mean(got[ok] == ref[ok]) > 0.99
 
 
+def test_frame_major_f64_stft_and_logbin_vs_golden(golden):
+    """v4 kernel (f64 / 8192, frame-major) against the golden STFT and log-bin curves, and bit-equal to the (F, T) path."""
+    from audio_analysis_amd.analyse import modalcloud as mc
+    from audio_analysis_amd.engine import get_engine
+    g, c, _ = golden
+    eng = get_engine()
+    assert eng.stft_frame_major_ok(8192, 64)
+    cs = c["stft8192"]
+    seg = g["in/xb"][cs["seg_start"] : cs["seg_start"] + cs["seg_len"]]
+    b = eng.upload([seg])
+    nfr = np.array([1 + (seg.size - 8192) // 512], dtype=np.int32)
+    ft, _, _ = eng.stft_mag_db(b.x, b.off, nfr, 8192, 512, True, -120.0, 64)
+    tf, _, _ = eng.stft_mag_db(b.x, b.off, nfr, 8192, 512, True, -120.0, 64, frame_major=True)
+    a = ft.cpu().numpy()[: 4097 * nfr[0]].reshape(4097, nfr[0])
+    t = tf.cpu().numpy()[: 4097 * nfr[0]].reshape(nfr[0], 4097).T
+    ref = g["stft8192/mag_db"]
+    np.testing.assert_allclose(t, ref, rtol=0, atol=2e-5)
+    assert np.mean(t == ref) > 0.99
+    assert np.mean(t == a) > 0.999 and np.max(np.abs(t - a)) < 2e-5
+    # log-bin curves from the frame-major matrix
+    seg = g["in/xb"][243:]
+    b = eng.upload([seg])
+    nfr = np.array([1 + (seg.size - 8192) // 512], dtype=np.int32)
+    mag, off, cols = eng.stft_mag_db(b.x, b.off, nfr, 8192, 512, True, -120.0, 64, frame_major=True)
+    freq = np.fft.rfftfreq(8192, 1 / 48000.0).astype(np.float32)
+    rows = np.nonzero((freq >= 20.0) & (freq <= 20000.0))[0]
+    cen, first, count = mc.log_bin_rows(freq[rows], g["modal/edges"])
+    cur, _ = eng.logbin_aggregate(mag, off, cols, int(rows[0]), first, count, frame_major_rows=4097)
+    got = cur.cpu().numpy()[: cen.size * nfr[0]].reshape(cen.size, nfr[0])
+    refc = g["xb/modal/curves"]
+    assert np.array_equal(np.isnan(got), np.isnan(refc))
+    ok = ~np.isnan(refc)
+    np.testing.assert_allclose(got[ok], refc[ok], rtol=0, atol=2e-5)
+    assert np.mean(got[ok] == refc[ok]) > 0.99
+
+
 @pytest.mark.parametrize("tag,inp", [("xb", "xb"), ("xb16", "xb16"), ("xb_t20", "xb"), ("xd_4096", "xd")])
 def test_modal_cloud_vs_golden(golden, tag, inp):
     from audio_analysis_amd.analyse import modalcloud as mc
