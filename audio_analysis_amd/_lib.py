@@ -30,6 +30,7 @@ PROTOTYPES = {
     "ira_curve_fits": (i32, [vp, vp, vp, i32, i32, f32, f32, vp, C.POINTER(f64), i32, i32, C.POINTER(f64), i32, i32,
                              f64, f64, vp, vp, vp]),
     "ira_stft_mag_db": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, f64, vp, vp, vp, vp, vp]),
+    "ira_stft_logbin": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, f64, i32, vp, vp, i32, vp, vp, vp]),
     "ira_stft_mag_db_tf": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, f64, vp, vp, vp, vp, vp]),
     "ira_fft_split": (i32, [i32, vp, vp]),
     "ira_bluestein_filter": (i32, [vp, i32, i32, vp, vp, vp, vp, vp]),

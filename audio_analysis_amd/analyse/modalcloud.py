@@ -121,8 +121,9 @@ def modal_records_to_results(dev, rec: np.ndarray, sample_rate_hz: int, channel_
     return out
 
 
-def modal_cloud_device(eng, batch, sample_rate_hz: int, settings: ModalCloudAnalysisSettings):
-    """Device-resident modal cloud: per-(channel, log bin) fit records stay in HBM."""
+def modal_cloud_device(eng, batch, sample_rate_hz: int, settings: ModalCloudAnalysisSettings, fused: bool = True):
+    """Device-resident modal cloud: per-(channel, log bin) fit records stay in HBM.  fused=False forces the two-kernel
+    path (STFT matrix + ira_logbin_aggregate) where the fused kernel would apply (A/B, tests)."""
     starts, lens, nframes = select_stft_segments(eng, batch, sample_rate_hz, settings, "modal cloud")
     n_fft, hop = int(settings.n_fft), int(settings.hop_length)
     metric = str(settings.metric).lower()
@@ -146,12 +147,20 @@ def modal_cloud_device(eng, batch, sample_rate_hz: int, settings: ModalCloudAnal
     centres, first, count = log_bin_rows(freq[rows], edges)
     nbins = int(centres.size)
 
-    # the STFT matrix is only an intermediate here: take the frame-major layout where the library has it (8192 / f64)
-    tf = eng.stft_frame_major_ok(n_fft, 64)
-    mag, mag_off, cols = eng.stft_mag_db(batch.x, batch.off + starts, nframes, n_fft, hop,
-                                         bool(settings.use_hann_window), float(settings.floor_db), 64, frame_major=tf)
-    curves, cur_off = eng.logbin_aggregate(mag, mag_off, cols, k_base, first, count,
-                                           frame_major_rows=(n_fft // 2 + 1) if tf else 0)
+    # The STFT matrix is only an intermediate here.  n_fft 8192: one fused kernel (STFT + aggregation, the dB matrix is
+    # never written); otherwise STFT (frame-major where the library has it) followed by ira_logbin_aggregate.
+    rows_ok = nbins == 0 or int(k_base + (first + count).max()) <= n_fft // 2 + 1
+    if eng.stft_logbin_ok(n_fft) and nbins > 0 and rows_ok and fused:
+        cols = nframes.astype(np.int32)
+        curves, cur_off = eng.stft_logbin(batch.x, batch.off + starts, nframes, n_fft, hop,
+                                          bool(settings.use_hann_window), float(settings.floor_db), k_base, first, count)
+    else:
+        tf = eng.stft_frame_major_ok(n_fft, 64)
+        mag, mag_off, cols = eng.stft_mag_db(batch.x, batch.off + starts, nframes, n_fft, hop,
+                                             bool(settings.use_hann_window), float(settings.floor_db), 64,
+                                             frame_major=tf)
+        curves, cur_off = eng.logbin_aggregate(mag, mag_off, cols, k_base, first, count,
+                                               frame_major_rows=(n_fft // 2 + 1) if tf else 0)
     c_off = np.concatenate([cur_off[i] + np.arange(nbins, dtype=np.int64) * int(cols[i]) for i in range(batch.count)])
     c_len = np.concatenate([np.full(nbins, int(cols[i]), dtype=np.int64) for i in range(batch.count)])
     fits, _ = eng.curve_fits(curves, c_off, c_len, float(hop), float(sample_rate_hz),

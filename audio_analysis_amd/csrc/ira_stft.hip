@@ -196,3 +196,25 @@ extern "C" int32_t ira_stft_mag_db_tf(const float* x_dev, const int64_t* off_dev
                                precision, floor_db, out_dev, out_off_dev, frame_sel_dev, sel_off_dev,
                                (hipStream_t)stream);
 }
+
+int32_t ira_stft4_dispatch_logbin(const float* x, const int64_t* off, const int32_t* nframes, int32_t nseg,
+                                  int32_t max_frames, int32_t n_fft, int32_t hop, const void* window, const void* tw,
+                                  int32_t precision, double floor_db, int32_t k_base, const int32_t* first,
+                                  const int32_t* count, int32_t nbins, float* curves, const int64_t* curves_off,
+                                  hipStream_t st);
+
+extern "C" int32_t ira_stft_logbin(const float* x_dev, const int64_t* off_dev, const int32_t* nframes_dev,
+                                   int32_t nseg, int32_t max_frames, int32_t n_fft, int32_t hop,
+                                   const void* window_dev, const void* twiddle_dev, int32_t precision, double floor_db,
+                                   int32_t k_base, const int32_t* first_dev, const int32_t* count_dev, int32_t nbins,
+                                   float* curves_dev, const int64_t* curves_off_dev, void* stream) {
+  IRA_CHECK_PTR(x_dev); IRA_CHECK_PTR(off_dev); IRA_CHECK_PTR(nframes_dev); IRA_CHECK_PTR(window_dev);
+  IRA_CHECK_PTR(twiddle_dev); IRA_CHECK_PTR(first_dev); IRA_CHECK_PTR(count_dev); IRA_CHECK_PTR(curves_dev);
+  IRA_CHECK_PTR(curves_off_dev);
+  if (nseg < 0 || max_frames < 0 || hop <= 0 || nbins <= 0 || k_base < 0) return IRA_E_SIZE;
+  if (nseg == 0 || max_frames == 0) return IRA_OK;
+  if (nseg > 65535) return IRA_E_SIZE;
+  return ira_stft4_dispatch_logbin(x_dev, off_dev, nframes_dev, nseg, max_frames, n_fft, hop, window_dev, twiddle_dev,
+                                   precision, floor_db, k_base, first_dev, count_dev, nbins, curves_dev,
+                                   curves_off_dev, (hipStream_t)stream);
+}

@@ -49,7 +49,8 @@ __global__ __launch_bounds__(TL4) void stft4_kernel(
     const float* __restrict__ x, const int64_t* __restrict__ off, const int32_t* __restrict__ nframes, int hop,
     const double* __restrict__ window, const cdd* __restrict__ tw, double floor_lin, float floor_db,
     float* __restrict__ out, const int64_t* __restrict__ out_off, const int32_t* __restrict__ frame_sel,
-    const int64_t* __restrict__ sel_off) {
+    const int64_t* __restrict__ sel_off, int lb_nbins, int lb_kbase, const int32_t* __restrict__ lb_first,
+    const int32_t* __restrict__ lb_count) {
   __shared__ __attribute__((aligned(16))) cdd ex[EXC4];
   __shared__ ira::LogTabEntry ltab[ira::LOGTAB_N];
   // XCD-aware bijective remap: consecutive frames of a segment (which share 15/16 of their samples) meet in one L2
@@ -187,19 +188,60 @@ __global__ __launch_bounds__(TL4) void stft4_kernel(
   // ---- post: X[k] = E + P, X[M-k] = conj(E - P) with E = (Zk + conj Zp)/2, P = W_N^k (-i)(Zk - conj Zp)/2 ---------------
   const double floor_pow = floor_lin * floor_lin;
   const cdd wlane = tw[q];
-  float* fo = out + out_off[seg] + (int64_t)col * F4;
+  if (lb_nbins <= 0) {
+    // ---- frame-major dB matrix ---------------------------------------------------------------------------------------
+    float* fo = out + out_off[seg] + (int64_t)col * F4;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int k = q + TL4 * i;
+      const cdd e = {0.5 * (zkr[i] + zpr[i]), 0.5 * (zki[i] - zpi[i])};
+      const cdd d = {0.5 * (zkr[i] - zpr[i]), 0.5 * (zki[i] + zpi[i])};
+      const cdd o = {d.im, -d.re};
+      const cdd wk = ira::cmul(wlane, tw[TL4 * i]);        // W_N^k = W_N^q W_N^(128 i); second factor wave-uniform
+      const cdd pp = ira::cmul(wk, o);
+      fo[k] = db_of4(e.re + pp.re, e.im + pp.im, floor_pow, floor_db, ltab);
+      fo[M4 - k] = db_of4(e.re - pp.re, e.im - pp.im, floor_pow, floor_db, ltab);       // k = 0 -> bin M (Nyquist)
+    }
+    if (q == 0) fo[M4 / 2] = db_of4(midr, midi, floor_pow, floor_db, ltab);
+    return;
+  }
+
+  // ---- fused modal-cloud aggregation (reference modalcloud.py:176-207): the frame's dB values never leave the CU.
+  // float32 dB (the reference's STFT output type) -> linear magnitude 10^(dB/20) in float64 -> LDS; then log bin b is
+  // the mean of its rows, added in ascending order, -> 20 log10(max(., 1e-30)) -> float32 at out[b * T + frame].
+  __syncthreads();                                          // every lane has finished reading E3
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int k = q + TL4 * i;
     const cdd e = {0.5 * (zkr[i] + zpr[i]), 0.5 * (zki[i] - zpi[i])};
     const cdd d = {0.5 * (zkr[i] - zpr[i]), 0.5 * (zki[i] + zpi[i])};
     const cdd o = {d.im, -d.re};
-    const cdd wk = ira::cmul(wlane, tw[TL4 * i]);        // W_N^k = W_N^q W_N^(128 i); second factor wave-uniform
+    const cdd wk = ira::cmul(wlane, tw[TL4 * i]);
     const cdd pp = ira::cmul(wk, o);
-    fo[k] = db_of4(e.re + pp.re, e.im + pp.im, floor_pow, floor_db, ltab);
-    fo[M4 - k] = db_of4(e.re - pp.re, e.im - pp.im, floor_pow, floor_db, ltab);       // k = 0 -> bin M (Nyquist)
+    exd[k] = exp10((double)db_of4(e.re + pp.re, e.im + pp.im, floor_pow, floor_db, ltab) * 0.05);
+    exd[M4 - k] = exp10((double)db_of4(e.re - pp.re, e.im - pp.im, floor_pow, floor_db, ltab) * 0.05);
   }
-  if (q == 0) fo[M4 / 2] = db_of4(midr, midi, floor_pow, floor_db, ltab);
+  if (q == 0) exd[M4 / 2] = exp10((double)db_of4(midr, midi, floor_pow, floor_db, ltab) * 0.05);
+  __syncthreads();
+  float* co = out + out_off[seg];
+  for (int b = q; b < lb_nbins; b += TL4) {
+    const int c = lb_count[b];
+    float v = __uint_as_float(0x7fc00000u);
+    if (c > 0) {
+      const double* r = exd + lb_kbase + lb_first[b];
+      double acc = r[0];
+      for (int k0 = 1; k0 < c; k0 += 8) {
+        double v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v8[u] = (k0 + u < c) ? r[k0 + u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (k0 + u < c) acc += v8[u];
+      }
+      v = (float)(20.0 * log10(fmax(acc / (double)c, 1e-30)));
+    }
+    co[(int64_t)b * T_out + col] = v;
+  }
 }
 
 }  // namespace
@@ -214,6 +256,21 @@ int32_t ira_stft4_dispatch_tf(const float* x, const int64_t* off, const int32_t*
   dim3 grid(max_frames, nseg);
   stft4_kernel<<<grid, TL4, 0, st>>>(x, off, nframes, hop, static_cast<const double*>(window),
                                      static_cast<const cdd*>(tw), floor_lin, (float)floor_db, out, out_off, frame_sel,
-                                     sel_off);
+                                     sel_off, 0, 0, nullptr, nullptr);
+  IRA_RETURN_LAUNCH();
+}
+
+// STFT + log-bin aggregation in one kernel: out[e] is the (nbins, T_e) curve matrix of ira_logbin_aggregate.
+int32_t ira_stft4_dispatch_logbin(const float* x, const int64_t* off, const int32_t* nframes, int32_t nseg,
+                                  int32_t max_frames, int32_t n_fft, int32_t hop, const void* window, const void* tw,
+                                  int32_t precision, double floor_db, int32_t k_base, const int32_t* first,
+                                  const int32_t* count, int32_t nbins, float* curves, const int64_t* curves_off,
+                                  hipStream_t st) {
+  if (precision != 64 || n_fft != 8192) return IRA_E_UNSUPPORTED;
+  const double floor_lin = std::pow(10.0, floor_db / 20.0);
+  dim3 grid(max_frames, nseg);
+  stft4_kernel<<<grid, TL4, 0, st>>>(x, off, nframes, hop, static_cast<const double*>(window),
+                                     static_cast<const cdd*>(tw), floor_lin, (float)floor_db, curves, curves_off,
+                                     nullptr, nullptr, nbins, k_base, first, count);
   IRA_RETURN_LAUNCH();
 }

@@ -336,6 +336,32 @@ class Engine:
         self.event_tag = ""
         return out, out_off, cols
 
+    def stft_logbin(self, x_dev, seg_off: np.ndarray, nframes: np.ndarray, n_fft: int, hop: int, use_hann: bool,
+                    floor_db: float, k_base: int, first: np.ndarray, count: np.ndarray):
+        """Fused float64 STFT + log-bin aggregation (ira_stft_logbin; n_fft 8192): (curves device, curves_off host)."""
+        t = self.torch
+        n = int(seg_off.size)
+        nbins = int(first.size)
+        cols = np.ascontiguousarray(nframes, dtype=np.int32)
+        sizes = cols.astype(np.int64) * nbins
+        out_off = np.zeros(n, dtype=np.int64)
+        if n > 1:
+            out_off[1:] = np.cumsum(sizes[:-1])
+        out = self.empty(int(sizes.sum()), t.float32)
+        d_off, d_cols, d_ooff = self.to_dev(seg_off), self.to_dev(cols), self.to_dev(out_off)
+        d_f, d_c = self.to_dev(first.astype(np.int32)), self.to_dev(count.astype(np.int32))
+        self.event_tag = f"[f64,n{n_fft}]"
+        check(self.lib.ira_stft_logbin(_ptr(x_dev), _ptr(d_off), _ptr(d_cols), n, int(cols.max()) if n else 0,
+                                       int(n_fft), int(hop), _ptr(self.window(n_fft, use_hann, 64)),
+                                       _ptr(self.twiddle(n_fft, 64)), 64, float(floor_db), int(k_base), _ptr(d_f),
+                                       _ptr(d_c), nbins, _ptr(out), _ptr(d_ooff), self.stream), "ira_stft_logbin")
+        self.event_tag = ""
+        return out, out_off
+
+    @staticmethod
+    def stft_logbin_ok(n_fft: int) -> bool:
+        return int(n_fft) == 8192
+
     @staticmethod
     def stft_frame_major_ok(n_fft: int, precision: int) -> bool:
         """Configurations ira_stft_mag_db_tf implements."""

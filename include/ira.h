@@ -115,6 +115,17 @@ int32_t ira_stft_mag_db_tf(const float* x_dev, const int64_t* off_dev, const int
                            double floor_db, float* out_dev, const int64_t* out_off_dev,
                            const int32_t* frame_sel_dev, const int64_t* sel_off_dev, void* stream);
 
+/* STFT + modal-cloud log-bin aggregation in ONE kernel (ira_stft_mag_db followed by ira_logbin_aggregate, with the dB
+ * matrix never written): curves_dev[e] is the (nbins, T_e) float32 matrix at curves_off_dev[e]; k_base / first / count
+ * as in ira_logbin_aggregate (every row k_base + first[b] + j must be < n_fft/2 + 1).  Same arithmetic, including the
+ * float32 rounding of the dB value before it is converted back to linear magnitude.  precision 64 / n_fft 8192 only
+ * (IRA_E_UNSUPPORTED otherwise).  Replaces reference analyse/modalcloud.py:121-158 + :176-207 for the modal cloud. */
+int32_t ira_stft_logbin(const float* x_dev, const int64_t* off_dev, const int32_t* nframes_dev, int32_t nseg,
+                        int32_t max_frames, int32_t n_fft, int32_t hop, const void* window_dev,
+                        const void* twiddle_dev, int32_t precision, double floor_db, int32_t k_base,
+                        const int32_t* first_dev, const int32_t* count_dev, int32_t nbins, float* curves_dev,
+                        const int64_t* curves_off_dev, void* stream);
+
 /* ---- a9/a17: arbitrary-length float64 DFTs (Bluestein over a four-step power-of-two FFT) ---------------
  * Common arguments: log2m with M = 2^log2m >= 2*max(L) - 1 (4 <= log2m <= 22); three caller-provided
  * complex-f64 tables for M = N1*N2 with the split ira_fft_split() reports (N1 = 2^log2n1, N2 = 2^log2n2):

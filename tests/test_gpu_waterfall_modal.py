@@ -114,6 +114,39 @@ def test_frame_major_f64_stft_and_logbin_vs_golden(golden):
     assert np.mean(got[ok] == refc[ok]) > 0.99
 
 
+def test_fused_stft_logbin_matches_the_two_kernel_path(golden):
+    """ira_stft_logbin (dB matrix never written) gives the curves of ira_stft_mag_db + ira_logbin_aggregate."""
+    from audio_analysis_amd.analyse import modalcloud as mc
+    from audio_analysis_amd.engine import get_engine
+    from audio_analysis_amd.synth import synth_ir
+    g, c, _ = golden
+    eng = get_engine()
+    chans = [g["in/xb"], synth_ir(77, 0, 60001, rt60_seconds=0.5), synth_ir(78, 0, 30011, rt60_seconds=0.2)]
+    b = eng.upload(chans)
+    st = mc.ModalCloudAnalysisSettings()
+    fused = mc.modal_cloud_device(eng, b, SR, st, fused=True)
+    split = mc.modal_cloud_device(eng, b, SR, st, fused=False)
+    cf, cs = fused["curves"].cpu().numpy(), split["curves"].cpu().numpy()
+    assert cf.shape == cs.shape and np.array_equal(np.isnan(cf), np.isnan(cs))
+    ok = ~np.isnan(cs)
+    assert np.max(np.abs(cf[ok] - cs[ok])) < 2e-5 and np.mean(cf[ok] == cs[ok]) > 0.999
+    np.testing.assert_array_equal(fused["fits"].cpu().numpy()[:, 0], split["fits"].cpu().numpy()[:, 0])   # same valid bins
+    # and the fused kernel directly against the golden curves (segment and bins exactly as the golden script took them)
+    seg = g["in/xb"][243:]
+    bs = eng.upload([seg])
+    nfr = np.array([1 + (seg.size - 8192) // 512], dtype=np.int32)
+    freq = np.fft.rfftfreq(8192, 1 / 48000.0).astype(np.float32)
+    rows = np.nonzero((freq >= 20.0) & (freq <= 20000.0))[0]
+    cen, first, count = mc.log_bin_rows(freq[rows], g["modal/edges"])
+    cur, _ = eng.stft_logbin(bs.x, bs.off, nfr, 8192, 512, True, -120.0, int(rows[0]), first, count)
+    got = cur.cpu().numpy()[: cen.size * nfr[0]].reshape(cen.size, nfr[0])
+    ref = g["xb/modal/curves"]
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    okr = ~np.isnan(ref)
+    np.testing.assert_allclose(got[okr], ref[okr], rtol=0, atol=2e-5)
+    assert np.mean(got[okr] == ref[okr]) > 0.99
+
+
 @pytest.mark.parametrize("tag,inp", [("xb", "xb"), ("xb16", "xb16"), ("xb_t20", "xb"), ("xd_4096", "xd")])
 def test_modal_cloud_vs_golden(golden, tag, inp):
     from audio_analysis_amd.analyse import modalcloud as mc
