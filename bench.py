@@ -189,9 +189,14 @@ def main():
         if name.startswith("ira_stft_mag_db") and "[f32" in name:
             b = stft_bytes(settings.spectrogram.n_fft, settings.spectrogram.hop_length)
             what = "4L in + 4*F*T out bytes per channel"
-        elif name.startswith("ira_stft_mag_db[f64,n%d]" % settings.modal_cloud.n_fft):
+        elif name.startswith("ira_stft_mag_db") and ("[f64,n%d]" % settings.modal_cloud.n_fft) in name:
             b = stft_bytes(settings.modal_cloud.n_fft, settings.modal_cloud.hop_length)
             what = "4L in + 4*F*T out bytes per channel"
+        elif name.startswith("ira_stft_logbin"):
+            nf = settings.modal_cloud.n_fft
+            frames = 1 + (L - nf) // settings.modal_cloud.hop_length
+            b = float(np.sum(4.0 * L + 4.0 * 240 * frames))
+            what = "4L in + 4*nbins*T out bytes per channel (fused STFT + log-bin aggregation; the dB matrix is never written)"
         elif name.startswith("ira_rfft_any"):
             # compulsory traffic: samples in + half spectra out of the windowed fr/filter transform (arbitrary length ->
             # Bluestein).  The three float64 passes over M = 2^20 move ~15x that through L2/MALL/HBM (see "traffic");

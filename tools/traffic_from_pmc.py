@@ -13,7 +13,8 @@ d, batch = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 64
 
 def call_of(kernel, last_fft):
     k = kernel
-    if "stft3_kernel" in k: return "ira_stft_mag_db[f32,n4096]", last_fft
+    if "stft3_kernel" in k: return "ira_stft_mag_db_tf[f32,n4096]" if ", true>" in k else "ira_stft_mag_db[f32,n4096]", last_fft
+    if "stft4_kernel" in k: return "ira_stft_logbin[f64,n8192]", last_fft
     if "stft2_kernel<double, 2" in k: return "ira_stft_mag_db[f64,n8192]", last_fft
     if "stft2_kernel<double, 1" in k: return "ira_stft_mag_db[f64,n4096,sel]", last_fft
     if "smooth_cols_kernel<0>" in k: return "ira_rfft_smooth", "ira_rfft_smooth"
@@ -22,7 +23,7 @@ def call_of(kernel, last_fft):
     if "cols_fwd_kernel<0>" in k: return "ira_rfft_any", "ira_rfft_any"
     if "cols_fwd_kernel<2>" in k: return "ira_band_irfft", "ira_band_irfft"
     if "cols_fwd_kernel<1>" in k: return "ira_bluestein_filter", "ira_bluestein_filter"
-    if "rows_kernel" in k or "cols_inv_kernel" in k or "pair_split" in k: return last_fft, last_fft
+    if "rows_kernel" in k or "cols_inv_kernel" in k or "pair_split" in k or "half_split" in k: return last_fft, last_fft
     if "ar_lag_kernel" in k or "ar_gram_kernel" in k: return "ira_ar_gram", last_fft
     if "ar_solve" in k: return "ira_ar_solve", last_fft
     if "edc_" in k: return "ira_edc_db", last_fft
