@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdlib>
 
+#include "ira_bandmask.h"
 #include "ira_fft_reg.h"
 
 namespace {
@@ -22,7 +23,6 @@ typedef cplx<double> cd;
 constexpr int SM_THREADS = 256;
 constexpr int SM_MAX_N = 1024;     // largest sub-transform (LDS: 2 buffers x C x N x 16 B)
 constexpr int SM_MAX_RADICES = 12;
-constexpr double kPiS = 3.14159265358979323846;
 
 struct SmoothPlan {
   int n, n1, n2;
@@ -200,37 +200,8 @@ __device__ __forceinline__ cd twiddle_n(const SmoothPlan& P, unsigned p) {      
   return ira::cmul(P.t1[hi], P.tf[lo]);
 }
 
-// ---- band masks: same float32 arithmetic as ira_fftlong.hip (reference rt60bands.py:116-167) ------------------------
-struct BandMaskS { double kind, hp_x0, hp_x1, lp_x0, lp_x1, pad0, pad1, pad2; };
-
-__device__ __forceinline__ float ramp_s(float f, double x0, double x1) {
-  if (x1 <= x0) return f >= (float)x1 ? 1.0f : 0.0f;
-  float t = (f - (float)x0) / (float)(x1 - x0);
-  t = fminf(fmaxf(t, 0.0f), 1.0f);
-  if (t <= 0.0f) return 0.0f;
-  if (t >= 1.0f) return 1.0f;
-  const float arg = (float)kPiS * t;
-  return 0.5f - 0.5f * (float)cos((double)arg);
-}
-__device__ __forceinline__ float lowpass_s(float f, double pass, double stop) {
-  float m = 1.0f - ramp_s(f, pass, stop);
-  if (f <= (float)pass) m = 1.0f;
-  if (f >= (float)stop) m = 0.0f;
-  return m;
-}
-__device__ __forceinline__ float highpass_s(float f, double stop, double pass) {
-  float m = ramp_s(f, stop, pass);
-  if (f <= (float)stop) m = 0.0f;
-  if (f >= (float)pass) m = 1.0f;
-  return m;
-}
-__device__ __forceinline__ float mask_s(const BandMaskS& b, float f) {
-  const int kind = (int)b.kind;
-  if (kind == 1) return lowpass_s(f, b.lp_x0, b.lp_x1);
-  if (kind == 2) return highpass_s(f, b.hp_x0, b.hp_x1);
-  if (kind == 3) return highpass_s(f, b.hp_x0, b.hp_x1) * lowpass_s(f, b.lp_x0, b.lp_x1);
-  return 0.0f;
-}
+using BandMaskS = ira::BandMask;
+__device__ __forceinline__ float mask_s(const BandMaskS& b, float f) { return ira::mask_at(b, f); }
 
 struct SJobs {
   // forward: one or two real signals per job
