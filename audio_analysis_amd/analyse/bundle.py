@@ -52,3 +52,49 @@ def run_bundle_report(bundle_root: str | Path, settings: Optional[BundleRunSetti
         lines += [f"- [{tap}]({settings.reports_subdir}/{tap}/{tap}_report.md)" for tap in taps]
         index.write_text("\n".join(lines) + "\n")
     return index
+
+
+def run_bundle_metrics(bundle_root: str | Path, settings=None, use_mono_downmix_for_stereo: bool = False,
+                       taps_per_step: int = 32):
+    """
+    Batched metrics-only pass over a bundle (SURVEY.md section 8f rank 2 + section 8e): every rank ingests its block
+    of taps natively (audio_analysis_amd.ingest: int16 upload, conversion on the device), runs the metrics-only full
+    report (audio_analysis_amd.pipeline.FullReport) `taps_per_step` files at a time, and ONE gather brings the
+    fixed-width records to rank 0.  Returns ([(tap name, channel name), ...], records (channels x METRICS_WIDTH)) on
+    rank 0 and (None, None) elsewhere.  No PNGs, no Markdown: this is the data-parallel axis of the reference's
+    serial loop (bundle.py:56-67) without its per-file plotting.
+    """
+    import numpy as np
+
+    from ..engine import get_engine
+    from ..ingest import ingest_taps
+    from ..pipeline import METRICS_WIDTH, FullReport, FullReportSettings
+
+    root = Path(bundle_root)
+    meta = json.loads((root / "meta.json").read_text())
+    taps: List[str] = list(meta.get("taps", []))
+    rank, _, world = _dist.env_world()
+    lo, hi = _dist.shard_files(len(taps), rank, world)
+    eng = get_engine()
+    fr = FullReport(eng, settings or FullReportSettings())
+    rows, labels = [], []
+    pending = None
+    for a in range(lo, hi, max(1, int(taps_per_step))):
+        names = taps[a : min(hi, a + taps_per_step)]
+        batch, lab = ingest_taps(eng, [root / "taps" / f"{t}.wav" for t in names], use_mono_downmix_for_stereo,
+                                 int(meta.get("sample_rate_hz", 48_000) or 48_000))
+        labels += [(names[i], ch) for i, ch in lab]
+        nxt = fr.submit(batch)                       # step k+1 is enqueued before step k's records are read back
+        if pending is not None:
+            rows.append(fr.finish(pending))
+        pending = nxt
+    if pending is not None:
+        rows.append(fr.finish(pending))
+    local = np.concatenate(rows, axis=0) if rows else np.zeros((0, METRICS_WIDTH))
+    records = _dist.gather_metrics(local, eng.device)
+    if world > 1:
+        import torch.distributed as td
+        gathered = [None] * world if rank == 0 else None
+        td.gather_object(labels, gathered, dst=0)
+        labels = [x for part in gathered for x in part] if rank == 0 else None
+    return (labels, records) if rank == 0 else (None, None)

@@ -1,0 +1,153 @@
+"""
+Native tap ingest: bundle tap files -> a device-resident ChannelBatch without the
+Python WAV stack.
+
+The reference reads every tap with scipy.io.wavfile.read, converts int16 -> float32 on the host
+(analyse/io.py:46-64, :98-113), applies the channel policy (analyse/io.py:66-95) and repeats all of that once per
+analysis module (ten times per report).  Here a tap written by the reference's C++ recorder
+(include/analysis/recorder.hpp:55-90: 44-byte header, 16-bit PCM, stereo) is
+
+  1. probed by libira's RIFF walker (ira_wav_probe; host),
+  2. read as raw interleaved int16 straight into pinned memory (ira_wav_read_pcm16; host),
+  3. uploaded as int16 (2 bytes per sample on the PCIe link instead of 4), and
+  4. converted on the device (ira_pcm16_to_channels): x/32768 clipped to [-1, 1], split into planar channels or
+     mixed down to 0.5*(L+R) in float32 -- bit-identical to the reference's conversion.
+
+WAV encodings the native reader does not take (int32, float, 24-bit ...) go through analyse.io.load_wav_file (file
+decoding only; every analysis still runs on the device).  Validation errors are the reference's
+(analyse/io.py:156-178), raised per file with the file's path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from pathlib import Path
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+from .engine import ChannelBatch, Engine
+
+IRA_E_UNSUPPORTED = -3
+
+
+@dataclass(frozen=True)
+class TapInfo:
+    path: Path
+    sample_rate_hz: int
+    channels: int
+    frames: int
+    data_offset: int
+    native: bool                 # True: 16-bit PCM that libira reads itself
+
+
+def probe_tap(path: str | Path) -> TapInfo:
+    """RIFF/WAVE header of one tap (host only; does not need a GPU)."""
+    lib = _lib.load()
+    p = Path(path)
+    rate, ch = C.c_int32(0), C.c_int32(0)
+    frames, off = C.c_int64(0), C.c_int64(0)
+    rc = lib.ira_wav_probe(str(p).encode(), C.addressof(rate), C.addressof(ch), C.addressof(frames), C.addressof(off))
+    if rc == IRA_E_UNSUPPORTED:
+        return TapInfo(p, int(rate.value), int(ch.value), int(frames.value), int(off.value), False)
+    check(rc, f"ira_wav_probe({p})")
+    return TapInfo(p, int(rate.value), int(ch.value), int(frames.value), int(off.value), True)
+
+
+def read_tap_pcm16(info: TapInfo, dst: Optional[np.ndarray] = None) -> np.ndarray:
+    """Interleaved int16 payload of a native tap, shape (frames, channels) (host only)."""
+    if not info.native:
+        raise ValueError(f"{info.path} is not 16-bit PCM")
+    lib = _lib.load()
+    if dst is None:
+        dst = np.empty((info.frames, info.channels), dtype=np.int16)
+    if dst.dtype != np.int16 or dst.size != info.frames * info.channels or not dst.flags.c_contiguous:
+        raise ValueError("dst must be a C-contiguous int16 array of frames*channels values")
+    check(lib.ira_wav_read_pcm16(str(info.path).encode(), info.data_offset, info.frames, info.channels,
+                                 dst.ctypes.data), f"ira_wav_read_pcm16({info.path})")
+    return dst
+
+
+def _validate(info: TapInfo, expected_rate: int) -> None:
+    # messages of the reference's validate_audio_format (analyse/io.py:161-178), channel mode "mono_or_stereo"
+    if info.sample_rate_hz != expected_rate:
+        raise ValueError(f"Expected sample rate {expected_rate} Hz, but got {info.sample_rate_hz} Hz "
+                         f"for file {info.path}")
+    if info.channels not in (1, 2):
+        raise ValueError(f"Expected mono or stereo (1 or 2 channels) but got {info.channels} channels "
+                         f"for file {info.path}")
+
+
+def channel_names(channels: int, mono_downmix: bool) -> List[str]:
+    """Channel policy of analyse/io.py:66-95."""
+    if channels == 1 or mono_downmix:
+        return ["mono"]
+    return ["left", "right"]
+
+
+def ingest_taps(eng: Engine, paths: Sequence[str | Path], use_mono_downmix_for_stereo: bool = False,
+                expected_sample_rate_hz: int = 48_000) -> Tuple[ChannelBatch, List[Tuple[int, str]]]:
+    """
+    Tap files -> (device batch of analysis channels, [(file index, channel name), ...] in batch order).
+
+    All native taps share ONE pinned int16 staging buffer and ONE host-to-device copy; each file then gets one
+    conversion launch that writes its planar channels at their place in the flat float32 batch buffer.
+    """
+    t = eng.torch
+    infos = [probe_tap(p) for p in paths]
+    for info in infos:
+        _validate(info, expected_sample_rate_hz)
+    mono = bool(use_mono_downmix_for_stereo)
+
+    labels: List[Tuple[int, str]] = []
+    lens: List[int] = []
+    for i, info in enumerate(infos):
+        for name in channel_names(info.channels, mono):
+            labels.append((i, name))
+            lens.append(info.frames)
+    lens_a = np.asarray(lens, dtype=np.int64)
+    off = np.zeros(len(lens), dtype=np.int64)
+    if len(lens) > 1:
+        off[1:] = np.cumsum(lens_a[:-1])
+    x = eng.empty(int(lens_a.sum()), t.float32)
+
+    # ---- native files: raw int16 into pinned memory (4-byte aligned per file), one upload -------------------------
+    native = [i for i, info in enumerate(infos) if info.native and info.frames > 0]
+    pcm_off = {}
+    total = 0
+    for i in native:
+        pcm_off[i] = total
+        total += (infos[i].frames * infos[i].channels + 1) & ~1        # keep every file's stereo frames 4-byte aligned
+    if total:
+        stage = t.empty(total, dtype=t.int16).pin_memory()
+        stage_np = stage.numpy()
+        for i in native:
+            n = infos[i].frames * infos[i].channels
+            read_tap_pcm16(infos[i], stage_np[pcm_off[i] : pcm_off[i] + n])
+        pcm_dev = stage.to(eng.device, non_blocking=True)
+    first_channel = {}
+    for k, (i, _) in enumerate(labels):
+        first_channel.setdefault(i, k)
+    for i in native:
+        info = infos[i]
+        k = first_channel[i]
+        src = int(pcm_dev.data_ptr()) + 2 * pcm_off[i]
+        dst = int(x.data_ptr()) + 4 * int(off[k])
+        check(eng.lib.ira_pcm16_to_channels(src, info.frames, info.channels, 1 if (mono and info.channels == 2) else 0,
+                                            dst, eng.stream), "ira_pcm16_to_channels")
+    # ---- other encodings: decode with the Python reader, upload float32 ------------------------------------------
+    if len(native) < sum(1 for info in infos if info.frames > 0):
+        from .analyse.io import get_analysis_channels, load_wav_file
+        for i, info in enumerate(infos):
+            if info.native or info.frames == 0:
+                continue
+            loaded = load_wav_file(info.path, expected_sample_rate_hz, "mono_or_stereo", False)
+            k = first_channel[i]
+            for j, (_, c) in enumerate(get_analysis_channels(loaded, mono)):
+                o = int(off[k + j])
+                x[o : o + c.size].copy_(t.from_numpy(np.ascontiguousarray(c, dtype=np.float32)), non_blocking=False)
+    if total:
+        pcm_dev.record_stream(t.cuda.current_stream(eng.device))
+    return eng.wrap(x, off, lens_a), labels

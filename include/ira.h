@@ -324,6 +324,23 @@ int32_t ira_diffusion_stereo(const float* x_dev, const int64_t* loff_dev, const 
                              int32_t max_lag, float* corr0_dev, float* iacc_dev, const int64_t* out_off_dev,
                              void* stream);
 
+/* ---- Section 8f, rank 2: native tap ingest (RIFF/WAVE 16-bit PCM as written by the reference's C++ recorder,
+ * include/analysis/recorder.hpp:55-90) ----------------------------------------------------------------------------
+ * ira_wav_probe: HOST call; walks the RIFF chunks of `path` and reports rate / channels / frames and the byte offset
+ *   of the sample data.  IRA_OK for mono/stereo PCM16, IRA_E_UNSUPPORTED for any other valid WAV encoding (use the
+ *   Python reader), IRA_E_SIZE if the file cannot be read as RIFF/WAVE.
+ * ira_wav_read_pcm16: HOST call; reads frames*channels interleaved int16 into dst_host (ideally pinned memory).
+ * ira_pcm16_to_channels: DEVICE; interleaved int16 -> planar float32 channels (out[c*frames + i]) with the
+ *   reference's conversion x/32768 clipped to [-1, 1] (analyse/io.py:46-64, :98-113), or with mono_downmix (stereo
+ *   only) the single channel 0.5*(L+R) in float32 (analyse/io.py:85-91).  Replaces scipy.io.wavfile.read +
+ *   convert_wav_samples_to_float32 + get_analysis_channels for tap files; the upload carries 2 bytes per sample. */
+int32_t ira_wav_probe(const char* path, int32_t* sample_rate, int32_t* channels, int64_t* frames,
+                      int64_t* data_offset);
+int32_t ira_wav_read_pcm16(const char* path, int64_t data_offset, int64_t frames, int32_t channels,
+                           int16_t* dst_host);
+int32_t ira_pcm16_to_channels(const int16_t* pcm_dev, int64_t frames, int32_t channels, int32_t mono_downmix,
+                              float* out_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

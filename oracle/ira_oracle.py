@@ -68,6 +68,58 @@ def analysis_channels(samples_nc: np.ndarray, mono_downmix: bool = False) -> Lis
 
 
 # ----------------------------------------------------------------------------------------
+# section 8f rank 2: the bundle on-disk format      (reference include/analysis/recorder.hpp:49-126)
+# ----------------------------------------------------------------------------------------
+
+
+def recorder_float_to_pcm16(x: np.ndarray) -> np.ndarray:
+    """recorder.hpp:49-53: clamp to [-1, 1] in float32, multiply by 32767.0f in float32, truncate toward zero."""
+    c = np.clip(np.asarray(x, dtype=np.float32), np.float32(-1.0), np.float32(1.0))
+    return np.trunc(c * np.float32(32767.0)).astype(np.int16)
+
+
+def recorder_wav_bytes(stereo_interleaved: np.ndarray, sample_rate: int = SR) -> bytes:
+    """recorder.hpp:55-90: 44-byte RIFF/WAVE header (PCM, 2 channels, 16 bit, block align 4) + interleaved int16."""
+    import struct
+    v = np.asarray(stereo_interleaved, dtype=np.float32).reshape(-1)
+    frames = v.size // 2
+    data_bytes = frames * 4
+    hdr = (b"RIFF" + struct.pack("<I", 36 + data_bytes) + b"WAVEfmt "
+           + struct.pack("<IHHIIHH", 16, 1, 2, sample_rate, sample_rate * 4, 4, 16)
+           + b"data" + struct.pack("<I", data_bytes))
+    return hdr + recorder_float_to_pcm16(v[: frames * 2]).astype("<i2").tobytes()
+
+
+def recorder_meta_json(sample_rate: int, length_samples: int, tap_names: Sequence[str]) -> str:
+    """recorder.hpp:112-125: taps in std::map (byte-wise sorted) order."""
+    names = ", ".join(f'"{n}"' for n in sorted(tap_names, key=lambda t: t.encode()))
+    return ("{\n" + f'  "sample_rate_hz": {sample_rate},\n' + f'  "length_samples": {length_samples},\n'
+            + f'  "taps": [{names}]\n' + "}\n")
+
+
+def wav_pcm16_payload(blob: bytes) -> Tuple[int, np.ndarray]:
+    """What io.py:200 (scipy.io.wavfile.read, third-party, version recorded in goldens.json) returns for a 16-bit PCM
+    file: (sample rate, int16 array (frames, channels) or (frames,) for mono).  RIFF chunks are word aligned."""
+    import struct
+    if blob[:4] != b"RIFF" or blob[8:12] != b"WAVE":
+        raise ValueError("not a RIFF/WAVE file")
+    pos, fmt = 12, None
+    while pos + 8 <= len(blob):
+        tag, size = blob[pos : pos + 4], struct.unpack("<I", blob[pos + 4 : pos + 8])[0]
+        body = blob[pos + 8 : pos + 8 + size]
+        if tag == b"fmt ":
+            fmt = struct.unpack("<HHIIHH", body[:16])
+        elif tag == b"data":
+            if fmt is None or fmt[0] != 1 or fmt[5] != 16:
+                raise ValueError("not 16-bit PCM")
+            ch = fmt[1]
+            a = np.frombuffer(body[: (len(body) // (2 * ch)) * 2 * ch], dtype="<i2")
+            return int(fmt[2]), (a.reshape(-1, ch) if ch > 1 else a)
+        pos += 8 + size + (size & 1)
+    raise ValueError("no data chunk")
+
+
+# ----------------------------------------------------------------------------------------
 # a2  time-selection prologue (duplicated in every reference module)
 # ----------------------------------------------------------------------------------------
 

@@ -1,0 +1,122 @@
+"""
+GPU: native tap ingest.  int16 taps are uploaded as they lie on disk and converted on
+the device; the float32 channels must be BIT-IDENTICAL to what the reference's loader + channel policy produce
+(goldens from the reference reading a bundle the reference's own C++ recorder wrote; oracle on seeded extremes).
+"""
+import json
+import shutil
+import struct
+from pathlib import Path
+
+import numpy as np
+import pytest
+from scipy.io import wavfile
+
+from oracle import ira_oracle as O
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+TAPS = ["early", "late_hot"]
+SR = 48000
+
+
+def _host(batch):
+    x = batch.x.cpu().numpy()
+    return [x[o : o + n] for o, n in zip(batch.off, batch.length)]
+
+
+@pytest.mark.parametrize("mono", [False, True])
+def test_golden_bundle_channels_are_bit_exact(mono):
+    from audio_analysis_amd.engine import get_engine
+    from audio_analysis_amd.ingest import ingest_taps
+    z = np.load(GOLD / "bundle_expected.npz")
+    batch, labels = ingest_taps(get_engine(), [GOLD / "bundle" / "taps" / f"{t}.wav" for t in TAPS], mono)
+    want = [(i, ch) for i in range(2) for ch in (["mono"] if mono else ["left", "right"])]
+    assert labels == want
+    for (i, ch), got in zip(labels, _host(batch)):
+        ref = z[f"{TAPS[i]}/{'mix' if mono else 'split'}/{ch}"]
+        assert got.dtype == np.float32 and got.tobytes() == ref.tobytes()
+
+
+def test_extreme_values_ragged_lengths_and_other_encodings(tmp_path):
+    """All 65536 int16 codes, odd frame counts (alignment of the next file's payload), a mono file, an empty file and a
+    float32 file (decoded by the Python reader) in ONE batch; both channel policies."""
+    from audio_analysis_amd.engine import get_engine
+    from audio_analysis_amd.ingest import ingest_taps
+    rng = np.random.default_rng(11)
+    codes = np.arange(-32768, 32768, dtype=np.int16)
+    files = {
+        "all_codes": np.stack([codes, codes[::-1]], axis=1),                       # 65536 frames stereo
+        "odd": rng.integers(-32768, 32768, size=(1001, 2)).astype(np.int16),
+        "mono_odd": rng.integers(-32768, 32768, size=777).astype(np.int16),
+        "one": np.array([[-32768, 32767]], dtype=np.int16),
+        "f32": (rng.standard_normal((500, 2)) * 0.7).astype(np.float32),           # values beyond +-1 get clipped
+        "tail": rng.integers(-32768, 32768, size=(4096, 2)).astype(np.int16),
+    }
+    paths = []
+    for name, a in files.items():
+        p = tmp_path / f"{name}.wav"
+        wavfile.write(str(p), SR, a)
+        paths.append(p)
+    empty = tmp_path / "empty.wav"
+    empty.write_bytes(b"RIFF" + struct.pack("<I", 36) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 2, SR, SR * 4, 4, 16)
+                      + b"data" + struct.pack("<I", 0))
+    paths.insert(3, empty)
+    order = ["all_codes", "odd", "mono_odd", None, "one", "f32", "tail"]
+    for mono in (False, True):
+        batch, labels = ingest_taps(get_engine(), paths, mono)
+        got = _host(batch)
+        k = 0
+        for i, name in enumerate(order):
+            if name is None:
+                chans = [("mono", np.zeros(0, np.float32))] if mono else [("left", np.zeros(0, np.float32)),
+                                                                         ("right", np.zeros(0, np.float32))]
+            else:
+                a = files[name]
+                chans = O.analysis_channels(O.pcm_to_float32(a if a.ndim == 2 else a.reshape(-1, 1)), mono)
+            for ch, ref in chans:
+                assert labels[k] == (i, ch)
+                assert got[k].tobytes() == np.ascontiguousarray(ref, dtype=np.float32).tobytes(), (name, ch, mono)
+                k += 1
+        assert k == len(labels) == batch.count
+
+
+def test_ingest_rejects_wrong_rate(tmp_path):
+    from audio_analysis_amd.engine import get_engine
+    from audio_analysis_amd.ingest import ingest_taps
+    p = tmp_path / "r.wav"
+    wavfile.write(str(p), 44100, np.zeros((100, 2), np.int16))
+    with pytest.raises(ValueError, match="Expected sample rate 48000 Hz, but got 44100 Hz"):
+        ingest_taps(get_engine(), [p])
+
+
+def test_bundle_metrics_equal_the_float_upload_path(tmp_path):
+    """run_bundle_metrics (native ingest, several taps per step, pipelined) == FullReport over the same channels
+    uploaded as float32 from the oracle's reading of the files: byte-identical records."""
+    from audio_analysis_amd import pipeline as P
+    from audio_analysis_amd.analyse import bundle
+    from audio_analysis_amd.engine import get_engine
+    from audio_analysis_amd.synth import synth_ir
+    root = tmp_path / "b"
+    (root / "taps").mkdir(parents=True)
+    names = [f"tap{i:02d}" for i in range(5)]
+    chans = []
+    for i, name in enumerate(names):
+        st = np.stack([synth_ir(70 + i, c, 30000, rt60_seconds=0.12 + 0.02 * i) for c in (0, 1)], axis=1)
+        (root / "taps" / f"{name}.wav").write_bytes(O.recorder_wav_bytes(st))           # the recorder's format
+        f = O.pcm_to_float32(O.recorder_float_to_pcm16(st))
+        chans += [x for _, x in O.analysis_channels(f, False)]
+    (root / "meta.json").write_text(O.recorder_meta_json(SR, 30000, names))
+    labels, rec = bundle.run_bundle_metrics(root, taps_per_step=2)
+    assert labels == [(n, ch) for n in names for ch in ("left", "right")]
+    eng = get_engine()
+    want = P.FullReport(eng).run(eng.upload(chans))
+    assert rec.shape == want.shape == (10, P.METRICS_WIDTH)
+    assert rec.tobytes() == want.tobytes()
+    # the reference-written golden bundle runs end to end too
+    dst = tmp_path / "g"
+    shutil.copytree(GOLD / "bundle", dst)
+    labels, rec = bundle.run_bundle_metrics(dst, use_mono_downmix_for_stereo=True)
+    assert labels == [("early", "mono"), ("late_hot", "mono")] and rec.shape[0] == 2
+    assert json.loads((dst / "meta.json").read_text())["taps"] == TAPS
+    assert np.all(rec[:, P.M_NSAMPLES] == 12000) and np.all(rec[:, P.M_START] >= 240)
