@@ -14,16 +14,28 @@ from pathlib import Path
 from typing import List, Optional
 
 from .. import dist as _dist
-from .report import ReportSettings, run_report_from_wav_file
+from .report import ReportSettings
 
 
 @dataclass(frozen=True)
 class BundleRunSettings:
     reports_subdir: str = "reports"
     report_settings: Optional[ReportSettings] = None
+    # extra fields (defaults reproduce the reference's outputs): taps analysed per device batch, and the number of CPU
+    # worker processes that render PNGs off the critical path (0 = render inline like the reference)
+    taps_per_batch: int = 16
+    plot_workers: int = 0
 
 
 def run_bundle_report(bundle_root: str | Path, settings: Optional[BundleRunSettings] = None) -> Path:
+    """
+    reference bundle.py:35-74.  Taps are analysed `taps_per_batch` files at a time through report.run_reports_batched
+    (every block runs once over the channels of the whole group; per-tap Markdown string-identical to the per-file
+    path).  Error semantics are the reference's: the first tap that cannot be analysed raises, taps before it have
+    their reports written -- a failing group is re-run tap by tap to find it.
+    """
+    from .report import PlotPool, run_reports_batched
+
     settings = settings or BundleRunSettings()
     root = Path(bundle_root)
     meta = json.loads((root / "meta.json").read_text())
@@ -33,11 +45,25 @@ def run_bundle_report(bundle_root: str | Path, settings: Optional[BundleRunSetti
 
     rank, _, world = _dist.env_world()
     lo, hi = _dist.shard_files(len(taps), rank, world)
-    for tap in taps[lo:hi]:
-        out_dir = reports / tap
-        out_dir.mkdir(parents=True, exist_ok=True)
-        run_report_from_wav_file(input_wav_file_path=root / "taps" / f"{tap}.wav", output_basename=out_dir / tap,
-                                 settings=settings.report_settings)
+    rs = settings.report_settings
+    draw = bool(rs.render_plots) if rs is not None else True
+    pool = PlotPool(settings.plot_workers) if (settings.plot_workers > 0 and draw) else None
+    try:
+        step = max(1, int(settings.taps_per_batch))
+        for a in range(lo, hi, step):
+            group = taps[a : min(hi, a + step)]
+            items = [(root / "taps" / f"{tap}.wav", reports / tap / tap) for tap in group]
+            try:
+                run_reports_batched(items, rs, plot_pool=pool)
+            except ValueError:
+                if len(items) == 1:
+                    raise
+                for item in items:                              # find the offending tap the way the reference would
+                    run_reports_batched([item], rs, plot_pool=pool)
+                raise
+    finally:
+        if pool is not None:
+            pool.close()
     _dist.barrier()
 
     index = reports / "bundle_report.md"

@@ -144,6 +144,32 @@ def stereo_series(left: np.ndarray, right: np.ndarray, sample_rate_hz: int, sett
     return c0.cpu().numpy()[:frames].copy(), ia.cpu().numpy()[:frames].copy()
 
 
+def stereo_series_device(eng, split_batch, left_index: Sequence[int], mix_peaks: Sequence[int], sample_rate_hz: int,
+                         settings: DiffusionAnalysisSettings) -> List[Tuple[np.ndarray, np.ndarray]]:
+    """
+    stereo_series for MANY files of one device batch: file j's left channel is split_batch channel left_index[j], its
+    right channel the next one; mix_peaks[j] = argmax|0.5*(L+R)| of that file (reference diffusion.py:326-335).  One
+    launch for all files.
+    """
+    win, hop, max_lag = window_geometry(sample_rate_hz, settings)
+    li = np.asarray(left_index, dtype=np.int64)
+    n = split_batch.length[li]
+    starts = np.array([trim_start(int(n[j]), int(mix_peaks[j]) if settings.trim_to_peak else 0, sample_rate_hz, settings)
+                       for j in range(li.size)], dtype=np.int64)
+    frames = np.array([max(0, _frame_count(int(n[j] - starts[j]), win, hop)) for j in range(li.size)], dtype=np.int32)
+    empty = (np.zeros(0, dtype=np.float32), np.zeros(0, dtype=np.float32))
+    out: List[Tuple[np.ndarray, np.ndarray]] = [empty] * int(li.size)
+    live = np.flatnonzero(frames > 0)
+    if live.size:
+        c0, ia, off = eng.diffusion_stereo(split_batch.x, split_batch.off[li[live]] + starts[live],
+                                           split_batch.off[li[live] + 1] + starts[live], frames[live], win, hop, max_lag)
+        c0, ia = c0.cpu().numpy(), ia.cpu().numpy()
+        for k, j in enumerate(live):
+            o, f = int(off[k]), int(frames[j])
+            out[int(j)] = (c0[o : o + f].copy(), ia[o : o + f].copy())
+    return out
+
+
 def analyse_diffusion_from_wav_file(input_wav_file_path: str | Path,
                                     settings: Optional[DiffusionAnalysisSettings] = None
                                     ) -> List[DiffusionChannelResult]:

@@ -87,6 +87,108 @@ def channel_names(channels: int, mono_downmix: bool) -> List[str]:
     return ["left", "right"]
 
 
+class TapSet:
+    """
+    A set of tap files resident on the device: ONE upload (int16 for native taps), any number of channel-policy views.
+
+    view(mono_downmix) -> (ChannelBatch, [(file index, channel name), ...]) converts on the device
+    (ira_pcm16_to_channels) the first time a policy is asked for and caches the batch, so a report whose blocks
+    disagree about the policy (the reference's rt60bands / group delay / diffusion blocks keep their own,
+    report.py:172-186) reads and uploads every file once.
+    """
+
+    def __init__(self, eng: Engine, paths: Sequence[str | Path], expected_sample_rate_hz: int = 48_000):
+        t = eng.torch
+        self.eng = eng
+        self.infos = [probe_tap(p) for p in paths]
+        self.expected_sample_rate_hz = int(expected_sample_rate_hz)
+        for info in self.infos:
+            _validate(info, self.expected_sample_rate_hz)
+        # ---- native files: raw int16 into pinned memory (4-byte aligned per file), one upload ---------------------
+        self._native = [i for i, info in enumerate(self.infos) if info.native and info.frames > 0]
+        self._pcm_off = {}
+        total = 0
+        for i in self._native:
+            self._pcm_off[i] = total
+            total += (self.infos[i].frames * self.infos[i].channels + 1) & ~1   # stereo frames stay 4-byte aligned
+        self._pcm_dev = None
+        if total:
+            stage = t.empty(total, dtype=t.int16).pin_memory()
+            stage_np = stage.numpy()
+            for i in self._native:
+                n = self.infos[i].frames * self.infos[i].channels
+                read_tap_pcm16(self.infos[i], stage_np[self._pcm_off[i] : self._pcm_off[i] + n])
+            self._pcm_dev = stage.to(eng.device, non_blocking=True)
+        # ---- other encodings: decoded by the Python reader when first needed -------------------------------------
+        self._loaded = {}
+        self._views = {}
+
+    def __len__(self) -> int:
+        return len(self.infos)
+
+    def view(self, use_mono_downmix_for_stereo: bool = False) -> Tuple[ChannelBatch, List[Tuple[int, str]]]:
+        mono = bool(use_mono_downmix_for_stereo)
+        if mono in self._views:
+            return self._views[mono]
+        eng, t, infos = self.eng, self.eng.torch, self.infos
+        labels: List[Tuple[int, str]] = []
+        lens: List[int] = []
+        for i, info in enumerate(infos):
+            for name in channel_names(info.channels, mono):
+                labels.append((i, name))
+                lens.append(info.frames)
+        lens_a = np.asarray(lens, dtype=np.int64)
+        off = np.zeros(len(lens), dtype=np.int64)
+        if len(lens) > 1:
+            off[1:] = np.cumsum(lens_a[:-1])
+        x = eng.empty(int(lens_a.sum()), t.float32)
+        first_channel = {}
+        for k, (i, _) in enumerate(labels):
+            first_channel.setdefault(i, k)
+        for i in self._native:
+            info = infos[i]
+            src = int(self._pcm_dev.data_ptr()) + 2 * self._pcm_off[i]
+            dst = int(x.data_ptr()) + 4 * int(off[first_channel[i]])
+            check(eng.lib.ira_pcm16_to_channels(src, info.frames, info.channels,
+                                                1 if (mono and info.channels == 2) else 0, dst, eng.stream),
+                  "ira_pcm16_to_channels")
+        if self._pcm_dev is not None:
+            self._pcm_dev.record_stream(t.cuda.current_stream(eng.device))
+        for i, info in enumerate(infos):
+            if info.native or info.frames == 0:
+                continue
+            from .analyse.io import get_analysis_channels, load_wav_file
+            if i not in self._loaded:
+                self._loaded[i] = load_wav_file(info.path, self.expected_sample_rate_hz, "mono_or_stereo", False)
+            for j, (_, c) in enumerate(get_analysis_channels(self._loaded[i], mono)):
+                o = int(off[first_channel[i] + j])
+                x[o : o + c.size].copy_(t.from_numpy(np.ascontiguousarray(c, dtype=np.float32)))
+        self._views[mono] = (eng.wrap(x, off, lens_a), labels)
+        return self._views[mono]
+
+
+    def mix_peaks(self, files: Sequence[int]) -> np.ndarray:
+        """argmax |0.5*(L+R)| (first maximum) of the given STEREO files -- the alignment point of the reference's stereo
+        diffusion metrics (diffusion.py:326-335).  Native taps: peak pick of the device's mono-downmix view (for int16
+        data the float32 mean equals the reference's float64 mean rounded once).  Decoded float files: the reference's
+        own expression on the host copy, so that double rounding cannot move a tie."""
+        out = np.zeros(len(files), dtype=np.int64)
+        batch, _ = self.view(True)
+        peaks = None
+        for j, f in enumerate(files):
+            if self.infos[f].channels != 2:
+                raise ValueError("mix_peaks is defined for stereo files")
+            if f in self._loaded:
+                smp = self._loaded[f].samples
+                comb = ((smp[:, 0].astype(np.float64) + smp[:, 1].astype(np.float64)) * 0.5).astype(np.float32)
+                out[j] = int(np.argmax(np.abs(comb))) if comb.size else 0
+            else:
+                if peaks is None:
+                    peaks = self.eng.peaks(batch)
+                out[j] = int(peaks[f])                        # the downmix view holds exactly one channel per file
+        return out
+
+
 def ingest_taps(eng: Engine, paths: Sequence[str | Path], use_mono_downmix_for_stereo: bool = False,
                 expected_sample_rate_hz: int = 48_000) -> Tuple[ChannelBatch, List[Tuple[int, str]]]:
     """
@@ -95,59 +197,4 @@ def ingest_taps(eng: Engine, paths: Sequence[str | Path], use_mono_downmix_for_s
     All native taps share ONE pinned int16 staging buffer and ONE host-to-device copy; each file then gets one
     conversion launch that writes its planar channels at their place in the flat float32 batch buffer.
     """
-    t = eng.torch
-    infos = [probe_tap(p) for p in paths]
-    for info in infos:
-        _validate(info, expected_sample_rate_hz)
-    mono = bool(use_mono_downmix_for_stereo)
-
-    labels: List[Tuple[int, str]] = []
-    lens: List[int] = []
-    for i, info in enumerate(infos):
-        for name in channel_names(info.channels, mono):
-            labels.append((i, name))
-            lens.append(info.frames)
-    lens_a = np.asarray(lens, dtype=np.int64)
-    off = np.zeros(len(lens), dtype=np.int64)
-    if len(lens) > 1:
-        off[1:] = np.cumsum(lens_a[:-1])
-    x = eng.empty(int(lens_a.sum()), t.float32)
-
-    # ---- native files: raw int16 into pinned memory (4-byte aligned per file), one upload -------------------------
-    native = [i for i, info in enumerate(infos) if info.native and info.frames > 0]
-    pcm_off = {}
-    total = 0
-    for i in native:
-        pcm_off[i] = total
-        total += (infos[i].frames * infos[i].channels + 1) & ~1        # keep every file's stereo frames 4-byte aligned
-    if total:
-        stage = t.empty(total, dtype=t.int16).pin_memory()
-        stage_np = stage.numpy()
-        for i in native:
-            n = infos[i].frames * infos[i].channels
-            read_tap_pcm16(infos[i], stage_np[pcm_off[i] : pcm_off[i] + n])
-        pcm_dev = stage.to(eng.device, non_blocking=True)
-    first_channel = {}
-    for k, (i, _) in enumerate(labels):
-        first_channel.setdefault(i, k)
-    for i in native:
-        info = infos[i]
-        k = first_channel[i]
-        src = int(pcm_dev.data_ptr()) + 2 * pcm_off[i]
-        dst = int(x.data_ptr()) + 4 * int(off[k])
-        check(eng.lib.ira_pcm16_to_channels(src, info.frames, info.channels, 1 if (mono and info.channels == 2) else 0,
-                                            dst, eng.stream), "ira_pcm16_to_channels")
-    # ---- other encodings: decode with the Python reader, upload float32 ------------------------------------------
-    if len(native) < sum(1 for info in infos if info.frames > 0):
-        from .analyse.io import get_analysis_channels, load_wav_file
-        for i, info in enumerate(infos):
-            if info.native or info.frames == 0:
-                continue
-            loaded = load_wav_file(info.path, expected_sample_rate_hz, "mono_or_stereo", False)
-            k = first_channel[i]
-            for j, (_, c) in enumerate(get_analysis_channels(loaded, mono)):
-                o = int(off[k + j])
-                x[o : o + c.size].copy_(t.from_numpy(np.ascontiguousarray(c, dtype=np.float32)), non_blocking=False)
-    if total:
-        pcm_dev.record_stream(t.cuda.current_stream(eng.device))
-    return eng.wrap(x, off, lens_a), labels
+    return TapSet(eng, paths, expected_sample_rate_hz).view(use_mono_downmix_for_stereo)
