@@ -2,10 +2,10 @@
 Command-line interface: `python -m audio_analysis_amd.analyse.cli <command> ...` (also `python -m analyse.cli`
 through the top-level shim package).  Same sub-commands, flag spellings, dests and defaults as the reference's
 analyse/cli.py (:110-1186 parser, :1210-1662 dispatch) for the commands on the accelerated path:
-zplane, bundle, decay, rt60bands, fr, filter, spectrogram, waterfall, modalcloud, report.
+zplane, groupdelay, diffusion, deconvolve, bundle, decay, rt60bands, fr, filter, spectrogram, waterfall, modalcloud, report.
 The reference's inconsistent spellings are kept verbatim (--no_show vs --no-show, --ignore-leading vs
 --ignore_leading_seconds, rt60bands --trim_to_peak being store_true with default True).
-ir / deconvolve are outside the accelerated path and exit with a message.
+ir (waveform plots only) is outside the accelerated path and exits with a message.
 
 The parser is table driven: one row per flag.
 """
@@ -60,6 +60,13 @@ COMMANDS = {
         F("--max_lag_milliseconds", 10.0), F("--echo_density_threshold_rms", 1.0),
         ("--echo_density_normalise_to_gaussian", dict(action=BOOL, default=True)),
     ],
+    "deconvolve": [
+        ("--recorded_wav_file_path", dict(type=str, required=True)), ("--sweep_wav_file_path", dict(type=str, required=True)),
+        ("--output_ir_wav_file_path", dict(type=str, default=None)), F("--regularization_relative", 1e-10),
+        ("--normalise_peak", dict(action=BOOL, default=True)), F("--target_peak", 0.95),
+        ("--remove_dc", dict(action=BOOL, default=True)),
+        S("--output_length_mode", "recorded", ["recorded", "full_fft"]),
+    ],
     "bundle": [("--input", dict(dest="bundle_root", type=str, required=True)),
                S("--reports-subdir", "reports", dest="reports_subdir")],
     "decay": [
@@ -112,7 +119,7 @@ COMMANDS = {
          for k in ("ir", "decay", "rt60bands", "fr", "gd", "spectrogram", "waterfall", "diffusion", "modalcloud",
                    "echodensity")],
 }
-OUT_OF_SCOPE = ("ir", "deconvolve")
+OUT_OF_SCOPE = ("ir",)
 
 
 def build_parser() -> argparse.ArgumentParser:
@@ -285,6 +292,18 @@ def main(argv=None) -> None:
         res = run_report_from_wav_file(str(a.input_wav_file_path), str(Path(a.output_basename)), rs)
         print(res.summary_markdown)
         print(f"Wrote: {res.summary_markdown_path}")
+    elif cmd == "deconvolve":
+        from .deconvolve import DeconvolveSettings, default_output_ir_path, deconvolve_from_wav_files
+        out = a.output_ir_wav_file_path
+        out = str(default_output_ir_path(a.recorded_wav_file_path)) if out is None else str(Path(out))
+        s = DeconvolveSettings(regularization_relative=float(a.regularization_relative),
+                               normalise_peak=bool(a.normalise_peak), target_peak=float(a.target_peak),
+                               remove_dc=bool(a.remove_dc), output_length_mode=str(a.output_length_mode))
+        r = deconvolve_from_wav_files(str(a.recorded_wav_file_path), str(a.sweep_wav_file_path), s, out)
+        print(f"Wrote IR WAV: {out}")
+        print(f"  sample_rate_hz={r.sample_rate_hz}")
+        print(f"  channels={r.samples.shape[1]}")
+        print(f"  length_seconds={r.samples.shape[0] / float(r.sample_rate_hz):.3f}")
     elif cmd == "bundle":
         from .bundle import BundleRunSettings, run_bundle_report
         index = run_bundle_report(str(a.bundle_root), settings=BundleRunSettings(reports_subdir=str(a.reports_subdir)))

@@ -37,6 +37,7 @@ SOURCES = {
     "ira_modal.hip": ["-ffp-contract=off"],
     "ira_ar.hip": [],
     "ira_ingest.hip": ["-ffp-contract=off"],
+    "ira_deconv.hip": ["-ffp-contract=off"],
     # float32 arithmetic of the reference is reproduced operation by operation: no FMA contraction
     "ira_diffusion.hip": ["-ffp-contract=off"],
 }

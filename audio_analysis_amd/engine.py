@@ -871,6 +871,36 @@ class Engine:
                                          n, int(zero_order), _ptr(b), self.stream), "ira_fir_numerator")
         return b[: n * (zero_order + 1)].view(n, zero_order + 1)
 
+    # ------------------------------------------------------------------ section 8f rank 4: deconvolution
+    def deconv_divide(self, yspec_dev, yspec_off: np.ndarray, xspec_dev, xspec_off: np.ndarray, n_fft: np.ndarray,
+                      regularization_relative: float) -> None:
+        """Y <- Y conj(X) / (|X|^2 + eps) in place (see ira_deconv_divide)."""
+        t = self.torch
+        n = int(yspec_off.size)
+        n_fft = np.ascontiguousarray(n_fft, dtype=np.int32)
+        pmax = self.empty(n, t.float64)
+        # device copies stay referenced until the launch is enqueued (a temporary would hand its block back to the
+        # allocator, and the next to_dev would overwrite it before the kernel reads it)
+        d_yo, d_xo = self.to_dev(np.ascontiguousarray(yspec_off, np.int64)), self.to_dev(np.ascontiguousarray(xspec_off, np.int64))
+        d_nf = self.to_dev(n_fft)
+        check(self.lib.ira_deconv_divide(_ptr(yspec_dev), _ptr(d_yo), _ptr(xspec_dev), _ptr(d_xo), _ptr(d_nf), n,
+                                         int(n_fft.max()), float(regularization_relative), _ptr(pmax), self.stream),
+              "ira_deconv_divide")
+
+    def deconv_finish(self, h_dev, h_off: np.ndarray, n_out: np.ndarray, group: np.ndarray, remove_dc: bool,
+                      normalise_peak: bool, target_peak: float) -> None:
+        """DC removal per channel and one peak normalisation per file, in place (see ira_deconv_finish)."""
+        t = self.torch
+        n = int(h_off.size)
+        n_out = np.ascontiguousarray(n_out, dtype=np.int32)
+        group = np.ascontiguousarray(group, dtype=np.int32)
+        ngroups = int(group.max()) + 1 if n else 0
+        mean, peak = self.empty(n, t.float32), self.empty(ngroups, t.int32)
+        d_ho, d_no, d_gr = self.to_dev(np.ascontiguousarray(h_off, np.int64)), self.to_dev(n_out), self.to_dev(group)
+        check(self.lib.ira_deconv_finish(_ptr(h_dev), _ptr(d_ho), _ptr(d_no), _ptr(d_gr), n, ngroups,
+                                         int(n_out.max()) if n else 0, 1 if remove_dc else 0, 1 if normalise_peak else 0,
+                                         float(target_peak), _ptr(mean), _ptr(peak), self.stream), "ira_deconv_finish")
+
     def segment_peaks(self, x_dev, off: np.ndarray, lens: np.ndarray):
         """max|x| (float32 values as float64) of arbitrary segments."""
         t = self.torch

@@ -341,6 +341,24 @@ int32_t ira_wav_read_pcm16(const char* path, int64_t data_offset, int64_t frames
 int32_t ira_pcm16_to_channels(const int16_t* pcm_dev, int64_t frames, int32_t channels, int32_t mono_downmix,
                               float* out_dev, void* stream);
 
+/* ---- Section 8f, rank 4: sweep deconvolution (reference analyse/deconvolve.py:124-193) -----------------------------------
+ * The transforms are ira_rfft_any / ira_rfft_smooth (zero-padded to n_fft = next power of two, no window) and
+ * ira_band_irfft / ira_band_irfft_smooth (all-pass mask).  In between and after:
+ * ira_deconv_divide: element e: Y (half spectrum of nfft[e]/2+1 bins at yspec_dev + 2*yspec_off[e], overwritten) becomes
+ *   H = Y conj(X) / (|X|^2 + eps) with X at xspec_dev + 2*xspec_off[e] (elements may share one sweep spectrum) and
+ *   eps = regularization_relative * max(1e-30, max_k |X_k|^2), |X|^2 formed as hypot(re, im)^2 like numpy.abs(X)**2
+ *   (deconvolve.py:150-166).  pmax_dev: nb doubles of scratch (receives max |X|^2 per element).
+ * ira_deconv_finish: element e is one channel of length n_out[e] at h_dev + h_off[e], group[e] < ngroups its FILE:
+ *   remove_dc: h -= float32(mean(h)) per channel; normalise_peak: every channel of a file is multiplied by
+ *   float32(target_peak / max |h| over the file) unless that peak is 0 (deconvolve.py:176-189, :100-106).  mean_dev: nb
+ *   floats, peak_bits_dev: ngroups uint32 of scratch. */
+int32_t ira_deconv_divide(double* yspec_dev, const int64_t* yspec_off_dev, const double* xspec_dev,
+                          const int64_t* xspec_off_dev, const int32_t* nfft_dev, int32_t nb, int32_t max_nfft,
+                          double regularization_relative, double* pmax_dev, void* stream);
+int32_t ira_deconv_finish(float* h_dev, const int64_t* h_off_dev, const int32_t* n_out_dev, const int32_t* group_dev,
+                          int32_t nb, int32_t ngroups, int32_t max_len, int32_t remove_dc, int32_t normalise_peak,
+                          double target_peak, float* mean_dev, uint32_t* peak_bits_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

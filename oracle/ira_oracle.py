@@ -1073,3 +1073,54 @@ def diffusion_summary(names: List[str], series: List[Dict], stereo: Optional[Dic
             lines.append(f"  median_corr0={float(np.nanmedian(stereo['corr0'])):.3f}")
             lines.append(f"  median_iacc_max={float(np.nanmedian(stereo['iacc'])):.3f}")
     return "\n".join(lines)
+
+
+# ----------------------------------------------------------------------------------------
+# section 8f rank 4: sweep deconvolution                  (reference analyse/deconvolve.py:85-193)
+# ----------------------------------------------------------------------------------------
+
+
+def next_power_of_two(n: int) -> int:
+    """deconvolve.py:85-88."""
+    return 1 if n <= 1 else 1 << (int(n - 1).bit_length())
+
+
+def sweep_downmix(samples_nc: np.ndarray) -> np.ndarray:
+    """deconvolve.py:91-97: float64 mean over channels -> float32."""
+    return np.mean(samples_nc.astype(np.float64, copy=False), axis=1).astype(np.float32)
+
+
+def deconvolve(recorded: np.ndarray, sweep: np.ndarray, regularization_relative: float = 1e-10,
+               normalise_peak: bool = True, target_peak: float = 0.95, remove_dc: bool = True,
+               output_length_mode: str = "recorded") -> np.ndarray:
+    """deconvolve.py:124-193: H = Y conj(X) / (|X|^2 + eps), eps = reg * max(1e-30, max |X|^2); per channel irfft ->
+    float32, truncate, remove the float32 mean, then one peak normalisation over all channels.  (N_out, C) float32."""
+    rec = pcm_to_float32(np.asarray(recorded))
+    rec = rec.reshape(-1, 1) if rec.ndim == 1 else rec
+    sw = np.asarray(sweep, dtype=np.float32)
+    if rec.shape[0] < 8 or sw.size < 8:
+        raise ValueError("Recorded and sweep must both contain at least a few samples.")
+    n_rec = int(rec.shape[0])
+    n_fft = next_power_of_two(max(n_rec, int(sw.size)))
+    X = np.fft.rfft(sw.astype(np.float64), n=n_fft)
+    power = np.abs(X) ** 2
+    eps = float(regularization_relative) * max(1e-30, float(np.max(power)))
+    denom = power + eps
+    Xc = np.conj(X)
+    chans = []
+    for c in range(rec.shape[1]):
+        Y = np.fft.rfft(rec[:, c].astype(np.float64), n=n_fft)
+        h = np.fft.irfft((Y * Xc) / denom, n=n_fft).astype(np.float32)
+        if output_length_mode == "recorded":
+            h = h[:n_rec]
+        elif output_length_mode != "full_fft":
+            raise ValueError(f"Unknown output_length_mode: {output_length_mode}")
+        if remove_dc and h.size > 0:
+            h = (h - float(np.mean(h))).astype(np.float32)
+        chans.append(h)
+    ir = np.stack(chans, axis=1).astype(np.float32)
+    if normalise_peak:
+        peak = float(np.max(np.abs(ir))) if ir.size else 0.0
+        if peak > 0.0:
+            ir = (ir * (float(target_peak) / peak)).astype(np.float32)
+    return ir

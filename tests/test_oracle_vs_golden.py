@@ -231,3 +231,22 @@ def test_diffusion_stereo_oracle_bit_exact(golden):
     for name, v in zip((nl, nr), gd):
         np.testing.assert_array_equal(v, g[f"report/stereo16/gd/{name}"])
     assert O.group_delay_summary([nl, nr], gd) == c["report"]["stereo16/groupdelay"]["summary"]
+
+
+# ---------------------------------------------------------------------------------------- section 8f rank 4
+def test_deconvolve_oracle_reproduces_the_reference_bit_for_bit():
+    from pathlib import Path
+    z = np.load(Path(__file__).resolve().parent / "golden" / "deconvolve.npz")
+    r, sw = z["stereo/recorded_pcm16"], z["stereo/sweep"]
+    assert np.array_equal(O.deconvolve(r, sw), z["stereo/default"])
+    assert np.array_equal(O.deconvolve(r, sw, normalise_peak=False, remove_dc=False), z["stereo/raw"])
+    assert np.array_equal(O.deconvolve(r, sw, output_length_mode="full_fft", regularization_relative=1e-6,
+                                       target_peak=0.5), z["stereo/full"])
+    assert np.array_equal(O.deconvolve(z["mono/recorded_f32"], z["mono/sweep"]), z["mono/default"])
+    sweep_file = O.sweep_downmix(O.pcm_to_float32(z["file/sweep_pcm16"]))
+    assert np.array_equal(O.deconvolve(r, sweep_file), z["file/ir"])
+    assert O.next_power_of_two(15000) == 16384 and O.next_power_of_two(16384) == 16384 and O.next_power_of_two(1) == 1
+    with pytest.raises(ValueError):
+        O.deconvolve(r[:5], sw)
+    with pytest.raises(ValueError):
+        O.deconvolve(r, sw, output_length_mode="nope")
