@@ -249,11 +249,117 @@ __global__ __launch_bounds__(LAG_THREADS) void ar_lag_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Iterative refinement of the normal-equation solution (corrected semi-normal equations): for elements whose Cholesky
+// pivots show cond(G) above a threshold, the residual rho = y - A a of the CURRENT coefficients is formed from the
+// samples in float64 (rho[n] = -(s[n] + sum_k a_k s[n-k]): a short FIR over the LDS-staged chunk) and its gradient
+// g_j = sum_n s[n-j] rho[n] accumulated exactly like the lag sums; the solve kernel then adds G^-1 g to a.  Each step
+// multiplies the error by ~cond(G) eps, down to the cond(A) eps level of a QR/SVD solve (the reference's lstsq).
+// Same grid and chunking as ar_lag_kernel; partial layout [nchunks_max][p+1] per element (entry 0 unused).
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool ar_needs_refinement(const double* info, int e, double cond_threshold) {
+  const double status = info[IRA_AR_INFO_DOUBLES * e + 0];
+  if (status == 1.0) return false;                                     // no factorisation to refine with
+  return info[IRA_AR_INFO_DOUBLES * e + 3] > cond_threshold;            // trace(G) * ||G^-1|| estimate
+}
+
+__global__ __launch_bounds__(LAG_THREADS) void ar_grad_kernel(const float* __restrict__ x, const double* __restrict__ x64,
+                                                              const int64_t* __restrict__ xoff,
+                                                              const int32_t* __restrict__ nlen,
+                                                              const double* __restrict__ divisor, int p, int nchunks_max,
+                                                              const double* __restrict__ coeffs,
+                                                              const double* __restrict__ info, double cond_threshold,
+                                                              double* __restrict__ gpart) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int e = blockIdx.z;
+  if (!ar_needs_refinement(info, e, cond_threshold)) return;
+  const int chunk = blockIdx.x;
+  const long long N = nlen[e];
+  const long long row0 = (long long)p + (long long)chunk * LAG_CHUNK;
+  if (row0 >= N) return;
+  const long long n_end = (row0 + LAG_CHUNK < N) ? row0 + LAG_CHUNK : N;
+  const int rows = (int)(n_end - row0);
+  const int halo = p + 3;
+  const long long origin = row0 - halo;
+  const int nlag = p + 1, ngroups = (nlag + 3) / 4;
+  const int nsub = ngroups >= LAG_THREADS ? 1 : LAG_THREADS / ngroups;
+  double* lds = reinterpret_cast<double*>(smem_raw);                 // halo + LAG_CHUNK samples
+  double* res = lds + halo + LAG_CHUNK;                              // LAG_CHUNK residuals
+  double* co = res + LAG_CHUNK;                                      // p + 1 coefficients
+  double* red = co + nlag;                                           // [nsub][4 * ngroups]
+  const float* xs = x ? x + xoff[e] : nullptr;
+  const double* xd = x64 ? x64 + xoff[e] : nullptr;
+  const double div = divisor ? divisor[e] : 1.0;
+  const int tid = threadIdx.x;
+  for (int m = tid; m < halo + rows; m += LAG_THREADS) {
+    const long long idx = origin + m;
+    lds[m] = (idx >= 0 && idx < N) ? (xd ? xd[idx] : (double)xs[idx]) / div : 0.0;
+  }
+  for (int m = tid; m < nlag; m += LAG_THREADS) co[m] = coeffs[(long long)e * nlag + m];
+  __syncthreads();
+  for (int r = tid; r < rows; r += LAG_THREADS) {
+    const double* sn = lds + halo + r;
+    double acc = 0.0;
+    for (int k = p; k >= 1; --k) acc = fma(co[k], sn[-k], acc);      // small terms first
+    res[r] = -(sn[0] + acc);
+  }
+  __syncthreads();
+  const int sub_len = (rows + nsub - 1) / nsub;
+  for (int item = tid; item < ngroups * nsub; item += LAG_THREADS) {
+    const int g = item % ngroups, sub = item / ngroups;
+    const int b0 = 4 * g;
+    const int r_begin = sub * sub_len;
+    const int r_end = (r_begin + sub_len < rows) ? r_begin + sub_len : rows;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (r_begin < r_end) {
+      const double* cur = res + r_begin;
+      const double* lag = lds + halo + r_begin - b0;                  // s[n - b0]
+      double w1 = lag[-1], w2 = lag[-2], w3 = lag[-3];
+      for (int r = r_begin; r < r_end; ++r) {
+        const double rn = *cur++;
+        const double w0 = *lag++;
+        a0 = fma(rn, w0, a0);
+        a1 = fma(rn, w1, a1);
+        a2 = fma(rn, w2, a2);
+        a3 = fma(rn, w3, a3);
+        w3 = w2; w2 = w1; w1 = w0;
+      }
+    }
+    double* o = red + (size_t)sub * (4 * ngroups) + b0;
+    o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+  }
+  __syncthreads();
+  double* rec = gpart + ((long long)e * nchunks_max + chunk) * nlag;
+  for (int b = tid; b < nlag; b += LAG_THREADS) {
+    double sum = 0.0;
+    for (int sub = 0; sub < nsub; ++sub) sum += red[(size_t)sub * (4 * ngroups) + b];
+    rec[b] = sum;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Reduction of partials + Cholesky + solves.  One 256-thread workgroup per element.
 // The p x p matrix lives in LDS when it fits (p <= 128), otherwise in caller-provided global scratch.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int SV_THREADS = 256;
 constexpr int SV_LDS_P = 128;
+
+// L y = r (forward), L^T a = y (backward), column oriented, in place on vec; all threads of the workgroup call.
+__device__ __forceinline__ void chol_solve_inplace(const double* G, double* vec, int p, int tid) {
+  for (int k = 0; k < p; ++k) {
+    if (tid == 0) vec[k] = vec[k] / G[k * p + k];
+    __syncthreads();
+    const double yk = vec[k];
+    for (int i = k + 1 + tid; i < p; i += SV_THREADS) vec[i] -= G[i * p + k] * yk;
+    __syncthreads();
+  }
+  for (int k = p - 1; k >= 0; --k) {
+    if (tid == 0) vec[k] = vec[k] / G[k * p + k];
+    __syncthreads();
+    const double ak = vec[k];
+    for (int i = tid; i < k; i += SV_THREADS) vec[i] -= G[k * p + i] * ak;
+    __syncthreads();
+  }
+}
 
 __global__ __launch_bounds__(SV_THREADS) void ar_solve_kernel(const double* __restrict__ part,
                                                               const int32_t* __restrict__ nlen, int p,
@@ -261,12 +367,15 @@ __global__ __launch_bounds__(SV_THREADS) void ar_solve_kernel(const double* __re
                                                               double* __restrict__ gscratch,
                                                               double* __restrict__ coeffs,
                                                               double* __restrict__ info, int lag_mode,
-                                                              int lag_nchunks_max, long long lag_rec_doubles) {
+                                                              int lag_nchunks_max, long long lag_rec_doubles,
+                                                              const double* __restrict__ gpart, double cond_threshold) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __shared__ double piv;
+  __shared__ double piv, trace_s, nrm_s;
   __shared__ int fail;
   const int e = blockIdx.x;
   const int tid = threadIdx.x;
+  // refinement call (gpart != null): only flagged elements; rhs = gradient of the current residual, a += G^-1 rhs
+  if (gpart != nullptr && !ar_needs_refinement(info, e, cond_threshold)) return;
   const long long N = nlen[e];
   const int nchunks = (int)((N - p + GR_CHUNK - 1) / GR_CHUNK);
   const int ng = groups_total(p);
@@ -328,8 +437,23 @@ __global__ __launch_bounds__(SV_THREADS) void ar_solve_kernel(const double* __re
       vec[j] = s;
     }
   }
+  if (gpart != nullptr) {
+    __syncthreads();                                              // vec was written by other threads above
+    const int lchunks = lag_chunks(N, p);
+    const double* ge = gpart + (long long)e * lag_nchunks_max * (p + 1);
+    for (int j = tid; j < p; j += SV_THREADS) {
+      double c = 0.0;
+      for (int ch = 0; ch < lchunks; ++ch) c += ge[(long long)ch * (p + 1) + j + 1];
+      vec[j] = c;
+    }
+  }
   if (tid == 0) fail = 0;
   __syncthreads();
+  if (tid == 0) {
+    double tr = 0.0;
+    for (int k = 0; k < p; ++k) tr += G[k * p + k];
+    trace_s = tr;
+  }
   double dmax = 0.0, dmin = INFINITY;
 
   // ---- Cholesky, right-looking, lower triangle in place ---------------------------------------------------
@@ -354,28 +478,48 @@ __global__ __launch_bounds__(SV_THREADS) void ar_solve_kernel(const double* __re
     }
     __syncthreads();
   }
-  // ---- L y = r (forward), L^T a = y (backward), column oriented ----------------------------------------------
-  for (int k = 0; k < p; ++k) {
-    if (tid == 0) vec[k] = vec[k] / G[k * p + k];
-    __syncthreads();
-    const double yk = vec[k];
-    for (int i = k + 1 + tid; i < p; i += SV_THREADS) vec[i] -= G[i * p + k] * yk;
-    __syncthreads();
-  }
-  for (int k = p - 1; k >= 0; --k) {
-    if (tid == 0) vec[k] = vec[k] / G[k * p + k];
-    __syncthreads();
-    const double ak = vec[k];
-    for (int i = tid; i < k; i += SV_THREADS) vec[i] -= G[k * p + i] * ak;
-    __syncthreads();
-  }
+  chol_solve_inplace(G, vec, p, tid);
   double* co = coeffs + (long long)e * (p + 1);
+  if (gpart != nullptr) {
+    if (!fail)
+      for (int j = tid; j < p; j += SV_THREADS) co[j + 1] += vec[j];
+    if (tid == 0 && !fail) info[IRA_AR_INFO_DOUBLES * e + 0] = 2.0;  // refined
+    return;
+  }
   if (tid == 0) co[0] = 1.0;
   for (int j = tid; j < p; j += SV_THREADS) co[j + 1] = vec[j];
-  if (tid == 0 && info) {
-    info[3 * e + 0] = (double)fail;
-    info[3 * e + 1] = dmax;   // largest / smallest Cholesky pivot: (dmax/dmin)^2 ~ cond(G) lower bound
-    info[3 * e + 2] = dmin;
+  if (info == nullptr) return;
+  // cond(G) estimate: lambda_max <= trace(G); 1/lambda_min from two inverse iterations on the factor, started from the
+  // alternating vector (the weakest direction of a low-passed signal's Gram is the one at Nyquist).  Within a factor p
+  // above the true condition number -- it only decides whether ira_ar_refine has work to do.
+  double cond_est = INFINITY;
+  if (!fail) {
+    __syncthreads();
+    for (int j = tid; j < p; j += SV_THREADS) vec[j] = (j & 1) ? -1.0 : 1.0;
+    __syncthreads();
+    for (int it = 0; it < 2; ++it) {
+      if (tid == 0) {
+        double q = 0.0;
+        for (int j = 0; j < p; ++j) q += vec[j] * vec[j];
+        nrm_s = sqrt(q);
+      }
+      __syncthreads();
+      const double inv = 1.0 / nrm_s;
+      for (int j = tid; j < p; j += SV_THREADS) vec[j] *= inv;
+      __syncthreads();
+      chol_solve_inplace(G, vec, p, tid);
+    }
+    if (tid == 0) {
+      double q = 0.0;
+      for (int j = 0; j < p; ++j) q += vec[j] * vec[j];
+      cond_est = trace_s * sqrt(q);
+    }
+  }
+  if (tid == 0) {
+    info[IRA_AR_INFO_DOUBLES * e + 0] = (double)fail;
+    info[IRA_AR_INFO_DOUBLES * e + 1] = dmax;   // largest / smallest Cholesky pivot
+    info[IRA_AR_INFO_DOUBLES * e + 2] = dmin;
+    info[IRA_AR_INFO_DOUBLES * e + 3] = cond_est;
   }
 }
 
@@ -578,7 +722,48 @@ extern "C" int32_t ira_ar_solve(const double* partial_dev, const int32_t* len_de
   ar_solve_kernel<<<nb, SV_THREADS, lds, (hipStream_t)stream>>>(partial_dev, len_dev, order, nchunks, ridge,
                                                                  gscratch_dev, coeffs_dev, info_dev,
                                                                  ar_dense() ? 0 : 1, lag_chunks(max_len, order),
-                                                                 lag_record_doubles(max_len, order));
+                                                                 lag_record_doubles(max_len, order), nullptr, 0.0);
+  IRA_RETURN_LAUNCH();
+}
+
+extern "C" int32_t ira_ar_refine(const float* x_dev, const double* x64_dev, const int64_t* xoff_dev,
+                                 const int32_t* len_dev, const double* divisor_dev, int32_t nb, int32_t max_len,
+                                 int32_t order, const double* partial_dev, double* gscratch_dev, double* coeffs_dev,
+                                 double* info_dev, double* grad_dev, double cond_threshold, int32_t steps,
+                                 void* stream) {
+  if (x_dev == nullptr && x64_dev == nullptr) return IRA_E_NULL;
+  IRA_CHECK_PTR(xoff_dev); IRA_CHECK_PTR(len_dev); IRA_CHECK_PTR(partial_dev); IRA_CHECK_PTR(coeffs_dev);
+  IRA_CHECK_PTR(info_dev); IRA_CHECK_PTR(grad_dev);
+  const int32_t rc = ar_check(nb, max_len, order);
+  if (rc != IRA_OK || nb == 0 || steps <= 0) return rc;
+  if (steps > 4 || !(cond_threshold >= 1.0)) return IRA_E_SIZE;
+  if (order > SV_LDS_P && gscratch_dev == nullptr) return IRA_E_NULL;
+  const int lchunks = lag_chunks(max_len, order);
+  const int nlag = order + 1, ngroups = (nlag + 3) / 4;
+  const int nsub = ngroups >= LAG_THREADS ? 1 : LAG_THREADS / ngroups;
+  const size_t lds_g = sizeof(double) * ((size_t)(order + 3) + 2 * LAG_CHUNK + nlag + (size_t)nsub * 4 * ngroups);
+  if (lds_g > 64 * 1024) {
+    hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&ar_grad_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g);
+    if (er != hipSuccess) return ira_hip_status(er);
+  }
+  const int nchunks = (int)(((int64_t)max_len - order + GR_CHUNK - 1) / GR_CHUNK);
+  size_t lds_s = sizeof(double) * (size_t)order;
+  if (order <= SV_LDS_P) lds_s += sizeof(double) * (size_t)order * order;
+  if (lds_s > 64 * 1024) {
+    hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&ar_solve_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
+    if (er != hipSuccess) return ira_hip_status(er);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  for (int it = 0; it < steps; ++it) {
+    ar_grad_kernel<<<dim3(lchunks, 1, nb), LAG_THREADS, lds_g, st>>>(x64_dev ? nullptr : x_dev, x64_dev, xoff_dev, len_dev,
+                                                                      divisor_dev, order, lchunks, coeffs_dev, info_dev,
+                                                                      cond_threshold, grad_dev);
+    ar_solve_kernel<<<nb, SV_THREADS, lds_s, st>>>(partial_dev, len_dev, order, nchunks, 0.0, gscratch_dev, coeffs_dev,
+                                                    info_dev, ar_dense() ? 0 : 1, lchunks,
+                                                    lag_record_doubles(max_len, order), grad_dev, cond_threshold);
+  }
   IRA_RETURN_LAUNCH();
 }
 

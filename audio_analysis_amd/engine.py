@@ -119,6 +119,9 @@ class Engine:
         self._tables: Dict[Tuple, object] = {}
         self._filter_pools: Dict[int, dict] = {}
         self._ring = None
+        import os
+        if os.environ.get("IRA_WORKSPACE_MB"):            # tuning knob: long-FFT jobs per launch (see workspace_budget_bytes)
+            self.workspace_budget_bytes = int(float(os.environ["IRA_WORKSPACE_MB"]) * (1 << 20))
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -829,7 +832,7 @@ class Engine:
     # ------------------------------------------------------------------ a19-a21: AR pole fit
     def ar_fit(self, x_dev, xoff: np.ndarray, lengths: np.ndarray, divisor: Optional[np.ndarray], order: int,
                ridge: float = 0.0, x_is_f64: bool = False):
-        """AR coefficients (nb, order+1) float64 device + info (nb, 3) for segments of x_dev."""
+        """AR coefficients (nb, order+1) float64 device + info (nb, 4: status, pivots, cond estimate) for segments of x_dev."""
         t = self.torch
         n = int(xoff.size)
         lengths = np.ascontiguousarray(lengths, dtype=np.int32)
@@ -840,7 +843,7 @@ class Engine:
         part = self.empty(n * per, t.float64)
         gs = self.empty(n * order * order, t.float64) if order > 128 else None
         coeffs = self.empty(n * (order + 1), t.float64)
-        info = self.empty(n * 3, t.float64)
+        info = self.empty(n * 4, t.float64)
         d_xo, d_l = self.to_dev(np.ascontiguousarray(xoff, np.int64)), self.to_dev(lengths)
         d_div = self.to_dev(np.ascontiguousarray(divisor, np.float64)) if divisor is not None else None
         check(self.lib.ira_ar_gram(0 if x_is_f64 else _ptr(x_dev), _ptr(x_dev) if x_is_f64 else 0, _ptr(d_xo),
@@ -848,7 +851,19 @@ class Engine:
               "ira_ar_gram")
         check(self.lib.ira_ar_solve(_ptr(part), _ptr(d_l), n, max_len, int(order), float(ridge), _ptr(gs),
                                     _ptr(coeffs), _ptr(info), self.stream), "ira_ar_solve")
-        return coeffs[: n * (order + 1)].view(n, order + 1), info[: n * 3].view(n, 3)
+        if ridge == 0.0 and self.ar_refine_steps > 0:
+            # conditional on the device: only elements whose pivots show cond(G) > threshold do any work
+            nchunks = -(-(max_len - int(order)) // 4096)
+            grad = self.empty(n * nchunks * (order + 1), t.float64)
+            check(self.lib.ira_ar_refine(0 if x_is_f64 else _ptr(x_dev), _ptr(x_dev) if x_is_f64 else 0, _ptr(d_xo),
+                                         _ptr(d_l), _ptr(d_div), n, max_len, int(order), _ptr(part), _ptr(gs),
+                                         _ptr(coeffs), _ptr(info), _ptr(grad), float(self.ar_refine_cond),
+                                         int(self.ar_refine_steps), self.stream), "ira_ar_refine")
+        return coeffs[: n * (order + 1)].view(n, order + 1), info[: n * 4].view(n, 4)
+
+    # Normal equations lose cond(A)^2 eps; above this cond(G) estimate the fit gets refinement steps (ira_ar_refine).
+    ar_refine_cond = 1e9          # on the estimate trace(G) ||G^-1|| (<= order * cond(G))
+    ar_refine_steps = 2
 
     def poly_roots(self, coeffs_dev, npoly: int, ncoef: int, trail_eps: float = 1e-14):
         """Roots (npoly, ncoef-1, 2) float64 device + counts int32 device."""

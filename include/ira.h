@@ -244,8 +244,11 @@ int32_t ira_logbin_aggregate(const float* mag_dev, const int64_t* mag_off_dev, c
  * solve.  coeffs_dev[e*(order+1) ..] = [1, a_1 .. a_order].  Replaces _fit_ar_least_squares, reference
  * analyse/zplane.py:83-120 (which uses an SVD-based lstsq; results agree to ~cond(A)^2 * 1e-16).
  * partial_dev: nb * ira_ar_partial_doubles(order, max_len) doubles of scratch; gscratch_dev: nb*order*order
- * doubles, only needed when order > 128; info_dev (optional): 3 doubles per element
- * [0] 1 if a Cholesky pivot was not positive, [1] largest, [2] smallest pivot.  1 <= order <= 1024 < len. */
+ * doubles, only needed when order > 128; info_dev (optional): IRA_AR_INFO_DOUBLES doubles per element
+ * [0] status: 0 solved, 1 a Cholesky pivot was not positive, 2 solved and refined (ira_ar_refine), [1] largest,
+ * [2] smallest pivot, [3] condition estimate trace(G) * ||G^-1|| (two inverse iterations on the factor; between
+ * cond(G) and order * cond(G)).  1 <= order <= 1024 < len. */
+#define IRA_AR_INFO_DOUBLES 4
 int64_t ira_ar_partial_doubles(int32_t order, int32_t max_len);
 /* The two halves of ira_ar_fit, callable separately: the MFMA Gram contraction, and reduce + Cholesky solve. */
 int32_t ira_ar_gram(const float* x_dev, const double* x64_dev, const int64_t* xoff_dev,
@@ -254,6 +257,17 @@ int32_t ira_ar_gram(const float* x_dev, const double* x64_dev, const int64_t* xo
 int32_t ira_ar_solve(const double* partial_dev, const int32_t* len_dev, int32_t nb, int32_t max_len,
                      int32_t order, double ridge, double* gscratch_dev, double* coeffs_dev,
                      double* info_dev, void* stream);
+/* Iterative refinement for ill-conditioned fits (ridge = 0 only).  The reference's SVD-based lstsq is accurate to about
+ * cond(A) eps, the normal equations only to cond(A)^2 eps = cond(G) eps; elements whose condition estimate
+ * info[3] > cond_threshold get `steps` (1..4) rounds of  a += G^-1 A^T (y - A a)  with the residual and
+ * its gradient formed from the samples in float64 (corrected semi-normal equations): error ~ cond(A) eps again as long
+ * as cond(A)^2 eps < 1.  Runs after ira_ar_solve with the same partial/coeffs/info buffers; grad_dev: nb *
+ * ceil((max_len - order) / 4096) * (order + 1) doubles of scratch.  Unflagged elements cost nothing but the launch.
+ * info[0] becomes 2 for refined elements. */
+int32_t ira_ar_refine(const float* x_dev, const double* x64_dev, const int64_t* xoff_dev, const int32_t* len_dev,
+                      const double* divisor_dev, int32_t nb, int32_t max_len, int32_t order, const double* partial_dev,
+                      double* gscratch_dev, double* coeffs_dev, double* info_dev, double* grad_dev,
+                      double cond_threshold, int32_t steps, void* stream);
 int32_t ira_ar_fit(const float* x_dev, const double* x64_dev, const int64_t* xoff_dev,
                    const int32_t* len_dev, const double* divisor_dev, int32_t nb, int32_t max_len, int32_t order, double ridge,
                    double* partial_dev, double* gscratch_dev, double* coeffs_dev, double* info_dev,

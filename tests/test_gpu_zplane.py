@@ -123,3 +123,60 @@ def test_ar_lag_path_matches_dense_mfma_gram():
                 A = np.stack([s[n - k] for k in range(1, order + 1)], axis=1)
                 ref = np.linalg.lstsq(A, -s[n], rcond=None)[0]
                 assert np.max(np.abs(a[i, 1:] - ref)) / np.max(np.abs(ref)) < 1e-6, (order, i)
+
+
+def _band_limited(seed, b, a, n=48000):
+    from scipy.signal import lfilter
+    from audio_analysis_amd.synth import synth_ir
+    x = lfilter(b, a, synth_ir(seed, 0, n, rt60_seconds=0.4).astype(np.float64))
+    return (x / np.max(np.abs(x))).astype(np.float32)
+
+
+def test_ar_refinement_recovers_lstsq_accuracy_on_ill_conditioned_irs():
+    """Recordings band-limited just below Nyquist (anti-alias filters): cond(A) ~ 2e5, i.e. cond(G) ~ 5e10.  The plain
+    normal equations are off by ~1e-5 there; with the corrected-semi-normal-equation steps (ira_ar_refine, default) the
+    coefficients agree with the reference's SVD-based lstsq to 1e-8 and the pole radii to 1e-8 relative.  Well-conditioned
+    channels of the same batch are not touched (info[0] stays 0)."""
+    from scipy.signal import butter, ellip
+    from audio_analysis_amd.engine import get_engine
+    from audio_analysis_amd.analyse import zplane as zp
+    from audio_analysis_amd.synth import synth_ir
+    eng = get_engine()
+    order = 64
+    chans = [_band_limited(1, *butter(8, 18000 / 24000)), synth_ir(2, 0, 40000, rt60_seconds=0.3),
+             _band_limited(3, *ellip(8, 0.1, 100, 20000 / 24000))]
+    ref = [O.fit_ar(x.astype(np.float64), order) for x in chans]
+    b = eng.upload(chans)
+    lens = b.length.astype(np.int32)
+
+    def fit():
+        c, info = eng.ar_fit(b.x, b.off, lens, None, order)
+        return c.cpu().numpy().reshape(3, order + 1), info.cpu().numpy().reshape(3, 4)
+
+    def err(c):
+        return [float(np.max(np.abs(c[i] - ref[i])) / np.max(np.abs(ref[i]))) for i in range(3)]
+
+    c, info = fit()
+    e = err(c)
+    assert e[0] < 1e-8 and e[2] < 1e-8 and e[1] < 1e-12, e
+    assert list(info[:, 0]) == [2.0, 0.0, 2.0]                    # refined / untouched / refined
+    conds = [np.linalg.cond(np.stack([x.astype(np.float64)[np.arange(order, x.size) - k] for k in range(1, order + 1)],
+                                     axis=1)) ** 2 for x in chans]
+    for est, true in zip(info[:, 3], conds):                      # the estimate brackets cond(G) from above within p
+        assert 0.5 * true < est < 2.0 * order * true, (est, true)
+    saved = eng.ar_refine_steps
+    try:
+        eng.ar_refine_steps = 0
+        c0, info0 = fit()
+    finally:
+        eng.ar_refine_steps = saved
+    e0 = err(c0)
+    assert e0[0] > 1e-7 and e0[2] > 1e-7, e0                      # the test has teeth: unrefined fits are visibly off
+    assert np.array_equal(c0[1], c[1]) and list(info0[:, 0]) == [0.0, 0.0, 0.0]
+    # end to end through the drop-in API: pole radii against the oracle
+    res = zp.analyse_zplane_batch(chans, SR, list("abc"), zp.ZPlaneAnalysisSettings(ar_order=order))
+    for x, r in zip(chans, res):
+        o = O.analyse_zplane(x, SR, ar_order=order)
+        rad, rad_ref = np.sort(np.abs(r.poles)), np.sort(np.abs(o["poles"]))
+        assert np.max(np.abs(rad - rad_ref) / rad_ref) < 1e-7
+        assert int(np.sum(rad >= 1.0)) == o["unstable"]
