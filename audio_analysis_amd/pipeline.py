@@ -123,62 +123,104 @@ class FullReport:
                 eng.peaks(batch)                           # the one host round trip every block's geometry needs
         res: Dict[str, dict] = {}
         fut: Dict[str, object] = {}
+        state = {"spectrum": None, "filt": None}
 
-        if s.run_decay:
-            d = _decay.decay_device(eng, batch, sr, s.decay)
-            res["decay"] = d
-            fut["decay_fits"], fut["decay_cross"] = eng.fetch(d["fits"]), eng.fetch(d["cross"])
-        if s.run_rt60_bands:
-            bands, band_values, have = _bands.rt60_bands_device(eng, batch, sr, s.rt60_bands, defer=True)
-            res["rt60bands"] = dict(bands=bands, values=band_values, have=have)
-        spectrum = None
-        if s.run_frequency_response:
-            share = s.run_filter and _same_spectrum(s.frequency_response, s.filter)
-            spectrum = _fr.spectrum_device(eng, batch, sr, s.frequency_response, "spectrum", want_phase=share,
-                                           unwrap=bool(s.filter.unwrap_phase), degrees=s.filter.phase_mode == "degrees")
-            res["spectrum"] = spectrum
-            fut["spectrum_stats"] = eng.fetch(spectrum["stats"])
-        filt = None
-        if s.run_filter:
-            if spectrum is not None and spectrum["phase"] is not None:
-                filt = spectrum
-            else:
-                filt = _fr.spectrum_device(eng, batch, sr, s.filter, "filter response", want_phase=True,
-                                           unwrap=bool(s.filter.unwrap_phase), degrees=s.filter.phase_mode == "degrees")
-                res["filter"] = filt
-                fut["filter_stats"] = eng.fetch(filt["stats"])
-        if s.run_spectrogram:
-            # nothing downstream reads the matrix in this pipeline: take the frame-major layout where the kernel has it
-            sp = _spec.spectrogram_device(eng, batch, sr, s.spectrogram, frame_major=True)
-            res["spectrogram"] = sp
-            m[:, M_SPEC_FRAMES] = sp["cols"]
-        if s.run_waterfall:
-            wf = _wf.waterfall_device(eng, batch, sr, s.waterfall)
-            res["waterfall"] = wf
-            m[:, M_WF_SLICES] = wf["cols"]
-            m[:, M_WF_BINS] = wf["nsel"]
-        if s.run_modal_cloud:
-            mc = _modal.modal_cloud_device(eng, batch, sr, s.modal_cloud)
-            res["modal"] = mc
-            fut["modal_fits"] = eng.fetch(mc["fits"])
-        if s.run_zplane:
-            res["zplane"] = dict(finish=_zp.zplane_device(eng, batch, sr, s.zplane, defer=True))
-        if s.run_group_delay:
-            gdev = _gd.group_delay_device(eng, batch, sr, s.group_delay)
-            res["groupdelay"] = gdev
-            fut["gd_stats"] = _gd.summary_statistics_device(eng, gdev, sr, s.group_delay)
-        if s.run_diffusion:
-            ddev = _diff.diffusion_device(eng, batch, sr, s.diffusion)
-            res["diffusion"] = ddev
-            fut["diff_ac"], fut["diff_ed"] = eng.fetch(ddev["ac"]), eng.fetch(ddev["ed"])
-        done = t.cuda.Event()
-        done.record(t.cuda.current_stream(eng.device))
+        # ---- four independent groups of blocks; Engine.block_streams() decides how many streams they are dealt onto ------
+        def bands_group():
+            if s.run_rt60_bands:
+                bands, band_values, have = _bands.rt60_bands_device(eng, batch, sr, s.rt60_bands, defer=True)
+                res["rt60bands"] = dict(bands=bands, values=band_values, have=have)
+
+        def spectrum_group():
+            spectrum = None
+            if s.run_frequency_response:
+                share = s.run_filter and _same_spectrum(s.frequency_response, s.filter)
+                spectrum = _fr.spectrum_device(eng, batch, sr, s.frequency_response, "spectrum", want_phase=share,
+                                               unwrap=bool(s.filter.unwrap_phase),
+                                               degrees=s.filter.phase_mode == "degrees")
+                res["spectrum"] = spectrum
+                fut["spectrum_stats"] = eng.fetch(spectrum["stats"])
+            filt = None
+            if s.run_filter:
+                if spectrum is not None and spectrum["phase"] is not None:
+                    filt = spectrum
+                else:
+                    filt = _fr.spectrum_device(eng, batch, sr, s.filter, "filter response", want_phase=True,
+                                               unwrap=bool(s.filter.unwrap_phase),
+                                               degrees=s.filter.phase_mode == "degrees")
+                    res["filter"] = filt
+                    fut["filter_stats"] = eng.fetch(filt["stats"])
+            state["spectrum"], state["filt"] = spectrum, filt
+            if s.run_group_delay:
+                gdev = _gd.group_delay_device(eng, batch, sr, s.group_delay)
+                res["groupdelay"] = gdev
+                fut["gd_stats"] = _gd.summary_statistics_device(eng, gdev, sr, s.group_delay)
+
+        def modal_group():
+            if s.run_modal_cloud:
+                mc = _modal.modal_cloud_device(eng, batch, sr, s.modal_cloud)
+                res["modal"] = mc
+                fut["modal_fits"] = eng.fetch(mc["fits"])
+            if s.run_decay:
+                d = _decay.decay_device(eng, batch, sr, s.decay)
+                res["decay"] = d
+                fut["decay_fits"], fut["decay_cross"] = eng.fetch(d["fits"]), eng.fetch(d["cross"])
+
+        def stft_ar_group():
+            if s.run_spectrogram:
+                # nothing downstream reads the matrix in this pipeline: take the frame-major layout where the kernel has it
+                sp = _spec.spectrogram_device(eng, batch, sr, s.spectrogram, frame_major=True)
+                res["spectrogram"] = sp
+                m[:, M_SPEC_FRAMES] = sp["cols"]
+            if s.run_waterfall:
+                wf = _wf.waterfall_device(eng, batch, sr, s.waterfall)
+                res["waterfall"] = wf
+                m[:, M_WF_SLICES] = wf["cols"]
+                m[:, M_WF_BINS] = wf["nsel"]
+            if s.run_zplane:
+                res["zplane"] = dict(finish=_zp.zplane_device(eng, batch, sr, s.zplane, defer=True))
+            if s.run_diffusion:
+                ddev = _diff.diffusion_device(eng, batch, sr, s.diffusion)
+                res["diffusion"] = ddev
+                fut["diff_ac"], fut["diff_ed"] = eng.fetch(ddev["ac"]), eng.fetch(ddev["ed"])
+
+        main = t.cuda.current_stream(eng.device)
+        lanes = eng.block_streams()
+        groups = [bands_group, spectrum_group, modal_group, stft_ar_group]
+        done = []
+        if lanes is None:
+            for work in groups:
+                work()
+            ev = t.cuda.Event()
+            ev.record(main)
+            done.append(ev)
+        else:
+            # 2 lanes: (bands, spectrum) | (modal, stft+ar);  3: bands | spectrum | rest;  4: one group each.
+            deal = {2: [[0, 1], [2, 3]], 3: [[0], [1], [2, 3]], 4: [[0], [1], [2], [3]]}[len(lanes)]
+            # A lane waits for THIS batch's upload only (not for another lane's previous step: steps overlap across
+            # lanes) and is ordered behind its own earlier work by being a stream.  The batch's arrays were allocated
+            # on the caller's stream: record_stream keeps the allocator from recycling them while a lane may read them.
+            for lane, members in zip(lanes, deal):
+                if batch.ready is not None:
+                    lane.wait_event(batch.ready)
+                else:
+                    lane.wait_stream(main)
+                for buf in (batch.x, batch.off_dev, batch.len_dev):
+                    buf.record_stream(lane)
+                with t.cuda.stream(lane):
+                    for g in members:
+                        groups[g]()
+                    ev = t.cuda.Event()
+                    ev.record(lane)
+                    done.append(ev)
+        spectrum, filt = state["spectrum"], state["filt"]
         return dict(n=n, m=m, res=res, fut=fut, done=done, spectrum=spectrum, filt=filt)
 
     def finish(self, h: dict) -> np.ndarray:
         s = self.s
         n, m, res, fut, spectrum, filt = h["n"], h["m"], h["res"], h["fut"], h["spectrum"], h["filt"]
-        h["done"].synchronize()                            # the only wait of the step
+        for ev in h["done"]:                               # the only wait of the step (one event per lane)
+            ev.synchronize()
         # ---- the fixed-width record from the small result records (already in pinned host memory) ---------------
         if s.run_rt60_bands:
             bands = res["rt60bands"]["bands"]

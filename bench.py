@@ -6,14 +6,17 @@ bench.py -- IRs/sec of the metrics-only full report (BASELINE.json metric) on MI
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Steps are software-pipelined (submit k+1 before finishing k); all K steps complete inside the timed region.
+Steps are software-pipelined (submit k+1 before finishing k) and the independent report blocks of a step run on several
+HIP streams (Engine.block_streams); all K steps complete inside the timed region.
 One "step" = one pass of the full report (decay + rt60bands[three] + fr + filter + spectrogram + waterfall +
 modalcloud + zplane AR(64); PNG rendering, group delay and diffusion excluded -- SURVEY.md section 8d) over
 one batch of B synthetic 48 kHz, S-second mono IRs per GPU that is already resident in HBM, ending with the
 gather of the per-channel metrics records to rank 0 (RCCL when N > 1).  Weak scaling: B per GPU is fixed.
 Rank 0 prints ONE JSON line (contract in the task statement), including
-  "roofline"      for the dominant kernel (largest share of device time in the timed region), measured live with
-                  HIP events recorded on the launch stream,
+  "roofline"      for the dominant kernel (largest share of device time), measured live with HIP events recorded on the
+                  launch stream -- in a short serialised pass of the same steps (one stream) right after the timed region,
+                  because a kernel's own duration is not observable while other streams share the GPU with it
+                  ("timed_region_ms_per_step_by_call" holds the overlapped event times of the timed region itself),
   "roofline_stft" for the float32 spectrogram STFT kernel (the north-star HBM gate), same method,
   "cpu_baseline"  the oracle (NumPy restatement of the reference) timed on this box's host cores on a bounded
                   sample of the same workload.
@@ -84,6 +87,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="IRs per GPU per step")
     ap.add_argument("--seconds", type=float, default=10.0, help="IR length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-steps", type=int, default=5,
+                    help="steps of the serialised (one stream) pass that measures per-kernel durations for the rooflines")
     ap.add_argument("--literal-steps", type=int, default=5,
                     help="extra steps with the reference's default-on group-delay and diffusion blocks added "
                          "(reported as literal_full_report; 0 = skip)")
@@ -135,8 +140,27 @@ def main():
     gathered = run_steps(a.steps)
     D.barrier(); torch.cuda.synchronize()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, eng.device)
-    ev = eng.collect_events()
+    ev_timed = eng.collect_events()
     eng.events = None
+
+    # ---- per-kernel durations: a short SERIALISED pass (one stream, kernels one at a time) in the same run ---------------
+    # The timed region runs the independent report blocks on several streams (Engine.block_streams), so a kernel's
+    # event-to-event time there includes the kernels it shares the GPU with.  A kernel's roofline needs the time it takes
+    # when it owns the machine: the same steps are run once more with one lane and HIP events around every call.
+    lanes_used = eng.num_lanes
+    if lanes_used > 1:
+        eng.num_lanes = 1
+        run_steps(1)
+        D.barrier(); torch.cuda.synchronize()
+        eng.events = []
+        run_steps(a.roofline_steps)
+        D.barrier(); torch.cuda.synchronize()
+        ev = eng.collect_events()
+        eng.events = None
+        eng.num_lanes = lanes_used
+        roof_steps = a.roofline_steps
+    else:
+        ev, roof_steps = ev_timed, a.steps
 
     # ---- second, shorter measurement: the LITERAL default report (group delay + diffusion blocks added) ------------------
     literal = None
@@ -183,8 +207,8 @@ def main():
     def roof(name):
         """Roofline of one ABI call over the timed region.  Bytes (or flops) and time are both PER STEP: a call that is
         launched twice in a step (ira_rfft_any, ira_edc_db) is charged the sum of its launches."""
-        step_ms = tot[name] / a.steps
-        launches = len(ev[name]) / a.steps
+        step_ms = tot[name] / roof_steps
+        launches = len(ev[name]) / roof_steps
         nb3 = 3 if settings.rt60_bands.band_mode == "three" else None
         if name.startswith("ira_stft_mag_db") and "[f32" in name:
             b = stft_bytes(settings.spectrogram.n_fft, settings.spectrogram.hop_length)
@@ -251,8 +275,14 @@ def main():
         },
         "roofline": roof(dominant),
         "roofline_stft": roof(stft_name) if stft_name else None,
-        "device_ms_per_step_by_call": {k: v / a.steps for k, v in sorted(tot.items(), key=lambda kv: -kv[1])},
-        "device_ms_per_step": dev_ms / a.steps,
+        "roofline_measured": (f"serialised pass of {roof_steps} steps in this run (one stream, kernels one at a time); the "
+                              f"timed region deals the report blocks onto {lanes_used} streams" if lanes_used > 1 else
+                              "timed region (one stream)"),
+        "lanes": lanes_used,
+        "device_ms_per_step_by_call": {k: v / roof_steps for k, v in sorted(tot.items(), key=lambda kv: -kv[1])},
+        "device_ms_per_step": dev_ms / roof_steps,
+        "timed_region_ms_per_step_by_call": {k: sum(v) / a.steps for k, v in
+                                             sorted(ev_timed.items(), key=lambda kv: -sum(kv[1]))},
         "literal_full_report": literal,
     }
     if world == 1 and not a.no_cpu_baseline:
