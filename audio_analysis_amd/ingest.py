@@ -87,6 +87,20 @@ def channel_names(channels: int, mono_downmix: bool) -> List[str]:
     return ["left", "right"]
 
 
+_POOL = None
+
+
+def _io_pool():
+    """Threads for header probes and payload reads (file I/O + memcpy inside libira, GIL released by ctypes)."""
+    global _POOL
+    if _POOL is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 2)
+        _POOL = ThreadPoolExecutor(max_workers=max(2, min(16, n)), thread_name_prefix="ira-ingest")
+    return _POOL
+
+
 class TapSet:
     """
     A set of tap files resident on the device: ONE upload (int16 for native taps), any number of channel-policy views.
@@ -100,7 +114,8 @@ class TapSet:
     def __init__(self, eng: Engine, paths: Sequence[str | Path], expected_sample_rate_hz: int = 48_000):
         t = eng.torch
         self.eng = eng
-        self.infos = [probe_tap(p) for p in paths]
+        pool = _io_pool()
+        self.infos = list(pool.map(probe_tap, paths)) if len(paths) > 1 else [probe_tap(p) for p in paths]
         self.expected_sample_rate_hz = int(expected_sample_rate_hz)
         for info in self.infos:
             _validate(info, self.expected_sample_rate_hz)
@@ -113,11 +128,19 @@ class TapSet:
             total += (self.infos[i].frames * self.infos[i].channels + 1) & ~1   # stereo frames stay 4-byte aligned
         self._pcm_dev = None
         if total:
-            stage = t.empty(total, dtype=t.int16).pin_memory()
+            # pinned staging straight from torch's caching host allocator (a block of an earlier step is reused, nothing
+            # is pinned anew); the files are read concurrently -- libira's reader runs outside the GIL
+            stage = t.empty(total, dtype=t.int16, pin_memory=True)
             stage_np = stage.numpy()
-            for i in self._native:
+
+            def read(i):
                 n = self.infos[i].frames * self.infos[i].channels
                 read_tap_pcm16(self.infos[i], stage_np[self._pcm_off[i] : self._pcm_off[i] + n])
+
+            if len(self._native) > 1:
+                list(pool.map(read, self._native))
+            else:
+                read(self._native[0])
             self._pcm_dev = stage.to(eng.device, non_blocking=True)
         # ---- other encodings: decoded by the Python reader when first needed -------------------------------------
         self._loaded = {}
