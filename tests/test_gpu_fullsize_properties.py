@@ -134,3 +134,74 @@ def test_baseline_config_third_octave_bands_and_waterfall_ten_seconds():
     ow = O.analyse_waterfall(chans[2], SR)
     np.testing.assert_array_equal(wres[2].slice_times_seconds, ow["slice_times_seconds"])
     np.testing.assert_allclose(wres[2].slice_magnitude_rel_db, ow["slice_rel_db"], rtol=0, atol=2e-5)
+
+
+def test_baseline_config_zplane_and_modalcloud_sharded_over_ranks():
+    """BASELINE.json config 4 (zplane AR(64) + modalcloud, per-IR shards): only those two blocks enabled; the records of
+    the IRs analysed as one batch equal the concatenation of 2, 4 and 8 contiguous shards (dist.shard_files) byte for
+    byte -- what the single gather delivers on N GPUs -- and agree with the oracle on one 10 s IR."""
+    from audio_analysis_amd import pipeline as P
+    from audio_analysis_amd.dist import shard_files
+    from audio_analysis_amd.engine import get_engine
+    from audio_analysis_amd.synth import synth_ir
+    eng = get_engine()
+    s = P.FullReportSettings(run_decay=False, run_rt60_bands=False, run_frequency_response=False, run_filter=False,
+                             run_spectrogram=False, run_waterfall=False)
+    assert s.blocks() == ["modalcloud[8192/512]", "zplane[ar64]"]
+    chans = [synth_ir(900 + i, 0, N) for i in range(9)]               # 9 files: ragged last shards
+    full = P.FullReport(eng, s).run(eng.upload(chans))
+    for world in (2, 4, 8):
+        parts = []
+        for r in range(world):
+            lo, hi = shard_files(len(chans), r, world)
+            if hi > lo:
+                parts.append(P.FullReport(eng, s).run(eng.upload(chans[lo:hi])))
+        assert np.concatenate(parts, axis=0).tobytes() == full.tobytes(), world
+    z = O.analyse_zplane(chans[4], SR, ar_order=64)
+    assert abs(full[4, P.M_AR_MAX_R] - z["max_radius"]) < 1e-8 and abs(full[4, P.M_AR_MEDIAN_R] - z["median_radius"]) < 1e-8
+    assert int(full[4, P.M_AR_UNSTABLE]) == z["unstable"] and int(full[4, P.M_AR_POLES]) == 64
+    mc = O.analyse_modal_cloud(chans[4], SR)
+    rt = np.array([p[1] for p in mc["points"]])
+    assert int(full[4, P.M_MODAL_POINTS]) == rt.size
+    assert abs(full[4, P.M_MODAL_MEDIAN] - np.median(rt)) <= 1e-4 * np.median(rt)
+    assert abs(full[4, P.M_MODAL_MAX] - rt.max()) <= 1e-4 * rt.max()
+    assert np.all(np.isnan(full[:, P.M_FIT_T30 : P.M_FIT_T30 + 8]))     # disabled blocks leave their slots empty
+
+
+def test_baseline_config_bundle_of_stereo_five_second_taps(tmp_path):
+    """BASELINE.json config 5 (bundle report, stereo taps x 5 s, full pipeline) at a reduced tap count: taps in the
+    recorder's on-disk format -> native ingest -> full report, several taps per step; records equal the float-upload
+    path byte for byte and the oracle on one channel (which reads the file the way the reference would)."""
+    from audio_analysis_amd import pipeline as P
+    from audio_analysis_amd.analyse import bundle
+    from audio_analysis_amd.engine import get_engine
+    from audio_analysis_amd.synth import synth_ir
+    n = 240000
+    root = tmp_path / "b"
+    (root / "taps").mkdir(parents=True)
+    names = [f"t{i}" for i in range(6)]
+    for i, name in enumerate(names):
+        st = np.stack([synth_ir(300 + i, c, n) for c in (0, 1)], axis=1)
+        (root / "taps" / f"{name}.wav").write_bytes(O.recorder_wav_bytes(st))
+    (root / "meta.json").write_text(O.recorder_meta_json(SR, n, names))
+    labels, rec = bundle.run_bundle_metrics(root, taps_per_step=4)
+    assert labels == [(t, ch) for t in names for ch in ("left", "right")] and rec.shape == (12, P.METRICS_WIDTH)
+    _, raw = O.wav_pcm16_payload((root / "taps" / "t2.wav").read_bytes())
+    f = O.pcm_to_float32(raw)
+    chans = [x for _, x in O.analysis_channels(f, False)]
+    eng = get_engine()
+    direct = P.FullReport(eng).run(eng.upload(chans))
+    assert direct.tobytes() == rec[4:6].tobytes()
+    x = chans[1]
+    d = O.analyse_decay(x)
+    assert rec[5, P.M_START] == d["start"] and rec[5, P.M_NSAMPLES] == n
+    assert abs(rec[5, P.M_FIT_T30 + 6] - d["fits"]["T30"]["rt60"]) <= 1e-6 * d["fits"]["T30"]["rt60"]
+    b = O.analyse_rt60_bands(x)
+    for k, band in enumerate(b["bands"]):
+        ref = b["metrics"][band["name"]]["t30"]
+        got = rec[5, P.M_BANDS + 3 * k]
+        assert (ref is None) == bool(np.isnan(got))
+        if ref is not None:
+            assert abs(got - ref) <= 1e-4 * abs(ref)
+    fr = O.analyse_frequency_response(x)
+    assert rec[5, P.M_FR_PEAK] == fr["peak_hz"]
