@@ -306,7 +306,11 @@ def main(argv=None) -> None:
         print(f"  length_seconds={r.samples.shape[0] / float(r.sample_rate_hz):.3f}")
     elif cmd == "bundle":
         from .bundle import BundleRunSettings, run_bundle_report
-        index = run_bundle_report(str(a.bundle_root), settings=BundleRunSettings(reports_subdir=str(a.reports_subdir)))
+        import os
+        # flags are the reference's; the two knobs of the batched path come from the environment
+        index = run_bundle_report(str(a.bundle_root), settings=BundleRunSettings(
+            reports_subdir=str(a.reports_subdir), taps_per_batch=int(os.environ.get("IRA_TAPS_PER_BATCH", "16")),
+            plot_workers=int(os.environ.get("IRA_PLOT_WORKERS", "0"))))
         print(f"Wrote bundle report index: {index}")
     else:
         raise ValueError(f"Unknown command: {cmd}")

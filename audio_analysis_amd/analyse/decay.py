@@ -181,7 +181,10 @@ def decay_device(eng, batch, sample_rate_hz: int, settings: DecayAnalysisSetting
     return dict(edc=edc, edc_off=edc_off, starts=starts, lens=lens, fits=fits_dev, cross=cross_dev, specs=specs)
 
 
-def decay_records_to_results(dev, fits: np.ndarray, cross: np.ndarray, edc_host, sample_rate_hz, channel_names):
+def decay_records_to_results(dev, fits: np.ndarray, cross: np.ndarray, edc_host, sample_rate_hz, channel_names,
+                             with_time_axis: bool = True):
+    """Result dataclasses from the small device records; edc_host=None / with_time_axis=False leave the two per-sample
+    arrays out (summary-only callers: summarise_decay_results_text reads neither)."""
     out: List[ChannelDecayAnalysis] = []
     for i, name in enumerate(channel_names):
         t0, t10 = cross[i, 0], cross[i, 1]
@@ -195,11 +198,18 @@ def decay_records_to_results(dev, fits: np.ndarray, cross: np.ndarray, edc_host,
         o = int(dev["edc_off"][i])
         out.append(ChannelDecayAnalysis(
             channel_name=name, sample_rate_hz=sample_rate_hz, analysis_start_sample_index=int(dev["starts"][i]),
-            time_seconds=_time_axis(ln, sample_rate_hz),
+            time_seconds=_time_axis(ln, sample_rate_hz) if with_time_axis else None,
             edc_db=edc_host[o : o + ln].copy() if edc_host is not None else None,
             early_decay_10db_time_seconds=early, fits=fd,
         ))
     return out
+
+
+def decay_results_without_curves(dev, sample_rate_hz: int, channel_names) -> List[ChannelDecayAnalysis]:
+    """Result records of a device batch from its fit / crossing records alone (edc_db and time_seconds are None; no EDC
+    curve leaves HBM): everything summarise_decay_results_text reads."""
+    return decay_records_to_results(dev, dev["fits"].cpu().numpy(), dev["cross"].cpu().numpy(), None, sample_rate_hz,
+                                    channel_names, with_time_axis=False)
 
 
 def analyse_decay_batch(

@@ -173,6 +173,26 @@ def frequency_response_results(dev, sample_rate_hz: int, channel_names, settings
     return out
 
 
+def frequency_response_summary_lines(dev, sample_rate_hz: int, channel_names, settings) -> List[str]:
+    """One summarise_frequency_response_results_text line per channel from the (n, 8) statistics records alone; the
+    spectra stay in HBM.  (With the optional log-frequency smoothing the statistics depend on the smoothed curve: the
+    full path is used.)"""
+    if settings.smoothing_log_bins and int(settings.smoothing_log_bins) > 1:
+        return [summarise_frequency_response_results_text([r])
+                for r in frequency_response_results(dev, sample_rate_hz, channel_names, settings)]
+    stats = dev["stats"].cpu().numpy()
+    rows = []
+    for i, name in enumerate(channel_names):
+        st = stats[i]
+        if st[0] < 1.0:
+            raise ValueError("Selected frequency range is empty (check f_min_hz/f_max_hz).")
+        peak_hz = float(st[2])
+        centroid = float(st[3] / st[4]) if st[4] > 0.0 else float(st[5])
+        rows.append(f"[{name}] start_sample={int(dev['starts'][i])}  len_samples={int(dev['lens'][i])}  "
+                    f"peak={peak_hz:.1f}Hz  centroid={centroid:.1f}Hz")
+    return rows
+
+
 def analyse_frequency_response_for_channel(
     samples: np.ndarray,
     sample_rate_hz: int,

@@ -172,6 +172,29 @@ def finish_summary_statistics(values: np.ndarray, gam: np.ndarray, cnt: np.ndarr
     return out
 
 
+def group_delay_summary_lines(eng, dev, sample_rate_hz: int, channel_names: Sequence[str],
+                              settings: GroupDelayAnalysisSettings) -> List[Optional[str]]:
+    """One summarise_group_delay_results_text line per channel (None where the mask selects nothing) from device-side
+    order statistics (ira_order_stats); the curves stay in HBM.  (The optional moving-average smoothing is a host step:
+    the full path is used.)"""
+    if settings.smoothing_bins and settings.smoothing_bins > 1:
+        out = []
+        for r in group_delay_results(dev, sample_rate_hz, channel_names, settings):
+            text = summarise_group_delay_results_text([r])
+            out.append(text.split("\n", 1)[1] if text.startswith("Group delay summary:") else None)
+        return out
+    fut, gam, cnt = summary_statistics_device(eng, dev, sample_rate_hz, settings)
+    eng.sync()
+    st = finish_summary_statistics(fut.get(), gam, cnt)
+    return [f"- {name}: gd median={st[i, 0]:.3f} samples, p10={st[i, 1]:.3f}, p90={st[i, 2]:.3f}" if cnt[i] > 0 else None
+            for i, name in enumerate(channel_names)]
+
+
+def join_group_delay_summary(lines: Sequence[Optional[str]]) -> str:
+    kept = [ln for ln in lines if ln]
+    return "Group delay summary:\n" + "\n".join(kept) if kept else "No group delay results."
+
+
 def group_delay_results(dev, sample_rate_hz: int, channel_names: Sequence[str],
                         settings: GroupDelayAnalysisSettings, gd_host: Optional[np.ndarray] = None):
     host = dev["gd"].cpu().numpy() if gd_host is None else gd_host

@@ -175,6 +175,15 @@ class PlotPool:
         self.close()
 
 
+def _texts_per_file(per_channel: Sequence[str], labels: Sequence[Tuple[int, str]], nfiles: int, joiner: str = "\n"
+                    ) -> List[str]:
+    """Per-file summary text from one text piece per channel (the summaries are one entry per channel, in order)."""
+    out: List[List[str]] = [[] for _ in range(nfiles)]
+    for piece, (i, _) in zip(per_channel, labels):
+        out[i].append(piece)
+    return [joiner.join(p) for p in out]
+
+
 def _group(results: list, labels: Sequence[Tuple[int, str]], nfiles: int) -> List[list]:
     out: List[list] = [[] for _ in range(nfiles)]
     for r, (i, _) in zip(results, labels):
@@ -226,8 +235,11 @@ def run_reports_batched(
     if settings.run_decay:
         s = _apply_common_overrides(settings.decay_analysis_settings or DecayAnalysisSettings(), settings)
         dev = _decay.decay_device(eng, batch, sr, s)
-        res = _decay.decay_records_to_results(dev, dev["fits"].cpu().numpy(), dev["cross"].cpu().numpy(),
-                                              dev["edc"].cpu().numpy(), sr, names)
+        if draw:
+            res = _decay.decay_records_to_results(dev, dev["fits"].cpu().numpy(), dev["cross"].cpu().numpy(),
+                                                  dev["edc"].cpu().numpy(), sr, names)
+        else:                                   # text only: the EDC curves stay in HBM
+            res = _decay.decay_results_without_curves(dev, sr, names)
         for f, r in enumerate(_group(res, labels, nf)):
             if draw:
                 plot(("render_decay", (r, s, settings.decay_plot_settings or DecayPlotSettings(),
@@ -256,56 +268,78 @@ def run_reports_batched(
     if settings.run_frequency_response:
         s = _apply_common_overrides(settings.frequency_response_analysis_settings
                                     or FrequencyResponseAnalysisSettings(), settings)
-        res = _fr.frequency_response_results(_fr.spectrum_device(eng, batch, sr, s, "spectrum"), sr, names, s)
-        for f, r in enumerate(_group(res, labels, nf)):
-            if draw:
+        dev = _fr.spectrum_device(eng, batch, sr, s, "spectrum")
+        if draw:
+            res = _fr.frequency_response_results(dev, sr, names, s)
+            texts = []
+            for f, r in enumerate(_group(res, labels, nf)):
                 plot(("render_frequency_response", (r, s, settings.frequency_response_plot_settings
                                                     or FrequencyResponsePlotSettings(),
                                                     f"Frequency response (spectrum) — {wavs[f]}",
                                                     plotting.png_path(bases[f], "_fr"), show)))
+                texts.append(_fr.summarise_frequency_response_results_text(r))
+        else:                                   # text only: peak / centroid from the statistics records
+            texts = _texts_per_file(_fr.frequency_response_summary_lines(dev, sr, names, s), labels, nf)
+        for f in range(nf):
             md[f] += [_section("Frequency response"), _image(bases[f], "_fr", "Frequency response spectrum"),
-                      _code(_fr.summarise_frequency_response_results_text(r))]
+                      _code(texts[f])]
 
     if settings.run_group_delay:
         s = _apply_common_overrides(settings.group_delay_analysis_settings or GroupDelayAnalysisSettings(), settings)
         g_names, g_batch, g_labels = view(s.use_mono_downmix_for_stereo)
-        res = _gd.group_delay_results(_gd.group_delay_device(eng, g_batch, sr, s), sr, g_names, s)
+        dev = _gd.group_delay_device(eng, g_batch, sr, s)
         ps = settings.group_delay_plot_settings or GroupDelayPlotSettings()
-        for f, rs in enumerate(_group(res, g_labels, nf)):
-            if draw:
+        if draw:
+            texts = []
+            for f, rs in enumerate(_group(_gd.group_delay_results(dev, sr, g_names, s), g_labels, nf)):
                 for r in rs:
                     plot(("render_group_delay", (r, s, ps, f"Group delay ({r.channel_name})",
                                                  plotting.png_path(bases[f], f"_groupdelay_{r.channel_name}"), show)))
+                texts.append(_gd.summarise_group_delay_results_text(rs))
+        else:                                   # text only: median / p10 / p90 by device-side order statistics
+            lines = _gd.group_delay_summary_lines(eng, dev, sr, g_names, s)
+            texts = [_gd.join_group_delay_summary(g) for g in _group(lines, g_labels, nf)]
+        for f in range(nf):
             md[f] += [_section("Group delay"), _image(bases[f], "_groupdelay", "Group delay vs frequency"),
-                      _code(_gd.summarise_group_delay_results_text(rs))]
+                      _code(texts[f])]
 
     if settings.run_spectrogram:
         s = _apply_common_overrides(settings.spectrogram_analysis_settings or SpectrogramAnalysisSettings(), settings)
-        res = _spec.spectrogram_results(_spec.spectrogram_device(eng, batch, sr, s), sr, names, s)
-        for f, rs in enumerate(_group(res, labels, nf)):
-            if draw:
+        dev = _spec.spectrogram_device(eng, batch, sr, s, frame_major=not draw)
+        if draw:
+            texts = []
+            for f, rs in enumerate(_group(_spec.spectrogram_results(dev, sr, names, s), labels, nf)):
                 for r in rs:
                     plot(("render_spectrogram", (r, s, settings.spectrogram_plot_settings or SpectrogramPlotSettings(),
                                                  f"Spectrogram — {wavs[f]} — {r.channel_name}",
                                                  plotting.png_path(bases[f], f"_spectrogram_{r.channel_name}"), show)))
+                texts.append(_spec.summarise_spectrogram_results_text(rs))
+        else:                                   # text only: the matrices stay in HBM
+            texts = _texts_per_file(_spec.spectrogram_summary_lines(dev, sr, names, s), labels, nf)
+        for f in range(nf):
             md[f] += [_section("Spectrogram"), _image(bases[f], "_spectrogram_left", "Spectrogram (left)")]
             if not mono_mix:
                 md[f].append(_image(bases[f], "_spectrogram_right", "Spectrogram (right)"))
-            md[f].append(_code(_spec.summarise_spectrogram_results_text(rs)))
+            md[f].append(_code(texts[f]))
 
     if settings.run_waterfall:
         s = _apply_common_overrides(settings.waterfall_analysis_settings or WaterfallAnalysisSettings(), settings)
-        res = _wf.waterfall_results(_wf.waterfall_device(eng, batch, sr, s), sr, names, s)
-        for f, rs in enumerate(_group(res, labels, nf)):
-            if draw:
+        dev = _wf.waterfall_device(eng, batch, sr, s)
+        if draw:
+            texts = []
+            for f, rs in enumerate(_group(_wf.waterfall_results(dev, sr, names, s), labels, nf)):
                 for r in rs:
                     plot(("render_waterfall", (r, s, settings.waterfall_plot_settings or WaterfallPlotSettings(),
                                                f"Waterfall — {wavs[f]} — {r.channel_name}",
                                                plotting.png_path(bases[f], f"_waterfall_{r.channel_name}"), show)))
+                texts.append(_wf.summarise_waterfall_results_text(rs))
+        else:                                   # text only: the slice blocks stay in HBM
+            texts = _texts_per_file(_wf.waterfall_summary_lines(dev, sr, names), labels, nf)
+        for f in range(nf):
             md[f] += [_section("Waterfall"), _image(bases[f], "_waterfall_left", "Waterfall plot (left)")]
             if not mono_mix:
                 md[f].append(_image(bases[f], "_waterfall_right", "Waterfall plot (right)"))
-            md[f].append(_code(_wf.summarise_waterfall_results_text(rs)))
+            md[f].append(_code(texts[f]))
 
     if settings.run_diffusion:
         s = _apply_common_overrides(settings.diffusion_analysis_settings

@@ -121,6 +121,16 @@ def spectrogram_results(dev, sample_rate_hz: int, channel_names, settings) -> Li
     return res
 
 
+def spectrogram_summary_lines(dev, sample_rate_hz: int, channel_names, settings) -> List[str]:
+    """One summarise_spectrogram_results_text line per channel from the batch geometry alone; the matrices stay in HBM."""
+    bins = int(settings.n_fft) // 2 + 1
+    return list(
+        f"[{name}] start_sample={int(dev['starts'][i])}  len_samples={int(dev['lens'][i])}  "
+        f"dur={float(int(dev['lens'][i])) / float(int(sample_rate_hz)):.3f}s  "
+        f"stft(n_fft={bins * 2 - 2}, frames={int(dev['cols'][i])})"
+        for i, name in enumerate(channel_names))
+
+
 def analyse_spectrogram_for_channel(
     samples: np.ndarray,
     sample_rate_hz: int,

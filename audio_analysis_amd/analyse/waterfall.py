@@ -121,6 +121,15 @@ def waterfall_results(dev, sample_rate_hz: int, channel_names, settings) -> List
     return out
 
 
+def waterfall_summary_lines(dev, sample_rate_hz: int, channel_names) -> List[str]:
+    """One summarise_waterfall_results_text line per channel from the batch geometry alone; the slice blocks stay in HBM."""
+    return list(
+        f"[{name}] start_sample={int(dev['starts'][i])}  "
+        f"dur={float(int(dev['lens'][i])) / float(int(sample_rate_hz)):.3f}s  "
+        f"slices={int(np.asarray(dev['picks'][i]).size)}  f_bins={int(np.asarray(dev['f_sel']).size)}"
+        for i, name in enumerate(channel_names))
+
+
 def waterfall_device(eng, batch, sample_rate_hz: int, settings: WaterfallAnalysisSettings):
     """Device-resident waterfall: (S_i, nsel) relative-dB slice blocks in one flat float32 buffer."""
     starts, lens, nframes = select_stft_segments(eng, batch, sample_rate_hz, settings, "waterfall")

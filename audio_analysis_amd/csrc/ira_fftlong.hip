@@ -29,7 +29,6 @@ using ira::cplx;
 typedef cplx<double> cd;
 
 constexpr int FL_THREADS = 256;
-constexpr double kPi = 3.14159265358979323846;
 
 struct Geom {
   int log2m, log2n1, log2n2;
