@@ -125,7 +125,7 @@ class FullReport:
         fut: Dict[str, object] = {}
         state = {"spectrum": None, "filt": None}
 
-        # ---- four independent groups of blocks; Engine.block_streams() decides how many streams they are dealt onto ------
+        # ---- independent groups of blocks; Engine.block_streams() decides how many streams they are dealt onto -----------
         def bands_group():
             if s.run_rt60_bands:
                 bands, band_values, have = _bands.rt60_bands_device(eng, batch, sr, s.rt60_bands, defer=True)
@@ -161,12 +161,14 @@ class FullReport:
                 mc = _modal.modal_cloud_device(eng, batch, sr, s.modal_cloud)
                 res["modal"] = mc
                 fut["modal_fits"] = eng.fetch(mc["fits"])
+
+        def decay_group():
             if s.run_decay:
                 d = _decay.decay_device(eng, batch, sr, s.decay)
                 res["decay"] = d
                 fut["decay_fits"], fut["decay_cross"] = eng.fetch(d["fits"]), eng.fetch(d["cross"])
 
-        def stft_ar_group():
+        def stft_group():
             if s.run_spectrogram:
                 # nothing downstream reads the matrix in this pipeline: take the frame-major layout where the kernel has it
                 sp = _spec.spectrogram_device(eng, batch, sr, s.spectrogram, frame_major=True)
@@ -177,16 +179,18 @@ class FullReport:
                 res["waterfall"] = wf
                 m[:, M_WF_SLICES] = wf["cols"]
                 m[:, M_WF_BINS] = wf["nsel"]
-            if s.run_zplane:
-                res["zplane"] = dict(finish=_zp.zplane_device(eng, batch, sr, s.zplane, defer=True))
             if s.run_diffusion:
                 ddev = _diff.diffusion_device(eng, batch, sr, s.diffusion)
                 res["diffusion"] = ddev
                 fut["diff_ac"], fut["diff_ed"] = eng.fetch(ddev["ac"]), eng.fetch(ddev["ed"])
 
+        def zplane_group():
+            if s.run_zplane:
+                res["zplane"] = dict(finish=_zp.zplane_device(eng, batch, sr, s.zplane, defer=True))
+
         main = t.cuda.current_stream(eng.device)
         lanes = eng.block_streams()
-        groups = [bands_group, spectrum_group, modal_group, stft_ar_group]
+        groups = [bands_group, spectrum_group, zplane_group, decay_group, modal_group, stft_group]
         done = []
         if lanes is None:
             for work in groups:
@@ -195,8 +199,9 @@ class FullReport:
             ev.record(main)
             done.append(ev)
         else:
-            # 2 lanes: (bands, spectrum) | (modal, stft+ar);  3: bands | spectrum | rest;  4: one group each.
-            deal = {2: [[0, 1], [2, 3]], 3: [[0], [1], [2, 3]], 4: [[0], [1], [2], [3]]}[len(lanes)]
+            # Measured (64 x 10 s): once two or more lanes are busy the GPU is saturated -- 2, 3 and 4 lanes and several
+            # ways of dealing the groups all land within 2 % (7.2-7.4 ms per step); this deal was the best of them.
+            deal = {2: [[0, 1], [4, 3, 5, 2]], 3: [[0], [1], [4, 3, 5, 2]], 4: [[0], [1], [4, 3], [5, 2]]}[len(lanes)]
             # A lane waits for THIS batch's upload only (not for another lane's previous step: steps overlap across
             # lanes) and is ordered behind its own earlier work by being a stream.  The batch's arrays were allocated
             # on the caller's stream: record_stream keeps the allocator from recycling them while a lane may read them.

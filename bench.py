@@ -34,6 +34,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+F64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak (FMA counted as two flops)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -244,11 +245,33 @@ def main():
                     "frac": None, "traffic": None, "avg_launch_ms": step_ms / launches, "algorithmic": "not modelled"}
         ach = b / (step_ms * 1e-3) / 1e9
         tr = traffic_of(name)
-        return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": tr, "algorithmic_bytes": b, "launches_per_step": launches,
-                "avg_launch_ms": step_ms / launches, "ms_per_step": step_ms, "algorithmic": what,
-                # measured L2<->fabric traffic of the call divided by its time (what the memory system actually moved)
-                "traffic_GBps": None if tr is None else tr / (step_ms * 1e-3) / 1e9}
+        out = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": ach / HBM_PEAK_GBS, "traffic": tr, "algorithmic_bytes": b, "launches_per_step": launches,
+               "avg_launch_ms": step_ms / launches, "ms_per_step": step_ms, "algorithmic": what,
+               # measured L2<->fabric traffic of the call divided by its time (what the memory system actually moved)
+               "traffic_GBps": None if tr is None else tr / (step_ms * 1e-3) / 1e9}
+        # Whole-file float64 transforms do not fit on a CU: SURVEY.md 8(d) asks for the two-pass STREAMING model beside the
+        # compulsory bytes (every pass reads and writes its n complex values once), and they are vector-float64 work.
+        if name.startswith("ira_band_irfft_smooth") and nb3:
+            jobs = a.batch * nb3 / 2.0                                   # two bands ride one complex inverse
+            stream_b = jobs * (2 * 16.0 * n + 16.0 * n + 16.0 * n + 2 * 4.0 * n)   # spectra (both halves) in, work out/in, 2 bands out
+            flops = jobs * 5.0 * n * np.log2(n)
+        elif name.startswith("ira_rfft_smooth"):
+            jobs = a.batch / 2.0                                         # two channels ride one complex transform
+            stream_b = jobs * (2 * 4.0 * n + 16.0 * n + 16.0 * n + 16.0 * n + 16.0 * n + 2 * 16.0 * (n // 2 + 1))
+            flops = jobs * 5.0 * n * np.log2(n)
+        else:
+            stream_b = flops = None
+        if stream_b is not None:
+            out["streaming_model"] = {"bytes": stream_b, "achieved_GBps": stream_b / (step_ms * 1e-3) / 1e9,
+                                      "frac_of_hbm_peak": stream_b / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "model": "two passes over n complex float64 values per job, each read and written once, "
+                                               "plus inputs and outputs"}
+            out["flops_model"] = {"flop": flops, "achieved_TFLOPs": flops / (step_ms * 1e-3) / 1e12,
+                                  "f64_vector_peak_TFLOPs": F64_VECTOR_PEAK_TFLOPS,
+                                  "frac_of_f64_vector_peak": flops / (step_ms * 1e-3) / 1e12 / F64_VECTOR_PEAK_TFLOPS,
+                                  "model": "5 n log2 n per complex transform of n points"}
+        return out
 
     stft_name = next((k for k in tot if k.startswith("ira_stft_mag_db") and "[f32" in k), None)
     out = {
