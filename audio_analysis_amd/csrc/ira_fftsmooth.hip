@@ -289,7 +289,7 @@ __device__ __forceinline__ cd smooth_value(const SmoothPlan& P, const SJobs& J, 
 }
 
 constexpr int SM_U = 8;     // independent loads in flight per thread (pass 2)
-constexpr int SM_UC = 4;    // (pass 1: a fetch is up to four doubles)
+constexpr int SM_UC = 5;    // (pass 1: a fetch is up to four doubles; 640 x 2 columns = 5 x 256: ONE round of loads)
 
 // XCD-aware remap (speed only): workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  Neighbouring
 // column tiles read/write different 32-byte pieces of the SAME 128-byte lines; give each XCD a contiguous range of
@@ -318,6 +318,7 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_cols_kernel(SmoothPlan P, S
   const int n2_0 = (int)bx * C;
   unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
   SM_STAMP(s0);
+  build_twiddle_lds(twl, P.t1, N1, tid);                  // issued first: overlaps the input round trip below
   const int total1 = N1 * C;
   for (int base = 0; base < total1; base += SM_THREADS * SM_UC) {
     RawIn raw[SM_UC];
@@ -336,7 +337,6 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_cols_kernel(SmoothPlan P, S
       if (i < total1) a[(i % C) * N1 + i / C] = v;
     }
   }
-  build_twiddle_lds(twl, P.t1, N1, tid);
   __syncthreads();
   SM_STAMP(s1);
   const cd* r = lds_fft_stockham(a, b, N1, P.r1, P.nr1, twl, tid, C);
@@ -371,6 +371,7 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_rows_kernel(SmoothPlan P, S
   const cd* w = work + (long long)e * P.n;
   unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
   SM_STAMP(s0);
+  build_twiddle_lds(twl, P.t2, N2, tid);                  // issued first: overlaps the tile load below
   const int total2 = N2 * C;
   for (int base = 0; base < total2; base += SM_THREADS * SM_U) {
     cd raw[SM_U];
@@ -386,7 +387,6 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_rows_kernel(SmoothPlan P, S
       if (i < total2) a[(i % C) * N2 + i / C] = raw[u];
     }
   }
-  build_twiddle_lds(twl, P.t2, N2, tid);
   __syncthreads();
   SM_STAMP(s1);
   const cd* r = lds_fft_stockham(a, b, N2, P.r2, P.nr2, twl, tid, C);

@@ -260,17 +260,24 @@ def main():
             jobs = a.batch / 2.0                                         # two channels ride one complex transform
             stream_b = jobs * (2 * 4.0 * n + 16.0 * n + 16.0 * n + 16.0 * n + 16.0 * n + 2 * 16.0 * (n // 2 + 1))
             flops = jobs * 5.0 * n * np.log2(n)
+        elif name.startswith("ira_rfft_any"):
+            # Bluestein over M = 2^m >= 2*len - 1; even L runs as a complex transform of L/2 (half the convolution size).
+            tlen = np.where(L % 2 == 0, L / 2, L)
+            M = 2.0 ** np.ceil(np.log2(2 * tlen - 1))
+            stream_b = float(np.sum(4.0 * L + 16.0 * M * 5 + 16.0 * (L // 2 + 1)))     # K1 w, K2 r + filter r + w, K3 r
+            flops = float(np.sum(2 * 5.0 * M * np.log2(M) + 6.0 * M))
         else:
             stream_b = flops = None
         if stream_b is not None:
             out["streaming_model"] = {"bytes": stream_b, "achieved_GBps": stream_b / (step_ms * 1e-3) / 1e9,
                                       "frac_of_hbm_peak": stream_b / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                      "model": "two passes over n complex float64 values per job, each read and written once, "
-                                               "plus inputs and outputs"}
+                                      "model": "every pass over the job's complex float64 work array reads and writes it once "
+                                               "(two passes for the direct smooth transform, three plus the chirp-filter "
+                                               "spectrum for Bluestein), plus inputs and outputs"}
             out["flops_model"] = {"flop": flops, "achieved_TFLOPs": flops / (step_ms * 1e-3) / 1e12,
                                   "f64_vector_peak_TFLOPs": F64_VECTOR_PEAK_TFLOPS,
                                   "frac_of_f64_vector_peak": flops / (step_ms * 1e-3) / 1e12 / F64_VECTOR_PEAK_TFLOPS,
-                                  "model": "5 n log2 n per complex transform of n points"}
+                                  "model": "5 n log2 n per complex transform of n points (Bluestein: two of M points + 6 M)"}
         return out
 
     stft_name = next((k for k in tot if k.startswith("ira_stft_mag_db") and "[f32" in k), None)
