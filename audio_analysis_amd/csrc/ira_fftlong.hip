@@ -107,20 +107,49 @@ enum InMode { IN_SIGNAL = 0, IN_FILTER = 1, IN_SPECTRUM = 2 };
 enum RowMode { ROW_FWD = 0, ROW_CONV = 1 };
 enum OutMode { OUT_SPECTRUM = 0, OUT_BANDS = 1 };
 
-// w = chirp(n, L) and h = hann_at(n, L) come from the caller (recurrences along a thread's elements, see
-// cols_fwd_kernel); IN_FILTER evaluates its mirrored chirp directly (filters are plan data, built once and cached).
+// Input generation in two phases, so that ALL of a thread's global loads are in flight before the first one is used (a
+// load that is waited for inside the element loop costs one full memory round trip per element: 8 per workgroup tile):
+// fetch_input does nothing but the loads, value_input the arithmetic.  w = chirp(n, L) and h = hann_at(n, L) come from the
+// caller (recurrences along a thread's elements, see cols_fwd_kernel); IN_FILTER evaluates its mirrored chirp directly
+// (filters are plan data, built once and cached).
+struct RawL { double a, b, c, d; };
+constexpr int FL_UI = 4;    // K1: fetches in flight per thread and batch (a fetch is up to four doubles)
+constexpr int FL_U = 8;     // K2 / K3: 16-byte loads in flight per thread and batch
+
 template <int MODE>
-__device__ __forceinline__ cd gen_input(const Jobs& J, int e, long long n, long long L, long long M, cd w, double h,
-                                        double h2, long long nd1, long long nd2) {
+__device__ __forceinline__ RawL fetch_input(const Jobs& J, int e, long long n, long long L, long long nd1, long long nd2) {
+  RawL r{0.0, 0.0, 0.0, 0.0};
+  if (MODE == IN_SIGNAL) {
+    if (n < L) {
+      const long long st = (J.interleave && J.interleave[e]) ? 2 : 1;
+      if (n < nd1) r.a = (double)J.x[J.xoff[e] + st * n];
+      const long long o2 = J.x2off ? J.x2off[e] : -1;
+      if (o2 >= 0 && n < nd2) r.b = (double)J.x[o2 + st * n];
+    }
+  } else if (MODE == IN_SPECTRUM) {
+    if (n < L) {
+      const long long k = n > L / 2 ? L - n : n;
+      const cd xk = J.spec[J.spec_off[e] + k];
+      r.a = xk.re; r.b = xk.im;
+      if (J.spec_off2 != nullptr && J.spec_off2[e] != J.spec_off[e]) {
+        const cd x2 = J.spec[J.spec_off2[e] + k];
+        r.c = x2.re; r.d = x2.im;
+      }
+    }
+  }
+  return r;
+}
+
+template <int MODE>
+__device__ __forceinline__ cd value_input(const Jobs& J, int e, long long n, long long L, long long M, cd w, double h,
+                                          double h2, const RawL& r) {
   if (MODE == IN_SIGNAL) {
     if (n >= L) return {0.0, 0.0};
-    const long long st = (J.interleave && J.interleave[e]) ? 2 : 1;
-    double v = n < nd1 ? (double)J.x[J.xoff[e] + st * n] : 0.0;
-    const long long o2 = J.x2off ? J.x2off[e] : -1;
-    double v2 = (o2 >= 0 && n < nd2) ? (double)J.x[o2 + st * n] : 0.0;
+    double v = r.a, v2 = r.b;
     if (J.use_hann) {
       v *= h; v2 *= h2;
     }
+    const long long o2 = J.x2off ? J.x2off[e] : -1;
     if (o2 < 0) return {v * w.re, v * w.im};
     return {v * w.re - v2 * w.im, v * w.im + v2 * w.re};
   } else if (MODE == IN_FILTER) {
@@ -136,8 +165,7 @@ __device__ __forceinline__ cd gen_input(const Jobs& J, int e, long long n, long 
     // Hermitian extension of X * (m1 + i m2); the inverse DFT is conj(DFT(conj(.)))/L, so feed conj(W) * chirp
     const bool upper = n > L / 2;
     const long long k = upper ? L - n : n;
-    cd xk = J.spec[J.spec_off[e] + k];
-    if (upper) xk.im = -xk.im;
+    const cd xk = {r.a, upper ? -r.b : r.b};
     const float f = (float)((double)k * J.freq_val[e]);
     const double m1 = (double)mask_at(J.bands[2 * e], f);
     const double m2 = (double)mask_at(J.bands[2 * e + 1], f);
@@ -145,8 +173,7 @@ __device__ __forceinline__ cd gen_input(const Jobs& J, int e, long long n, long 
     if (J.spec_off2 == nullptr || J.spec_off2[e] == J.spec_off[e]) {
       wk = ira::cmul(xk, cd{m1, m2});
     } else {                                        // X1 m1 + i X2 m2: band 1 of one channel, band 2 of another
-      cd x2 = J.spec[J.spec_off2[e] + k];
-      if (upper) x2.im = -x2.im;
+      const cd x2 = {r.c, upper ? -r.d : r.d};
       wk = {xk.re * m1 - x2.im * m2, xk.im * m1 + x2.re * m2};
     }
     const cd cw = {wk.re, -wk.im};
@@ -216,32 +243,59 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         }
       }
     }
-    long long n = n0;
-    for (unsigned i = tid; i < N1 * (unsigned)C; i += FL_THREADS, n += dn) {
-      const unsigned n1 = i / C;
-      const double h = (lw1 > 1) ? 0.5 + 0.5 * hc : 1.0;
-      const double h2 = (lw2 > 1) ? 0.5 + 0.5 * hc2 : 1.0;
-      lds[c * stride + n1] = (g.ablate & 1) ? cd{(double)n, 1.0} : gen_input<MODE>(J, e, n, L, M, w, h, h2, nd1, nd2);
-      w = ira::cmul(w, d);
-      d = ira::cmul(d, e2);
-      const double nc = hc * rc - hs * rs;
-      hs = hs * rc + hc * rs;
-      hc = nc;
-      const double nc2 = hc2 * rc2 - hs2 * rs2;
-      hs2 = hs2 * rc2 + hc2 * rs2;
-      hc2 = nc2;
+    const unsigned total = N1 * (unsigned)C;
+    const unsigned cnt = total > (unsigned)tid ? (total - (unsigned)tid + FL_THREADS - 1) / FL_THREADS : 0u;   // my elements
+    for (unsigned jb = 0; jb < cnt; jb += FL_UI) {
+      RawL raw[FL_UI];
+#pragma unroll
+      for (int u = 0; u < FL_UI; ++u) {
+        const unsigned j = jb + u < cnt ? jb + u : cnt - 1;                 // clamp: unconditional loads
+        raw[u] = fetch_input<MODE>(J, e, n0 + (long long)j * dn, L, nd1, nd2);
+      }
+#pragma unroll
+      for (int u = 0; u < FL_UI; ++u) {
+        const unsigned j = jb + u;
+        if (j < cnt) {
+          const unsigned n1 = (tid + FL_THREADS * j) / C;
+          const long long n = n0 + (long long)j * dn;
+          const double h = (lw1 > 1) ? 0.5 + 0.5 * hc : 1.0;
+          const double h2 = (lw2 > 1) ? 0.5 + 0.5 * hc2 : 1.0;
+          lds[c * stride + n1] = (g.ablate & 1) ? cd{(double)n, 1.0} : value_input<MODE>(J, e, n, L, M, w, h, h2, raw[u]);
+          w = ira::cmul(w, d);
+          d = ira::cmul(d, e2);
+          const double nc = hc * rc - hs * rs;
+          hs = hs * rc + hc * rs;
+          hc = nc;
+          const double nc2 = hc2 * rc2 - hs2 * rs2;
+          hs2 = hs2 * rc2 + hc2 * rs2;
+          hc2 = nc2;
+        }
+      }
     }
   }
   __syncthreads();
   if (!(g.ablate & 2)) ira::lds_fft_dif<double>(lds, g.log2n1, g.t1, 1u, tid, FL_THREADS, C, stride);
   cd* w = work + (long long)e * M;
-  for (unsigned i = tid; i < N1 * (unsigned)C; i += FL_THREADS) {
-    const unsigned c = i % C, r = i / C;
-    const unsigned k1 = ira::lds_brev(r, g.log2n1);
-    const unsigned n2 = n2_0 + c;
-    const cd v = ira::cmul(lds[c * stride + r], twiddle_m(g, n2 * k1));
-    if ((g.ablate & 4) && v.re != 12345.678) continue;
-    w[(long long)r * N2 + n2] = v;
+  const unsigned total_o = N1 * (unsigned)C;
+  for (unsigned base = 0; base < total_o; base += FL_THREADS * FL_UI) {
+    cd th[FL_UI], tl[FL_UI];
+#pragma unroll
+    for (int u = 0; u < FL_UI; ++u) {
+      unsigned i = base + tid + FL_THREADS * u;
+      i = i < total_o ? i : total_o - 1;
+      const unsigned p = (n2_0 + i % C) * ira::lds_brev(i / C, g.log2n1);
+      th[u] = g.t1[p >> g.log2n2];
+      tl[u] = g.tf[p & (N2 - 1u)];
+    }
+#pragma unroll
+    for (int u = 0; u < FL_UI; ++u) {
+      const unsigned i = base + tid + FL_THREADS * u;
+      if (i >= total_o) continue;
+      const unsigned c = i % C, r = i / C;
+      const cd v = ira::cmul(lds[c * stride + r], ira::cmul(th[u], tl[u]));
+      if ((g.ablate & 4) && v.re != 12345.678) continue;
+      w[(long long)r * N2 + n2_0 + c] = v;
+    }
   }
 }
 
@@ -260,26 +314,63 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   const unsigned r0 = bx * R;
   const int tid = threadIdx.x;
   cd* w = work + (long long)e * M + (long long)r0 * N2;
-  for (unsigned i = tid; i < N2 * (unsigned)R; i += FL_THREADS) lds[i] = w[i];
+  const unsigned total = N2 * (unsigned)R;
+  for (unsigned base = 0; base < total; base += FL_THREADS * FL_U) {
+    cd raw[FL_U];
+#pragma unroll
+    for (int u = 0; u < FL_U; ++u) {
+      unsigned i = base + tid + FL_THREADS * u;
+      raw[u] = w[i < total ? i : total - 1];                  // all loads of the batch in flight together
+    }
+#pragma unroll
+    for (int u = 0; u < FL_U; ++u) {
+      const unsigned i = base + tid + FL_THREADS * u;
+      if (i < total) lds[i] = raw[u];
+    }
+  }
   __syncthreads();
   if (!(g.ablate & 8)) ira::lds_fft_dif<double>(lds, g.log2n2, g.t2, 1u, tid, FL_THREADS, R, N2);
   if (MODE == ROW_CONV) {
     const cd* b = J.bfilt + (long long)J.bidx[e] * M + (long long)r0 * N2;
     if (!(g.ablate & 16))
-      for (unsigned i = tid; i < N2 * (unsigned)R; i += FL_THREADS) lds[i] = ira::cmul(lds[i], b[i]);
+      for (unsigned base = 0; base < total; base += FL_THREADS * FL_U) {
+        cd fb[FL_U];
+#pragma unroll
+        for (int u = 0; u < FL_U; ++u) {
+          unsigned i = base + tid + FL_THREADS * u;
+          fb[u] = b[i < total ? i : total - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < FL_U; ++u) {
+          const unsigned i = base + tid + FL_THREADS * u;
+          if (i < total) lds[i] = ira::cmul(lds[i], fb[u]);
+        }
+      }
     __syncthreads();
     if (!(g.ablate & 8)) ira::lds_fft_dit<double>(lds, g.log2n2, g.t2, 1u, true, tid, FL_THREADS, R, N2);
-    for (unsigned i = tid; i < N2 * (unsigned)R; i += FL_THREADS) {
-      const unsigned rr = i >> g.log2n2, n2 = i & (N2 - 1);
-      const unsigned k1 = ira::lds_brev(r0 + rr, g.log2n1);
-      cd t = twiddle_m(g, n2 * k1);
-      t.im = -t.im;
-      const cd v = ira::cmul(lds[i], t);
-      if ((g.ablate & 128) && v.re != 12345.678) continue;
-      w[i] = v;
+    for (unsigned base = 0; base < total; base += FL_THREADS * FL_UI) {
+      cd th[FL_UI], tl[FL_UI];
+#pragma unroll
+      for (int u = 0; u < FL_UI; ++u) {
+        unsigned i = base + tid + FL_THREADS * u;
+        i = i < total ? i : total - 1;
+        const unsigned p = (i & (N2 - 1)) * ira::lds_brev(r0 + (i >> g.log2n2), g.log2n1);
+        th[u] = g.t1[p >> g.log2n2];
+        tl[u] = g.tf[p & (N2 - 1u)];
+      }
+#pragma unroll
+      for (int u = 0; u < FL_UI; ++u) {
+        const unsigned i = base + tid + FL_THREADS * u;
+        if (i >= total) continue;
+        cd t = ira::cmul(th[u], tl[u]);
+        t.im = -t.im;
+        const cd v = ira::cmul(lds[i], t);
+        if ((g.ablate & 128) && v.re != 12345.678) continue;
+        w[i] = v;
+      }
     }
   } else {
-    for (unsigned i = tid; i < N2 * (unsigned)R; i += FL_THREADS) w[i] = lds[i];
+    for (unsigned i = tid; i < total; i += FL_THREADS) w[i] = lds[i];
   }
 }
 
@@ -303,9 +394,20 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   const bool paired = (MODE == OUT_SPECTRUM) && J.x2off != nullptr && J.x2off[e] >= 0;
   const long long n_need = (MODE == OUT_SPECTRUM && !paired) ? L / 2 + 1 : L;
   const cd* w = work + (long long)e * M;
-  for (unsigned i = tid; i < N1 * (unsigned)C; i += FL_THREADS) {
-    const unsigned c = i % C, r = i / C;
-    lds[c * stride + r] = (g.ablate & 256) ? cd{(double)i, 1.0} : w[(long long)r * N2 + n2_0 + c];
+  const unsigned total = N1 * (unsigned)C;
+  for (unsigned base = 0; base < total; base += FL_THREADS * FL_U) {
+    cd raw[FL_U];
+#pragma unroll
+    for (int u = 0; u < FL_U; ++u) {
+      unsigned i = base + tid + FL_THREADS * u;
+      i = i < total ? i : total - 1;
+      raw[u] = (g.ablate & 256) ? cd{(double)i, 1.0} : w[(long long)(i / C) * N2 + n2_0 + i % C];
+    }
+#pragma unroll
+    for (int u = 0; u < FL_U; ++u) {
+      const unsigned i = base + tid + FL_THREADS * u;
+      if (i < total) lds[(i % C) * stride + i / C] = raw[u];
+    }
   }
   __syncthreads();
   if (!(g.ablate & 32)) ira::lds_fft_dit<double>(lds, g.log2n1, g.t1, 1u, true, tid, FL_THREADS, C, stride);
