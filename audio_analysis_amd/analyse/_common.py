@@ -1,8 +1,7 @@
 """Host-side helpers shared by the drop-in modules: time selection, batching, WAV channel loading."""
 from __future__ import annotations
 
-from pathlib import Path
-from typing import Callable, List, Optional, Sequence, Tuple
+from typing import Optional, Sequence, Tuple
 
 import numpy as np
 

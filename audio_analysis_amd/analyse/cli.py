@@ -12,7 +12,6 @@ The parser is table driven: one row per flag.
 from __future__ import annotations
 
 import argparse
-import sys
 from pathlib import Path
 from typing import Optional
 

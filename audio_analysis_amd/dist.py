@@ -11,7 +11,7 @@ world size.
 from __future__ import annotations
 
 import os
-from typing import List, Optional, Tuple
+from typing import Optional, Tuple
 
 import numpy as np
 

@@ -8,7 +8,6 @@ single-channel drop-in functions in audio_analysis_amd.analyse.* call them with 
 """
 from __future__ import annotations
 
-import math
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 

@@ -12,7 +12,7 @@ are not part of the step.
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, field, replace
+from dataclasses import dataclass
 from typing import Dict, List, Optional
 
 import numpy as np

@@ -233,3 +233,33 @@ def test_gloo_world2_gather_is_byte_identical(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "GATHER_OK" in outs[0]
+
+
+# ---------------------------------------------------------------------------------------- report host helpers
+def test_report_grouping_helpers_and_group_delay_quantiles():
+    """Host-side pieces of the batched / text-only report path: per-file grouping of per-channel items, the group-delay
+    summary joiner, and the order-statistic ranks that reproduce numpy.median / numpy.percentile."""
+    from audio_analysis_amd.analyse import group_delay as gd
+    from audio_analysis_amd.analyse import report as rp
+    labels = [(0, "left"), (0, "right"), (1, "mono"), (2, "left"), (2, "right")]
+    assert rp._group(list("abcde"), labels, 3) == [["a", "b"], ["c"], ["d", "e"]]
+    assert rp._texts_per_file(["L0", "R0", "M1", "L2", "R2"], labels, 3) == ["L0\nR0", "M1", "L2\nR2"]
+    assert rp._group([], [], 2) == [[], []]
+    assert gd.join_group_delay_summary(["- left: x", None, "- right: y"]) == "Group delay summary:\n- left: x\n- right: y"
+    assert gd.join_group_delay_summary([None, None]) == "No group delay results."
+    rng = np.random.default_rng(3)
+    for m in (1, 2, 3, 10, 11, 1000, 1001):
+        v = rng.standard_normal(m)
+        ranks, gam = gd.quantile_ranks(m)
+        s = np.sort(v)
+        vals = s[ranks][None, :]
+        got = gd.finish_summary_statistics(vals, gam[None, :], np.array([m]))[0]
+        assert got[0] == np.median(v) and got[1] == np.percentile(v, 10) and got[2] == np.percentile(v, 90), m
+    assert np.all(np.isnan(gd.finish_summary_statistics(np.zeros((1, 6)), np.zeros((1, 3)), np.array([0]))))
+
+
+def test_bundle_settings_defaults_reproduce_the_reference_behaviour():
+    from audio_analysis_amd.analyse.bundle import BundleRunSettings
+    s = BundleRunSettings()
+    assert s.reports_subdir == "reports" and s.report_settings is None
+    assert s.plot_workers == 0 and s.taps_per_batch >= 1           # inline rendering unless asked otherwise
