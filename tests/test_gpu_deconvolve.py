@@ -118,3 +118,16 @@ def test_batched_device_path_recovers_known_responses_at_full_size():
         # a few samples may differ between batch compositions, nothing more
         _close(one["h"].cpu().numpy()[:600000], got, "alone vs in a batch")
     _close(host[:600000].reshape(-1, 1), O.deconvolve(recs[0], sweeps[0]), "oracle spot check")
+
+
+def test_input_forms_the_reference_accepts(z):
+    """1-D (mono) recordings, int32 PCM and float64 inputs go through convert_wav_samples_to_float32 like the reference's
+    entry point; results against the oracle."""
+    from audio_analysis_amd.analyse import deconvolve as D
+    sweep = z["stereo/sweep"]
+    rec16 = z["stereo/recorded_pcm16"][:, 0]
+    cases = [rec16, (rec16.astype(np.int32) << 16), rec16.astype(np.float64) / 32768.0]
+    for rec in cases:
+        got = D.deconvolve_impulse_response(rec, sweep, SR, D.DeconvolveSettings())
+        assert got.shape == (15000, 1)
+        _close(got, O.deconvolve(rec, sweep), str(rec.dtype))

@@ -120,3 +120,44 @@ def test_bundle_metrics_equal_the_float_upload_path(tmp_path):
     assert labels == [("early", "mono"), ("late_hot", "mono")] and rec.shape[0] == 2
     assert json.loads((dst / "meta.json").read_text())["taps"] == TAPS
     assert np.all(rec[:, P.M_NSAMPLES] == 12000) and np.all(rec[:, P.M_START] >= 240)
+
+
+def test_bundle_edge_cases_empty_and_mono(tmp_path, capsys):
+    """A bundle without taps gives an index and empty records; mono PCM16 taps (not what the recorder writes, but what
+    the reference's loader accepts) run through both bundle paths; the CLI's bundle command works with the batched-path
+    knobs taken from the environment."""
+    import os
+    from audio_analysis_amd import pipeline as P
+    from audio_analysis_amd.analyse import bundle, cli, report as rp
+    from audio_analysis_amd.synth import synth_ir
+    empty = tmp_path / "empty"
+    (empty / "taps").mkdir(parents=True)
+    (empty / "meta.json").write_text(json.dumps({"sample_rate_hz": SR, "length_samples": 0, "taps": []}))
+    labels, rec = bundle.run_bundle_metrics(empty)
+    assert labels == [] and rec.shape == (0, P.METRICS_WIDTH)
+    idx = bundle.run_bundle_report(empty)
+    assert idx.read_text().startswith("# IR Bundle Report\n") and "## Taps" in idx.read_text()
+
+    mono = tmp_path / "mono"
+    (mono / "taps").mkdir(parents=True)
+    x = synth_ir(5, 0, 20000, rt60_seconds=0.1)
+    pcm = O.recorder_float_to_pcm16(x)
+    for name in ("m1", "m2"):
+        wavfile.write(str(mono / "taps" / f"{name}.wav"), SR, pcm)
+    (mono / "meta.json").write_text(json.dumps({"sample_rate_hz": SR, "length_samples": 20000, "taps": ["m1", "m2"]}))
+    labels, rec = bundle.run_bundle_metrics(mono)
+    assert labels == [("m1", "mono"), ("m2", "mono")] and rec[0].tobytes() == rec[1].tobytes()
+    d = O.analyse_decay(O.pcm_to_float32(pcm))
+    assert rec[0, P.M_START] == d["start"]
+    os.environ["IRA_TAPS_PER_BATCH"] = "2"
+    try:
+        # PNG rendering is inline here (the reference's behaviour); keep the run short: two 0.4 s taps
+        cli.main(["bundle", "--input", str(mono), "--reports-subdir", "rep2"])
+    finally:
+        os.environ.pop("IRA_TAPS_PER_BATCH", None)
+    assert capsys.readouterr().out.strip() == f"Wrote bundle report index: {mono / 'rep2' / 'bundle_report.md'}"
+    md = (mono / "rep2" / "m1" / "m1_report.md").read_text()
+    single = rp.run_report_from_wav_file(mono / "taps" / "m1.wav", tmp_path / "s" / "m1",
+                                         rp.ReportSettings(render_plots=False))
+    assert md.replace(str(mono / "taps" / "m1.wav"), "@") == single.summary_markdown.replace(str(mono / "taps" / "m1.wav"), "@")
+    assert (mono / "rep2" / "m2" / "m2_spectrogram_mono.png").stat().st_size > 1000
