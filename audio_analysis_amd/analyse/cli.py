@@ -2,10 +2,10 @@
 Command-line interface: `python -m audio_analysis_amd.analyse.cli <command> ...` (also `python -m analyse.cli`
 through the top-level shim package).  Same sub-commands, flag spellings, dests and defaults as the reference's
 analyse/cli.py (:110-1186 parser, :1210-1662 dispatch) for the commands on the accelerated path:
-zplane, groupdelay, diffusion, deconvolve, bundle, decay, rt60bands, fr, filter, spectrogram, waterfall, modalcloud, report.
+ir, zplane, groupdelay, diffusion, deconvolve, bundle, decay, rt60bands, fr, filter, spectrogram, waterfall, modalcloud, report.
 The reference's inconsistent spellings are kept verbatim (--no_show vs --no-show, --ignore-leading vs
 --ignore_leading_seconds, rt60bands --trim_to_peak being store_true with default True).
-ir (waveform plots only) is outside the accelerated path and exits with a message.
+ir draws its three waveform PNGs on the CPU (there are no numerics in it).
 
 The parser is table driven: one row per flag.
 """
@@ -39,6 +39,10 @@ def S(name, default, choices=None, **kw):
 
 
 COMMANDS = {
+    "ir": [
+        INPUT, F("--early-window", 0.08, dest="early_window_seconds"), F("--floor-db", -120.0, dest="log_magnitude_floor_db"),
+        ("--mono", dict(dest="use_mono_downmix", action="store_true")), OUTPUT, NO_SHOW,
+    ],
     "zplane": [
         INPUT, OUTPUT, ("--no-show", dict(dest="no_show", action="store_true")),
         ("--mono", dict(dest="use_mono_downmix_for_stereo", action="store_true")),
@@ -118,7 +122,7 @@ COMMANDS = {
          for k in ("ir", "decay", "rt60bands", "fr", "gd", "spectrogram", "waterfall", "diffusion", "modalcloud",
                    "echodensity")],
 }
-OUT_OF_SCOPE = ("ir",)
+OUT_OF_SCOPE = ()
 
 
 def build_parser() -> argparse.ArgumentParser:
@@ -148,7 +152,14 @@ def main(argv=None) -> None:
     if cmd in OUT_OF_SCOPE:
         raise SystemExit(f"'{cmd}' is outside the GPU-accelerated path of audio_analysis_amd; use the reference for it.")
 
-    if cmd == "decay":
+    if cmd == "ir":
+        from .impulse_response import ImpulseResponseViewSettings, plot_ir_from_wav_file
+        plot_ir_from_wav_file(str(a.input_wav_file_path),
+                              ImpulseResponseViewSettings(early_window_seconds=float(a.early_window_seconds),
+                                                          log_magnitude_floor_db=float(a.log_magnitude_floor_db),
+                                                          use_mono_downmix=bool(a.use_mono_downmix)),
+                              _basename(a), not bool(a.no_show))
+    elif cmd == "decay":
         from .decay import DecayAnalysisSettings, DecayPlotSettings, plot_decay_from_wav_file, summarise_decay_results_text
         s = DecayAnalysisSettings(
             trim_to_peak=bool(a.trim_to_peak), ignore_leading_seconds=float(a.ignore_leading_seconds),

@@ -57,6 +57,15 @@ def _log_hz(ax, lo, hi, axis="x"):
         ax.yaxis.set_major_formatter(mt.FuncFormatter(fmt)); ax.yaxis.set_minor_formatter(mt.NullFormatter())
 
 
+def render_ir_views(wav_path, settings, output_basename, expected_sample_rate_hz):
+    """The three impulse-response PNGs of one file (reads the WAV itself: it runs in a plot worker as well)."""
+    from . import impulse_response as irv
+    from .io import load_wav_file
+    loaded = load_wav_file(wav_path, expected_sample_rate_hz=expected_sample_rate_hz,
+                           expected_channel_mode="mono_or_stereo", allow_mono_and_upmix_to_stereo=False)
+    irv.plot_ir_views(loaded, settings, output_basename, False)
+
+
 def render_decay(results, settings, plot_settings, title, path, show):
     if path is None and not show:
         return

@@ -10,8 +10,9 @@ header block.  Differences, all outside the accelerated path:
   * run_reports_batched runs every block ONCE over the channels of MANY files and
     writes each file's Markdown from its slice of the results -- string-identical to the per-file path; PNG rendering
     can be handed to a pool of CPU worker processes (`plot_pool`) so it leaves the critical path;
-  * the impulse-response waveform plots are not implemented: when requested they are
-    skipped and listed at the end of the Markdown.  Group delay and diffusion (section 8f rows) run on the GPU;
+  * the impulse-response waveform plots (no numerics) are drawn on the CPU from the host copy of the file, only when
+    PNGs are rendered at all; their Markdown block is always the reference's.  Group delay and diffusion (section 8f
+    rows) run on the GPU;
   * `render_plots=False` (extra field, default True) skips the CPU-side PNG rendering.
 """
 from __future__ import annotations
@@ -26,6 +27,7 @@ from . import decay as _decay
 from . import diffusion as _diff
 from . import frequency_response as _fr
 from . import group_delay as _gd
+from . import impulse_response as _irv
 from . import modalcloud as _modal
 from . import plotting
 from . import rt60bands as _bands
@@ -230,7 +232,12 @@ def run_reports_batched(
     skipped: List[str] = []
 
     if settings.run_impulse_response_plots:
-        skipped.append("impulse response plots")
+        ir = _apply_common_overrides(settings.ir_view_settings or _irv.ImpulseResponseViewSettings(), settings)
+        for f in range(nf):
+            if draw:
+                plot(("render_ir_views", (str(wavs[f]), ir, str(bases[f]), settings.expected_sample_rate_hz)))
+            md[f] += [_section("Impulse response"), _image(bases[f], "", "Impulse response overview"),
+                      _image(bases[f], "_early", "Early reflections"), _image(bases[f], "_tail", "Tail (log magnitude)")]
 
     if settings.run_decay:
         s = _apply_common_overrides(settings.decay_analysis_settings or DecayAnalysisSettings(), settings)

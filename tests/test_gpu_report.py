@@ -44,14 +44,35 @@ def test_report_markdown_matches_reference(tmp_path, golden, name, variant):
     assert res.summary_markdown_path.read_text() == want
 
 
-def test_report_lists_skipped_blocks_and_renders_pngs(tmp_path, golden):
+@pytest.mark.parametrize("name,tag,kw", [
+    ("stereo16", "literal", {}), ("stereo16", "literal_mono", dict(common_use_mono_downmix_for_stereo=True)),
+    ("mono16", "literal", {})])
+def test_literal_default_report_markdown_and_png_set(tmp_path, name, tag, kw):
+    """`ReportSettings()` exactly as `python -m analyse.cli report` builds it: every block on, impulse-response plots
+    included, PNGs rendered.  Markdown string-identical to the reference's (tests/golden/report_literal.json, made by
+    tests/golden/make_literal_report_golden.py) and the SAME SET of PNG files written."""
+    import json as _json
     from audio_analysis_amd.analyse import report as rp
-    wav = _write(tmp_path, golden, "mono16")
-    res = rp.run_report_from_wav_file(wav, tmp_path / "o" / "r", rp.ReportSettings(run_waterfall=False, run_modal_cloud=False))
-    assert "## Skipped blocks" in res.summary_markdown and "impulse response plots" in res.summary_markdown
-    assert "## Group delay" in res.summary_markdown and "## Diffusion / echo density proxy" in res.summary_markdown
-    for suffix in ("_decay", "_rt60bands", "_fr", "_spectrogram_mono", "_groupdelay_mono", "_diffusion"):
-        assert (tmp_path / "o" / f"r{suffix}.png").stat().st_size > 1000
+    lit = _json.loads((Path(__file__).resolve().parent / "golden" / "report_literal.json").read_text())
+    g = np.load(Path(__file__).resolve().parent / "golden" / "goldens.npz")
+    pcm = g[f"report/{name}/pcm"]
+    wav = tmp_path / f"{name}.wav"
+    wavfile.write(str(wav), SR, pcm[:, 0] if (pcm.ndim == 2 and pcm.shape[1] == 1) else pcm)
+    res = rp.run_report_from_wav_file(wav, tmp_path / "out" / "rep", rp.ReportSettings(**kw))
+    assert res.summary_markdown == lit[f"{name}/{tag}"].replace("{WAV}", str(wav))
+    pngs = sorted(p.name for p in (tmp_path / "out").glob("*.png"))
+    assert pngs == lit[f"{name}/{tag}/pngs"]
+    assert all((tmp_path / "out" / p).stat().st_size > 1000 for p in pngs)
+    assert "Skipped blocks" not in res.summary_markdown
+
+
+def test_ir_command_writes_the_three_views(tmp_path, golden, capsys):
+    from audio_analysis_amd.analyse import cli
+    wav = _write(tmp_path, golden, "stereo16")
+    cli.main(["ir", "--input", str(wav), "--output", str(tmp_path / "v" / "take.1"), "--no_show"])
+    assert capsys.readouterr().out == ""                                  # the reference prints nothing for `ir`
+    # the reference derives the names with Path.with_suffix: a basename with a dot loses what follows it
+    assert sorted(p.name for p in (tmp_path / "v").glob("*.png")) == ["take.png", "take_early.png", "take_tail.png"]
 
 
 def test_zplane_and_filter_commands_match_reference(tmp_path, golden, capsys):
