@@ -32,6 +32,7 @@ struct SmoothPlan {
   const cd* t1;                     // exp(-2 pi i k / N1), k < N1
   const cd* t2;                     // exp(-2 pi i k / N2), k < N2
   const cd* tf;                     // exp(-2 pi i k / n),  k < N2
+  int inplace;                      // 1: single LDS buffer, in-place passes (default); 0: ping-pong Stockham (A/B)
   int stamp;                        // diagnostics (IRA_SMOOTH_STAMP): per-phase cycle counts of one workgroup per kernel
 };
 
@@ -194,6 +195,79 @@ __device__ cd* lds_fft_stockham(cd* a, cd* b, int N, const int* radices, int nra
   return x;
 }
 
+// ---- the same transform IN PLACE (one LDS buffer) ---------------------------------------------------------------------
+// Decimation in frequency with every butterfly writing back to the R slots it read: no second buffer, no staging, one
+// barrier per pass.  The price is the output order: X[k], k = k_0 + r_0 k_1 + r_0 r_1 k_2 ..., ends up at the
+// digit-reversed slot k_0 (N / r_0) + k_1 (N / (r_0 r_1)) + ...; the consumers ask dif_slot() where a k lives.
+// Half the LDS per tile means twice the columns per workgroup at the same number of resident workgroups: the passes are a
+// closed queue of tiles cycling between a memory phase and an LDS phase, and what is in flight per CU is what LDS holds.
+template <int R>
+__device__ __forceinline__ void dif_pass(cd* x, int N, int len, const cd* __restrict__ tw, int tid, int nbat) {
+  const int per = N / R;                        // butterflies per transform
+  const int m = len / R;
+  const int scale = N / len;                    // W_len^(p k) = W_N^(scale p k)
+  const unsigned magic = (unsigned)(0x100000000ull / (unsigned)m) + 1u;      // bf / m for bf < 2^16
+  for (int t = 0; t < nbat; ++t) {
+    cd* xt = x + t * N;
+    for (int bf = tid; bf < per; bf += SM_THREADS) {
+      const int blk = m == 1 ? bf : (int)__umulhi((unsigned)bf, magic);
+      const int p = bf - blk * m;
+      cd* base = xt + blk * len + p;
+      cd v[R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) v[j] = base[m * j];
+      bfly<R>(v);
+      base[0] = v[0];
+      if (p == 0) {
+#pragma unroll
+        for (int k = 1; k < R; ++k) base[m * k] = v[k];
+      } else {
+        const int tt = scale * p;                                          // < N / R
+        const cd w1 = ira::cmul(tw[tt >> 5], tw[33 + (tt & 31)]);
+        cd w = w1;
+#pragma unroll
+        for (int k = 1; k < R; ++k) {
+          base[m * k] = ira::cmul(v[k], w);
+          if (k + 1 < R) w = ira::cmul(w, w1);
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__device__ void lds_fft_dif_inplace(cd* a, int N, const int* radices, int nrad, const cd* __restrict__ tw, int tid,
+                                    int nbat) {
+  int len = N;
+  for (int pass = 0; pass < nrad; ++pass) {
+    const int r = radices[pass];
+    switch (r) {
+      case 16: dif_pass<16>(a, N, len, tw, tid, nbat); break;
+      case 8: dif_pass<8>(a, N, len, tw, tid, nbat); break;
+      case 6: dif_pass<6>(a, N, len, tw, tid, nbat); break;
+      case 5: dif_pass<5>(a, N, len, tw, tid, nbat); break;
+      case 4: dif_pass<4>(a, N, len, tw, tid, nbat); break;
+      case 3: dif_pass<3>(a, N, len, tw, tid, nbat); break;
+      default: dif_pass<2>(a, N, len, tw, tid, nbat); break;
+    }
+    len /= r;
+  }
+}
+
+// slot of X[k] after lds_fft_dif_inplace
+__device__ __forceinline__ int dif_slot(int k, int N, const int* radices, int nrad) {
+  int slot = 0, span = N;
+#pragma unroll 1
+  for (int i = 0; i < nrad; ++i) {
+    const int r = radices[i];
+    const int q = k / r;
+    span /= r;
+    slot += (k - q * r) * span;
+    k = q;
+  }
+  return slot;
+}
+
 // W_n^p for p < n = N1*N2 as a coarse (N1 entries) times a fine (N2 entries) table value.
 __device__ __forceinline__ cd twiddle_n(const SmoothPlan& P, unsigned p) {      // p < n <= 2^20
   const unsigned hi = p / (unsigned)P.n2, lo = p - hi * (unsigned)P.n2;
@@ -310,8 +384,8 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_cols_kernel(SmoothPlan P, S
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cd* a = reinterpret_cast<cd*>(smem);
   const int C = P.c1, N1 = P.n1, N2 = P.n2;
-  cd* b = a + (size_t)C * N1;
-  cd* twl = b + (size_t)C * N1;                            // SM_TW entries
+  cd* b = a + (size_t)C * N1;                              // second buffer (ping-pong plan only)
+  cd* twl = P.inplace ? b : b + (size_t)C * N1;            // SM_TW entries
   unsigned bx, by;
   smooth_remap(bx, by);
   const int e = (int)by, tid = threadIdx.x;
@@ -339,7 +413,9 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_cols_kernel(SmoothPlan P, S
   }
   __syncthreads();
   SM_STAMP(s1);
-  const cd* r = lds_fft_stockham(a, b, N1, P.r1, P.nr1, twl, tid, C);
+  const cd* r = a;
+  if (P.inplace) lds_fft_dif_inplace(a, N1, P.r1, P.nr1, twl, tid, C);
+  else r = lds_fft_stockham(a, b, N1, P.r1, P.nr1, twl, tid, C);
   SM_STAMP(s2);
   cd* w = work + (long long)e * P.n;
   for (int i = tid; i < N1 * C; i += SM_THREADS) {
@@ -347,7 +423,7 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_cols_kernel(SmoothPlan P, S
     const int n2 = n2_0 + c;
     const int C2 = P.c2;
     w[(long long)(k1 / C2) * ((long long)N2 * C2) + (long long)n2 * C2 + k1 % C2] =
-        ira::cmul(r[c * N1 + k1], twiddle_n(P, (unsigned)k1 * (unsigned)n2));
+        ira::cmul(r[c * N1 + (P.inplace ? dif_slot(k1, N1, P.r1, P.nr1) : k1)], twiddle_n(P, (unsigned)k1 * (unsigned)n2));
   }
   if (P.stamp) {
     SM_STAMP(s3);
@@ -362,8 +438,8 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_rows_kernel(SmoothPlan P, S
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cd* a = reinterpret_cast<cd*>(smem);
   const int C = P.c2, N1 = P.n1, N2 = P.n2;
-  cd* b = a + (size_t)C * N2;
-  cd* twl = b + (size_t)C * N2;
+  cd* b = a + (size_t)C * N2;                              // second buffer (ping-pong plan only)
+  cd* twl = P.inplace ? b : b + (size_t)C * N2;
   unsigned bx, by;
   smooth_remap(bx, by);
   const int e = (int)by, tid = threadIdx.x;
@@ -389,14 +465,16 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_rows_kernel(SmoothPlan P, S
   }
   __syncthreads();
   SM_STAMP(s1);
-  const cd* r = lds_fft_stockham(a, b, N2, P.r2, P.nr2, twl, tid, C);
+  const cd* r = a;
+  if (P.inplace) lds_fft_dif_inplace(a, N2, P.r2, P.nr2, twl, tid, C);
+  else r = lds_fft_stockham(a, b, N2, P.r2, P.nr2, twl, tid, C);
   SM_STAMP(s2);
   const long long n = P.n;
   const bool paired = (OUT == SM_OUT_SPEC) && J.x2off != nullptr && J.x2off[e] >= 0;
   for (int i = tid; i < N2 * C; i += SM_THREADS) {
     const int c = i % C, k2 = i / C;
     const long long k = (long long)(k1_0 + c) + (long long)N1 * k2;        // natural output index
-    cd v = r[c * N2 + k2];
+    cd v = r[c * N2 + (P.inplace ? dif_slot(k2, N2, P.r2, P.nr2) : k2)];
     if (OUT == SM_OUT_SPEC) {
       if (paired) {
         J.zpair[J.zpair_off[e] + k] = v;
@@ -452,12 +530,19 @@ int factor_radices(int n, int* out) {
   return cnt;
 }
 
-// columns per workgroup for a sub-transform of `len` points (other dimension `other`): as many as keep both LDS buffers
-// within 64 KB, dividing the other dimension
-int pick_columns(int len, int other) {
-  int c = 8;
-  while (c > 1 && (((size_t)2 * c * len + SM_TW) * sizeof(cd) > 64 * 1024 || other % c != 0)) c >>= 1;
-  return c;
+// columns per workgroup for a sub-transform of `len` points (other dimension `other`), dividing the other dimension.
+// Ping-pong plan: as many as keep both LDS buffers within 64 KB.  In-place plan: as many as keep the one buffer within
+// ~48 KB (three workgroups per CU).
+int pick_columns(int len, int other, bool inplace) {
+  if (!inplace) {
+    int c = 8;
+    while (c > 1 && (((size_t)2 * c * len + SM_TW) * sizeof(cd) > 64 * 1024 || other % c != 0)) c >>= 1;
+    return c;
+  }
+  int best = 1;
+  for (int c = 1; c <= 8; ++c)
+    if (other % c == 0 && ((size_t)c * len + SM_TW) * sizeof(cd) <= 50 * 1024) best = c;
+  return best;
 }
 
 bool smooth_split(long long n, int* n1_out, int* n2_out) {
@@ -491,8 +576,9 @@ int32_t make_smooth_plan(int32_t n, const void* t1, const void* t2, const void* 
   P->nr1 = factor_radices(n1, P->r1);
   P->nr2 = factor_radices(n2, P->r2);
   if (P->nr1 < 0 || P->nr2 < 0) return IRA_E_UNSUPPORTED;
-  P->c1 = pick_columns(n1, n2);
-  P->c2 = pick_columns(n2, n1);
+  P->inplace = std::getenv("IRA_SMOOTH_PINGPONG") == nullptr;
+  P->c1 = pick_columns(n1, n2, P->inplace != 0);
+  P->c2 = pick_columns(n2, n1, P->inplace != 0);
   if (const char* ev = std::getenv("IRA_SMOOTH_C1")) { const int v = std::atoi(ev); if (v >= 1 && n2 % v == 0) P->c1 = v; }
   if (const char* ev = std::getenv("IRA_SMOOTH_C2")) { const int v = std::atoi(ev); if (v >= 1 && n1 % v == 0) P->c2 = v; }
   P->t1 = static_cast<const cd*>(t1); P->t2 = static_cast<const cd*>(t2); P->tf = static_cast<const cd*>(tf);
@@ -546,7 +632,8 @@ extern "C" int32_t ira_rfft_smooth(const float* x_dev, const int64_t* xoff_dev, 
     J.zpair = reinterpret_cast<cd*>(zpair_dev); J.zpair_off = zpair_off_dev;
   }
   hipStream_t st = (hipStream_t)stream;
-  const size_t l1 = ((size_t)2 * P.c1 * P.n1 + SM_TW) * sizeof(cd), l2 = ((size_t)2 * P.c2 * P.n2 + SM_TW) * sizeof(cd);
+  const size_t nbuf = P.inplace ? 1 : 2;
+  const size_t l1 = (nbuf * P.c1 * P.n1 + SM_TW) * sizeof(cd), l2 = (nbuf * P.c2 * P.n2 + SM_TW) * sizeof(cd);
   SM_TRY(allow(smooth_cols_kernel<SM_SIGNAL>, l1));
   SM_TRY(allow(smooth_rows_kernel<SM_OUT_SPEC>, l2));
   cd* work = reinterpret_cast<cd*>(work_dev);
@@ -576,7 +663,8 @@ extern "C" int32_t ira_band_irfft_smooth(const double* spec_dev, const int64_t* 
   J.bands = reinterpret_cast<const BandMaskS*>(band_params_dev); J.freq_val = freq_val_dev;
   J.y = y_dev; J.y1_off = y1_off_dev; J.y2_off = y2_off_dev;
   hipStream_t st = (hipStream_t)stream;
-  const size_t l1 = ((size_t)2 * P.c1 * P.n1 + SM_TW) * sizeof(cd), l2 = ((size_t)2 * P.c2 * P.n2 + SM_TW) * sizeof(cd);
+  const size_t nbuf = P.inplace ? 1 : 2;
+  const size_t l1 = (nbuf * P.c1 * P.n1 + SM_TW) * sizeof(cd), l2 = (nbuf * P.c2 * P.n2 + SM_TW) * sizeof(cd);
   SM_TRY(allow(smooth_cols_kernel<SM_SPECTRUM>, l1));
   SM_TRY(allow(smooth_rows_kernel<SM_OUT_BANDS>, l2));
   cd* work = reinterpret_cast<cd*>(work_dev);
