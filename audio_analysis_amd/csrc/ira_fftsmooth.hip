@@ -532,7 +532,9 @@ int factor_radices(int n, int* out) {
 
 // columns per workgroup for a sub-transform of `len` points (other dimension `other`), dividing the other dimension.
 // Ping-pong plan: as many as keep both LDS buffers within 64 KB.  In-place plan: as many as keep the one buffer within
-// ~48 KB (three workgroups per CU).
+// 26 KB -- the registers allow four workgroups per CU and LDS must not be what stops the fourth; measured for
+// 480000 = 640 x 750 (band inverses / forward, ms): columns 2/2 1.48 / 0.61, 3/4 1.50 / 0.63, 5/4 1.61 / 0.67,
+// 6/5 2.03 / 0.82 (ping-pong 2/2: 1.62 / 0.64).
 int pick_columns(int len, int other, bool inplace) {
   if (!inplace) {
     int c = 8;
@@ -541,7 +543,7 @@ int pick_columns(int len, int other, bool inplace) {
   }
   int best = 1;
   for (int c = 1; c <= 8; ++c)
-    if (other % c == 0 && ((size_t)c * len + SM_TW) * sizeof(cd) <= 50 * 1024) best = c;
+    if (other % c == 0 && ((size_t)c * len + SM_TW) * sizeof(cd) <= 26 * 1024) best = c;
   return best;
 }
 
