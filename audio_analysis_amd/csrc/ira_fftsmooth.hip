@@ -97,6 +97,22 @@ __device__ __forceinline__ void bfly<6>(cd (&a)[6]) {
     a[k1 + 3] = ira::csub(e[k1], o[k1]);
   }
 }
+// 10 = 2 x 5: n = 2a + b, k = k1 + 5 k2
+template <>
+__device__ __forceinline__ void bfly<10>(cd (&a)[10]) {
+  cd e[5] = {a[0], a[2], a[4], a[6], a[8]}, o[5] = {a[1], a[3], a[5], a[7], a[9]};
+  bfly<5>(e);
+  bfly<5>(o);
+  o[1] = ira::cmul(o[1], cd{0.80901699437494742410, -0.58778525229247312917});      // W10^1
+  o[2] = ira::cmul(o[2], cd{0.30901699437494742410, -0.95105651629515357212});      // W10^2
+  o[3] = ira::cmul(o[3], cd{-0.30901699437494742410, -0.95105651629515357212});     // W10^3
+  o[4] = ira::cmul(o[4], cd{-0.80901699437494742410, -0.58778525229247312917});     // W10^4
+#pragma unroll
+  for (int k1 = 0; k1 < 5; ++k1) {
+    a[k1] = ira::cadd(e[k1], o[k1]);
+    a[k1 + 5] = ira::csub(e[k1], o[k1]);
+  }
+}
 // powers of two through the shared decimation-in-frequency kernel (it leaves X[k] in slot bitrev(k))
 template <>
 __device__ __forceinline__ void bfly<8>(cd (&a)[8]) {
@@ -180,7 +196,7 @@ __device__ cd* lds_fft_stockham(cd* a, cd* b, int N, const int* radices, int nra
     const int m = len / r;
     const unsigned magic = (unsigned)(0x100000000ull / (unsigned)s) + 1u;
     switch (r) {
-      case 16: stockham_pass<16>(x, y, N, m, s, magic, tw, tid, nbat); break;
+      case 10: stockham_pass<10>(x, y, N, m, s, magic, tw, tid, nbat); break;
       case 8: stockham_pass<8>(x, y, N, m, s, magic, tw, tid, nbat); break;
       case 6: stockham_pass<6>(x, y, N, m, s, magic, tw, tid, nbat); break;
       case 5: stockham_pass<5>(x, y, N, m, s, magic, tw, tid, nbat); break;
@@ -242,7 +258,7 @@ __device__ void lds_fft_dif_inplace(cd* a, int N, const int* radices, int nrad, 
   for (int pass = 0; pass < nrad; ++pass) {
     const int r = radices[pass];
     switch (r) {
-      case 16: dif_pass<16>(a, N, len, tw, tid, nbat); break;
+      case 10: dif_pass<10>(a, N, len, tw, tid, nbat); break;
       case 8: dif_pass<8>(a, N, len, tw, tid, nbat); break;
       case 6: dif_pass<6>(a, N, len, tw, tid, nbat); break;
       case 5: dif_pass<5>(a, N, len, tw, tid, nbat); break;
@@ -396,18 +412,17 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_cols_kernel(SmoothPlan P, S
   const int total1 = N1 * C;
   for (int base = 0; base < total1; base += SM_THREADS * SM_UC) {
     RawIn raw[SM_UC];
-    long long idx[SM_UC];
-#pragma unroll
-    for (int u = 0; u < SM_UC; ++u) {
+    auto index_of = [&](int u) -> long long {               // recomputed, not kept: registers are what limits occupancy
       int i = base + tid + SM_THREADS * u;
       i = i < total1 ? i : total1 - 1;                      // clamp: every fetch is unconditional (stays in registers)
-      idx[u] = (long long)(i / C) * N2 + n2_0 + i % C;
-      raw[u] = smooth_fetch<MODE>(P, J, e, idx[u]);
-    }
+      return (long long)(i / C) * N2 + n2_0 + i % C;
+    };
+#pragma unroll
+    for (int u = 0; u < SM_UC; ++u) raw[u] = smooth_fetch<MODE>(P, J, e, index_of(u));
 #pragma unroll
     for (int u = 0; u < SM_UC; ++u) {
       const int i = base + tid + SM_THREADS * u;
-      const cd v = smooth_value<MODE>(P, J, e, idx[u], raw[u]);
+      const cd v = smooth_value<MODE>(P, J, e, index_of(u), raw[u]);
       if (i < total1) a[(i % C) * N1 + i / C] = v;
     }
   }
@@ -511,19 +526,23 @@ __global__ __launch_bounds__(256) void smooth_pair_split_kernel(SmoothPlan P, SJ
 
 // ---- planning ------------------------------------------------------------------------------------------------------------
 int factor_radices(int n, int* out) {
-  // Few, wide passes: 16s, then one of 8 / 4 / 2 for the remaining twos (a lone 2 joins a 3 as a radix-6 pass), 5s, 3s.
+  // Few passes of moderate width: 8s, then one of 4 / 10 / 6 / 2 for the remaining twos, 5s, 3s.
   // Returns the count or -1 if n has another prime factor.
   int cnt = 0, twos = 0, threes = 0, fives = 0;
   while (n % 2 == 0) { n /= 2; ++twos; }
   while (n % 3 == 0) { n /= 3; ++threes; }
   while (n % 5 == 0) { n /= 5; ++fives; }
   if (n != 1) return -1;
-  for (; twos >= 4; twos -= 4) out[cnt++] = 16;
-  if (twos == 3) { out[cnt++] = 8; twos = 0; }
+  // No radix-16 passes: a 16-point butterfly holds 64 data registers and pins the kernels at ~120 VGPRs (4 waves per
+  // SIMD); with 8 / 10 / 6 as the widest radices they need ~80 and five to six workgroups fit a CU.  A lone 2 joins a 5
+  // (radix 10) or a 3 (radix 6).
+  for (; twos >= 3; twos -= 3) out[cnt++] = 8;
   if (twos == 2) { out[cnt++] = 4; twos = 0; }
   if (twos == 1) {
-    if (threes > 0) { out[cnt++] = 6; --threes; }
+    if (fives > 0) { out[cnt++] = 10; --fives; }
+    else if (threes > 0) { out[cnt++] = 6; --threes; }
     else out[cnt++] = 2;
+    twos = 0;
   }
   for (; fives > 0; --fives) { if (cnt >= SM_MAX_RADICES) return -1; out[cnt++] = 5; }
   for (; threes > 0; --threes) { if (cnt >= SM_MAX_RADICES) return -1; out[cnt++] = 3; }
