@@ -3,8 +3,9 @@
 //  lds_fft_dif : decimation-in-frequency, natural-order input -> BIT-REVERSED output (forward, e^{-i...}).
 //  lds_fft_dit : decimation-in-time, BIT-REVERSED input -> natural-order output; with conj_tw it is the
 //                (unnormalised) inverse of lds_fft_dif, so a forward/inverse pair needs no reorder pass.
-// Radix-16 passes (16-point DFT in registers, ONE twiddle lookup per butterfly, powers by a shallow tree) while at
-// least 4 bits remain, then radix-4 and radix-2 for the remainder; in place; `nbat` independent transforms laid out
+// Radix-2^LR passes, LR = 4 (default) or 3 (16- or 8-point DFT in registers, ONE twiddle lookup per butterfly, powers by
+// a shallow tree) while at least LR bits remain, then radix-4 and radix-2 for the remainder; in place;
+// (LR = 3 costs a pass more at 1024 points but needs ~40 registers less: the long-FFT kernels trade it for occupancy) `nbat` independent transforms laid out
 // `bstride` elements apart are processed together (all `nt` threads must call; the functions contain barriers).
 //
 // Twiddles come from a caller-provided table tw[k] = exp(-2*pi*i*k/TWN), k < TWN/2, TWN = M * tw_per_m;
@@ -28,34 +29,35 @@ __device__ __forceinline__ cplx<T> tw_lookup(const cplx<T>* __restrict__ tw, uns
   return tw[idx];
 }
 
-template <typename T>
+template <typename T, int LR = 4>
 __device__ __forceinline__ void lds_fft_dif(cplx<T>* buf, int log2m, const cplx<T>* __restrict__ tw,
                                             unsigned tw_per_m, int tid, int nt, int nbat = 1,
                                             unsigned bstride = 0) {
+  constexpr int R = 1 << LR;
   const unsigned M = 1u << log2m;
   const unsigned half = (M * tw_per_m) >> 1;
   int s = log2m;  // log2 of the current block length S
-  while (s >= 4) {
-    // radix-16: elements base + r*q (r < 16), q = S/16.  dft_dif leaves X[k] in v[brev4(k)], and storing v[i] at
-    // base + i*q is exactly the position the equivalent four radix-2 stages would have used (bit-reversed order).
-    const unsigned q = 1u << (s - 4);
+  while (s >= LR) {
+    // radix-R: elements base + r*q (r < R), q = S/R.  dft_dif leaves X[k] in v[brev(k)], and storing v[i] at
+    // base + i*q is exactly the position the equivalent LR radix-2 stages would have used (bit-reversed order).
+    const unsigned q = 1u << (s - LR);
     const unsigned step = tw_per_m << (log2m - s);
-    const unsigned per = M >> 4;
+    const unsigned per = M >> LR;
     for (unsigned g = tid; g < per * (unsigned)nbat; g += nt) {
-      const unsigned which = g >> (log2m - 4), b = g & (per - 1);
+      const unsigned which = g >> (log2m - LR), b = g & (per - 1);
       cplx<T>* p = buf + which * bstride;
       const unsigned j = b & (q - 1);
-      const unsigned base = ((b >> (s - 4)) << s) + j;
-      cplx<T> v[16];
+      const unsigned base = ((b >> (s - LR)) << s) + j;
+      cplx<T> v[R];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = p[base + r * q];
-      dft_dif<T, 16>(v);
-      if (j != 0) twiddle16<T, true>(v, tw[j * step]);     // W_S^(j k), k < 16  (j*step < half/8)
+      for (int r = 0; r < R; ++r) v[r] = p[base + r * q];
+      dft_dif<T, R>(v);
+      if (j != 0) twiddle_r<T, LR, true>(v, tw[j * step]);     // W_S^(j k), k < R  (j*step < half/(R/2))
 #pragma unroll
-      for (int i = 0; i < 16; ++i) p[base + i * q] = v[i];
+      for (int i = 0; i < R; ++i) p[base + i * q] = v[i];
     }
     __syncthreads();
-    s -= 4;
+    s -= LR;
   }
   while (s >= 2) {
     const unsigned q = 1u << (s - 2);               // quarter block
@@ -101,14 +103,16 @@ __device__ __forceinline__ void lds_fft_dif(cplx<T>* buf, int log2m, const cplx<
 
 // Bit-reversed input -> natural output.  conj_tw = true uses exp(+i...) twiddles (inverse transform,
 // unnormalised); false gives the forward transform of a bit-reversed-order input.
-template <typename T>
+template <typename T, int LR = 4>
 __device__ __forceinline__ void lds_fft_dit(cplx<T>* buf, int log2m, const cplx<T>* __restrict__ tw,
                                             unsigned tw_per_m, bool conj_tw, int tid, int nt, int nbat = 1,
                                             unsigned bstride = 0) {
+  constexpr int R = 1 << LR;
   const unsigned M = 1u << log2m;
   const unsigned half = (M * tw_per_m) >> 1;
+  const int rem = log2m % LR;   // low bits the radix-2 / radix-4 passes cover (mirror of the DIF tail); radix-R does the rest
   int s = 0;  // log2 of the block length already combined
-  if (log2m & 1) {  // first radix-2 pass, block length 2
+  if (rem & 1) {  // first radix-2 pass, block length 2
     const unsigned per = M >> 1;
     for (unsigned g = tid; g < per * (unsigned)nbat; g += nt) {
       const unsigned which = g >> (log2m - 1), b = g & (per - 1);
@@ -120,8 +124,7 @@ __device__ __forceinline__ void lds_fft_dit(cplx<T>* buf, int log2m, const cplx<
     __syncthreads();
     s = 1;
   }
-  const int s16_start = log2m & 3;   // the radix-2 / radix-4 passes cover these low bits; radix-16 does the rest
-  while (s < s16_start) {
+  while (s < rem) {
     // combine blocks of length q = 2^s into blocks of length S = 4q
     const unsigned q = 1u << s;
     const int sS = s + 2;
@@ -155,36 +158,36 @@ __device__ __forceinline__ void lds_fft_dit(cplx<T>* buf, int log2m, const cplx<
     s = sS;
   }
   while (s < log2m) {
-    // radix-16: the exact inverse of the DIF pass above.  Position base + i*q holds frequency index k = brev4(i) of
-    // the 16-point stage; untwiddle, then the 16-point (inverse) DFT puts sample n at base + n*q.
+    // radix-R: the exact inverse of the DIF pass above.  Position base + i*q holds frequency index k = brev(i) of
+    // the R-point stage; untwiddle, then the R-point (inverse) DFT puts sample n at base + n*q.
     const unsigned q = 1u << s;
-    const int sS = s + 4;
+    const int sS = s + LR;
     const unsigned step = tw_per_m << (log2m - sS);
-    const unsigned per = M >> 4;
+    const unsigned per = M >> LR;
     for (unsigned g = tid; g < per * (unsigned)nbat; g += nt) {
-      const unsigned which = g >> (log2m - 4), b = g & (per - 1);
+      const unsigned which = g >> (log2m - LR), b = g & (per - 1);
       cplx<T>* p = buf + which * bstride;
       const unsigned j = b & (q - 1);
       const unsigned base = ((b >> s) << sS) + j;
-      cplx<T> u[16];
+      cplx<T> u[R];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) u[k] = p[base + brev_bits(k, 4) * q];
+      for (int k = 0; k < R; ++k) u[k] = p[base + brev_bits(k, LR) * q];
       if (j != 0) {
         cplx<T> w = tw[j * step];
         if (conj_tw) w.im = -w.im;
-        twiddle16<T, false>(u, w);
+        twiddle_r<T, LR, false>(u, w);
       }
       if (conj_tw) {
-        // inverse 16-point DFT = conj(DFT(conj(.)))
+        // inverse R-point DFT = conj(DFT(conj(.)))
 #pragma unroll
-        for (int k = 0; k < 16; ++k) u[k].im = -u[k].im;
-        dft_dif<T, 16>(u);
+        for (int k = 0; k < R; ++k) u[k].im = -u[k].im;
+        dft_dif<T, R>(u);
 #pragma unroll
-        for (int n = 0; n < 16; ++n) { cplx<T> r = u[brev_bits(n, 4)]; r.im = -r.im; p[base + n * q] = r; }
+        for (int n = 0; n < R; ++n) { cplx<T> r = u[brev_bits(n, LR)]; r.im = -r.im; p[base + n * q] = r; }
       } else {
-        dft_dif<T, 16>(u);
+        dft_dif<T, R>(u);
 #pragma unroll
-        for (int n = 0; n < 16; ++n) p[base + n * q] = u[brev_bits(n, 4)];
+        for (int n = 0; n < R; ++n) p[base + n * q] = u[brev_bits(n, LR)];
       }
     }
     __syncthreads();

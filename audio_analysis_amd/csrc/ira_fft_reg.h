@@ -105,4 +105,25 @@ __device__ __forceinline__ void twiddle16(cplx<T> (&v)[16], cplx<T> w) {
   }
 }
 
+// The same for 8-point butterflies: v[idx(k)] *= w^k, k = 1..7, idx = 3-bit reversal or identity.
+template <typename T, bool BREV>
+__device__ __forceinline__ void twiddle8(cplx<T> (&v)[8], cplx<T> w) {
+  const cplx<T> w2 = ira::cmul(w, w);
+  const cplx<T> w3 = ira::cmul(w2, w);
+  const cplx<T> w4 = ira::cmul(w2, w2);
+  const cplx<T> p[8] = {{(T)1, (T)0}, w, w2, w3, w4, ira::cmul(w4, w), ira::cmul(w4, w2), ira::cmul(w4, w3)};
+#pragma unroll
+  for (int k = 1; k < 8; ++k) {
+    const int i = BREV ? brev_bits(k, 3) : k;
+    v[i] = ira::cmul(v[i], p[k]);
+  }
+}
+
+// radix selected by its log2 (3 or 4)
+template <typename T, int LR, bool BREV>
+__device__ __forceinline__ void twiddle_r(cplx<T> (&v)[1 << LR], cplx<T> w) {
+  if constexpr (LR == 4) twiddle16<T, BREV>(v, w);
+  else twiddle8<T, BREV>(v, w);
+}
+
 }  // namespace ira

@@ -29,6 +29,10 @@ using ira::cplx;
 typedef cplx<double> cd;
 
 constexpr int FL_THREADS = 256;
+// In-LDS sub-FFTs in radix-16 passes (3 passes for 1024 points).  Radix 8 (FL_LR = 3: 4 passes, ~80 VGPRs instead of 125)
+// was measured too: 1.66 ms against 1.61 ms for the fr/filter spectra -- at C = R = 2 these kernels are bound by LDS capacity
+// (4 workgroups per CU) and by memory (K2 moves 3.2 TB/s), not by registers; smaller tiles (C = R = 1) were slower still.
+constexpr int FL_LR = 4;
 
 struct Geom {
   int log2m, log2n1, log2n2;
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     }
   }
   __syncthreads();
-  if (!(g.ablate & 2)) ira::lds_fft_dif<double>(lds, g.log2n1, g.t1, 1u, tid, FL_THREADS, C, stride);
+  if (!(g.ablate & 2)) ira::lds_fft_dif<double, FL_LR>(lds, g.log2n1, g.t1, 1u, tid, FL_THREADS, C, stride);
   cd* w = work + (long long)e * M;
   const unsigned total_o = N1 * (unsigned)C;
   for (unsigned base = 0; base < total_o; base += FL_THREADS * FL_UI) {
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     }
   }
   __syncthreads();
-  if (!(g.ablate & 8)) ira::lds_fft_dif<double>(lds, g.log2n2, g.t2, 1u, tid, FL_THREADS, R, N2);
+  if (!(g.ablate & 8)) ira::lds_fft_dif<double, FL_LR>(lds, g.log2n2, g.t2, 1u, tid, FL_THREADS, R, N2);
   if (MODE == ROW_CONV) {
     const cd* b = J.bfilt + (long long)J.bidx[e] * M + (long long)r0 * N2;
     if (!(g.ablate & 16))
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         }
       }
     __syncthreads();
-    if (!(g.ablate & 8)) ira::lds_fft_dit<double>(lds, g.log2n2, g.t2, 1u, true, tid, FL_THREADS, R, N2);
+    if (!(g.ablate & 8)) ira::lds_fft_dit<double, FL_LR>(lds, g.log2n2, g.t2, 1u, true, tid, FL_THREADS, R, N2);
     for (unsigned base = 0; base < total; base += FL_THREADS * FL_UI) {
       cd th[FL_UI], tl[FL_UI];
 #pragma unroll
@@ -410,7 +414,7 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     }
   }
   __syncthreads();
-  if (!(g.ablate & 32)) ira::lds_fft_dit<double>(lds, g.log2n1, g.t1, 1u, true, tid, FL_THREADS, C, stride);
+  if (!(g.ablate & 32)) ira::lds_fft_dit<double, FL_LR>(lds, g.log2n1, g.t1, 1u, true, tid, FL_THREADS, C, stride);
   const double inv_m = 1.0 / (double)M;
   for (unsigned i = tid; i < N1 * (unsigned)C; i += FL_THREADS) {
     const unsigned c = i % C, n1 = i / C;
