@@ -396,7 +396,7 @@ __device__ __forceinline__ void smooth_remap(unsigned& bx, unsigned& by) {
 
 // ---- pass 1: columns.  grid (N2 / C, jobs) ------------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(SM_THREADS) void smooth_cols_kernel(SmoothPlan P, SJobs J, cd* __restrict__ work) {
+__global__ __launch_bounds__(SM_THREADS, (MODE == SM_SIGNAL ? 6 : 5)) void smooth_cols_kernel(SmoothPlan P, SJobs J, cd* __restrict__ work) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cd* a = reinterpret_cast<cd*>(smem);
   const int C = P.c1, N1 = P.n1, N2 = P.n2;
