@@ -8,6 +8,7 @@ single-channel drop-in functions in audio_analysis_amd.analyse.* call them with 
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -118,7 +119,6 @@ class Engine:
         self._tables: Dict[Tuple, object] = {}
         self._filter_pools: Dict[int, dict] = {}
         self._ring = None
-        import os
         if os.environ.get("IRA_WORKSPACE_MB"):            # tuning knob: long-FFT jobs per launch (see workspace_budget_bytes)
             self.workspace_budget_bytes = int(float(os.environ["IRA_WORKSPACE_MB"]) * (1 << 20))
 
@@ -202,8 +202,7 @@ class Engine:
         return self._side
 
     _lanes = None
-    import os as _os
-    num_lanes = max(1, min(4, int(_os.environ.get("IRA_STREAMS", "3"))))
+    num_lanes = max(1, min(4, int(os.environ.get("IRA_STREAMS", "3"))))
 
     def block_streams(self):
         """
