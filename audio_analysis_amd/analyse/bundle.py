@@ -93,7 +93,7 @@ def run_bundle_metrics(bundle_root: str | Path, settings=None, use_mono_downmix_
     import numpy as np
 
     from ..engine import get_engine
-    from ..ingest import ingest_taps
+    from ..ingest import TapSet
     from ..pipeline import METRICS_WIDTH, FullReport, FullReportSettings
 
     root = Path(bundle_root)
@@ -104,16 +104,41 @@ def run_bundle_metrics(bundle_root: str | Path, settings=None, use_mono_downmix_
     eng = get_engine()
     fr = FullReport(eng, settings or FullReportSettings())
     rows, labels = [], []
-    pending = None
-    for a in range(lo, hi, max(1, int(taps_per_step))):
-        names = taps[a : min(hi, a + taps_per_step)]
-        batch, lab = ingest_taps(eng, [root / "taps" / f"{t}.wav" for t in names], use_mono_downmix_for_stereo,
-                                 int(meta.get("sample_rate_hz", 48_000) or 48_000))
-        labels += [(names[i], ch) for i, ch in lab]
-        nxt = fr.submit(batch)                       # step k+1 is enqueued before step k's records are read back
+    step = max(1, int(taps_per_step))
+    rate = int(meta.get("sample_rate_hz", 48_000) or 48_000)
+    groups = [taps[a : min(hi, a + step)] for a in range(lo, hi, step)]
+
+    def host_half(names):                            # headers + payload reads into pinned staging: no GPU call in here
+        return TapSet(eng, [root / "taps" / f"{t}.wav" for t in names], rate, upload=False)
+
+    # Three groups in flight.  While this thread works on groups k, k-1 and k-2, a worker thread reads group k+1 from
+    # disk (the readers inside libira release the GIL); every GPU call stays on this thread:
+    #   group k    upload + conversion enqueued, peak pick started behind them (not waited for)
+    #   group k-1  its peaks have arrived meanwhile: all report kernels are enqueued (submit)
+    #   group k-2  its records are read back (finish)
+    # so the GPU always holds one enqueued step while the host finishes another, and uploads overlap compute.
+    from concurrent.futures import ThreadPoolExecutor
+    uploaded = None                                  # group k-1: batch waiting for its peaks
+    pending = None                                   # group k-2: submitted step
+    with ThreadPoolExecutor(max_workers=1, thread_name_prefix="ira-prefetch") as ahead:
+        nxt_set = ahead.submit(host_half, groups[0]) if groups else None
+        for gi, names in enumerate(groups):
+            tapset = nxt_set.result()
+            nxt_set = ahead.submit(host_half, groups[gi + 1]) if gi + 1 < len(groups) else None
+            batch, lab = tapset.view(use_mono_downmix_for_stereo)
+            labels += [(names[i], ch) for i, ch in lab]
+            fr.prepare(batch)
+            if uploaded is not None:
+                handle = fr.submit(uploaded)
+                if pending is not None:
+                    rows.append(fr.finish(pending))
+                pending = handle
+            uploaded = batch
+    if uploaded is not None:
+        handle = fr.submit(uploaded)
         if pending is not None:
             rows.append(fr.finish(pending))
-        pending = nxt
+        pending = handle
     if pending is not None:
         rows.append(fr.finish(pending))
     local = np.concatenate(rows, axis=0) if rows else np.zeros((0, METRICS_WIDTH))

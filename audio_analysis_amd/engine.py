@@ -37,6 +37,7 @@ class ChannelBatch:
     peak: Optional[np.ndarray] = None       # int64 (B,) host, filled by Engine.peaks()
     peak_abs: Optional[np.ndarray] = None   # float32 (B,)
     ready: Optional[object] = None          # event recorded after the batch's arrays were enqueued for upload
+    _peak_pending: Optional[tuple] = None   # Engine.peaks_begin(): pinned results + event, picked up by Engine.peaks()
 
     @property
     def count(self) -> int:
@@ -265,8 +266,38 @@ class Engine:
         return self._tables[key]
 
     # ------------------------------------------------------------------ a2
+    def peaks_begin(self, b: ChannelBatch) -> None:
+        """Enqueue the peak pick of a batch on the high-priority side stream (behind the batch's upload only) and its
+        result's copy into pinned memory, WITHOUT waiting: the host can do other work while a freshly uploaded batch is
+        still on its way.  peaks() picks the result up."""
+        if b.peak is not None or getattr(b, "_peak_pending", None) is not None:
+            return
+        t = self.torch
+        side = self.side_stream()
+        if b.ready is not None:
+            side.wait_event(b.ready)
+        with t.cuda.stream(side):
+            pk = self.empty(b.count, t.int64)
+            pa = self.empty(b.count, t.float32)
+            check(self.lib.ira_peak_index(_ptr(b.x), _ptr(b.off_dev), _ptr(b.len_dev), b.count, _ptr(pk), _ptr(pa),
+                                          self.stream), "ira_peak_index")
+            hk = t.empty(pk.shape, dtype=pk.dtype, pin_memory=True)
+            ha = t.empty(pa.shape, dtype=pa.dtype, pin_memory=True)
+            hk.copy_(pk, non_blocking=True)
+            ha.copy_(pa, non_blocking=True)
+            ev = t.cuda.Event()
+            ev.record(side)
+        b._peak_pending = (hk, ha, ev, pk, pa)
+
     def peaks(self, b: ChannelBatch) -> np.ndarray:
         """argmax|x| per channel (first max wins), synchronises once and caches on the batch."""
+        pend = getattr(b, "_peak_pending", None)
+        if b.peak is None and pend is not None:
+            hk, ha, ev, _, _ = pend
+            ev.synchronize()
+            b.peak = hk.numpy()[: b.count].copy()
+            b.peak_abs = ha.numpy()[: b.count].copy()
+            b._peak_pending = None
         if b.peak is None:
             t = self.torch
             pk = self.empty(b.count, t.int64)

@@ -111,7 +111,11 @@ class TapSet:
     report.py:172-186) reads and uploads every file once.
     """
 
-    def __init__(self, eng: Engine, paths: Sequence[str | Path], expected_sample_rate_hz: int = 48_000):
+    def __init__(self, eng: Engine, paths: Sequence[str | Path], expected_sample_rate_hz: int = 48_000,
+                 upload: bool = True):
+        """upload=False stops after the HOST half (headers probed, payloads read into pinned staging): it touches no
+        stream, so it can run on a worker thread while the caller's thread drives the GPU; call upload() on the
+        caller's thread before the first view()."""
         t = eng.torch
         self.eng = eng
         pool = _io_pool()
@@ -141,10 +145,19 @@ class TapSet:
                 list(pool.map(read, self._native))
             else:
                 read(self._native[0])
-            self._pcm_dev = stage.to(eng.device, non_blocking=True)
+            self._stage = stage
+            if upload:
+                self.upload()
         # ---- other encodings: decoded by the Python reader when first needed -------------------------------------
         self._loaded = {}
         self._views = {}
+
+    def upload(self) -> None:
+        """Enqueue the one host-to-device copy of the staged payloads on the caller's current stream (idempotent)."""
+        stage = getattr(self, "_stage", None)
+        if stage is not None and self._pcm_dev is None:
+            self._pcm_dev = stage.to(self.eng.device, non_blocking=True)
+        self._stage = None
 
     def __len__(self) -> int:
         return len(self.infos)
@@ -153,6 +166,7 @@ class TapSet:
         mono = bool(use_mono_downmix_for_stereo)
         if mono in self._views:
             return self._views[mono]
+        self.upload()
         eng, t, infos = self.eng, self.eng.torch, self.infos
         labels: List[Tuple[int, str]] = []
         lens: List[int] = []

@@ -99,6 +99,11 @@ class FullReport:
         self.s = settings or FullReportSettings()
         self.device_results: Dict[str, dict] = {}
 
+    def prepare(self, batch: ChannelBatch) -> None:
+        """Optional: start the peak pick of a batch that has just been uploaded without waiting for it, so that the host
+        can finish the previous step meanwhile (bundle path: upload k+1 overlaps the read-back of step k)."""
+        self.eng.peaks_begin(batch)
+
     def run(self, batch: ChannelBatch) -> np.ndarray:
         """One step: submit + finish."""
         return self.finish(self.submit(batch))
@@ -116,11 +121,8 @@ class FullReport:
         m[:, M_STATUS] = 0.0
         m[:, M_NSAMPLES] = batch.length
         if batch.peak is None:
-            side = eng.side_stream()
-            if batch.ready is not None:
-                side.wait_event(batch.ready)               # the upload of this batch, nothing else
-            with t.cuda.stream(side):
-                eng.peaks(batch)                           # the one host round trip every block's geometry needs
+            eng.peaks_begin(batch)                         # side stream, behind the upload of this batch and nothing else
+            eng.peaks(batch)                               # the one host round trip every block's geometry needs
         res: Dict[str, dict] = {}
         fut: Dict[str, object] = {}
         state = {"spectrum": None, "filt": None}
