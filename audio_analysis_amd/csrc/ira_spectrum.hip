@@ -236,25 +236,38 @@ __global__ __launch_bounds__(OS_THREADS) void order_stats_kernel(const double* _
       lead[r] = r < nranks && leader[r] == r;
     }
     const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
-    // uniform trip count (ballots below need every lane of the wave in the loop)
-    const long long trips = (n + OS_THREADS - 1) / OS_THREADS;
+    // uniform trip count (ballots below need every lane of the wave in the loop); OS_U independent loads per thread are
+    // in flight before the first one is used (one workgroup walking 2e5 values with a load per iteration is bound by
+    // one memory latency per value)
+    constexpr int OS_U = 4;
+    const long long trips = (n + (long long)OS_THREADS * OS_U - 1) / ((long long)OS_THREADS * OS_U);
     for (long long it = 0; it < trips; ++it) {
-      const long long i = it * OS_THREADS + tid;
-      const bool valid = i < n;
-      const unsigned long long k = valid ? os_key(v[i]) : 0ull;
-      const unsigned int digit = (unsigned int)(k >> shift) & 255u;
+      unsigned long long kk[OS_U];
+      bool vv[OS_U];
 #pragma unroll
-      for (int r = 0; r < OS_MAX_RANKS; ++r) {
-        if (!lead[r]) continue;                                      // wave-uniform
-        const bool m = valid && (k & himask) == pf[r];
-        const unsigned long long act = __ballot(m);
-        if (act == 0ull) continue;
-        // the early digits are the same for almost every value (sign / exponent): one atomic for the whole group
-        const int first = __ffsll((long long)act) - 1;
-        const unsigned int d0 = (unsigned int)__shfl((int)digit, first, 64);
-        const unsigned long long same = __ballot(m && digit == d0);
-        if (lane == first) atomicAdd(&hist[r][d0], (unsigned int)__popcll(same));
-        if (m && digit != d0) atomicAdd(&hist[r][digit], 1u);
+      for (int u = 0; u < OS_U; ++u) {
+        const long long i = (it * OS_U + u) * OS_THREADS + tid;
+        vv[u] = i < n;
+        kk[u] = os_key(v[vv[u] ? i : n - 1]);
+      }
+#pragma unroll
+      for (int u = 0; u < OS_U; ++u) {
+        const bool valid = vv[u];
+        const unsigned long long k = kk[u];
+        const unsigned int digit = (unsigned int)(k >> shift) & 255u;
+#pragma unroll
+        for (int r = 0; r < OS_MAX_RANKS; ++r) {
+          if (!lead[r]) continue;                                      // wave-uniform
+          const bool m = valid && (k & himask) == pf[r];
+          const unsigned long long act = __ballot(m);
+          if (act == 0ull) continue;
+          // the early digits are the same for almost every value (sign / exponent): one atomic for the whole group
+          const int first = __ffsll((long long)act) - 1;
+          const unsigned int d0 = (unsigned int)__shfl((int)digit, first, 64);
+          const unsigned long long same = __ballot(m && digit == d0);
+          if (lane == first) atomicAdd(&hist[r][d0], (unsigned int)__popcll(same));
+          if (m && digit != d0) atomicAdd(&hist[r][digit], 1u);
+        }
       }
     }
     __syncthreads();
