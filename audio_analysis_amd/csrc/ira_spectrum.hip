@@ -312,20 +312,33 @@ __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const float* __restri
   // argmin |f - probe| first-min-wins: key = (bits(|d|) << 32 | idx) minimised
   unsigned long long near = ~0ull;
   long long first_in = n;
-  for (long long k = t; k < n; k += ST_THREADS) {
-    const float f = (float)((double)k * val);
-    const float d = fabsf(f - probe_hz);
-    const unsigned long long nk = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(uint32_t)k;
-    near = nk < near ? nk : near;
-    if (f >= f_min && f <= f_max) {
-      const float db = m[k];
-      uint32_t u = __float_as_uint(db);
-      u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone map float -> uint
-      const unsigned long long key = ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)k);
-      best = key > best ? key : best;
-      const double lin = exp10((double)db * 0.05);        // 10^(dB/20); pow() costs 4.5x the instructions
-      cnt += 1.0; sfl += (double)f * lin; sl += lin;
-      first_in = k < first_in ? k : first_in;
+  // ST_U loads per thread in flight before the first is used; the per-thread order of the additions is unchanged
+  constexpr int ST_U = 4;
+  for (long long k0 = t; k0 < n; k0 += (long long)ST_THREADS * ST_U) {
+    float dbv[ST_U];
+#pragma unroll
+    for (int u = 0; u < ST_U; ++u) {
+      const long long k = k0 + (long long)ST_THREADS * u;
+      dbv[u] = m[k < n ? k : n - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < ST_U; ++u) {
+      const long long k = k0 + (long long)ST_THREADS * u;
+      if (k >= n) continue;
+      const float f = (float)((double)k * val);
+      const float d = fabsf(f - probe_hz);
+      const unsigned long long nk = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(uint32_t)k;
+      near = nk < near ? nk : near;
+      if (f >= f_min && f <= f_max) {
+        const float db = dbv[u];
+        uint32_t uu = __float_as_uint(db);
+        uu = (uu & 0x80000000u) ? ~uu : (uu | 0x80000000u);  // monotone map float -> uint
+        const unsigned long long key = ((unsigned long long)uu << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)k);
+        best = key > best ? key : best;
+        const double lin = exp10((double)db * 0.05);        // 10^(dB/20); pow() costs 4.5x the instructions
+        cnt += 1.0; sfl += (double)f * lin; sl += lin;
+        first_in = k < first_in ? k : first_in;
+      }
     }
   }
   cnt = ira::wave_sum(cnt); sfl = ira::wave_sum(sfl); sl = ira::wave_sum(sl);
