@@ -27,6 +27,7 @@ constexpr int SM_MAX_RADICES = 12;
 struct SmoothPlan {
   int n, n1, n2;
   int c1, c2;                       // columns per workgroup in pass 1 / pass 2
+  int ld1, ld2;                     // LDS column strides (n1 / n2 plus a bank-conflict pad, see column_stride)
   int r1[SM_MAX_RADICES], nr1;      // radices of the N1-point transform
   int r2[SM_MAX_RADICES], nr2;
   const cd* t1;                     // exp(-2 pi i k / N1), k < N1
@@ -218,13 +219,13 @@ __device__ cd* lds_fft_stockham(cd* a, cd* b, int N, const int* radices, int nra
 // Half the LDS per tile means twice the columns per workgroup at the same number of resident workgroups: the passes are a
 // closed queue of tiles cycling between a memory phase and an LDS phase, and what is in flight per CU is what LDS holds.
 template <int R>
-__device__ __forceinline__ void dif_pass(cd* x, int N, int len, const cd* __restrict__ tw, int tid, int nbat) {
+__device__ __forceinline__ void dif_pass(cd* x, int N, int ld, int len, const cd* __restrict__ tw, int tid, int nbat) {
   const int per = N / R;                        // butterflies per transform
   const int m = len / R;
   const int scale = N / len;                    // W_len^(p k) = W_N^(scale p k)
   const unsigned magic = (unsigned)(0x100000000ull / (unsigned)m) + 1u;      // bf / m for bf < 2^16
   for (int t = 0; t < nbat; ++t) {
-    cd* xt = x + t * N;
+    cd* xt = x + t * ld;
     for (int bf = tid; bf < per; bf += SM_THREADS) {
       const int blk = m == 1 ? bf : (int)__umulhi((unsigned)bf, magic);
       const int p = bf - blk * m;
@@ -252,19 +253,19 @@ __device__ __forceinline__ void dif_pass(cd* x, int N, int len, const cd* __rest
   __syncthreads();
 }
 
-__device__ void lds_fft_dif_inplace(cd* a, int N, const int* radices, int nrad, const cd* __restrict__ tw, int tid,
+__device__ void lds_fft_dif_inplace(cd* a, int N, int ld, const int* radices, int nrad, const cd* __restrict__ tw, int tid,
                                     int nbat) {
   int len = N;
   for (int pass = 0; pass < nrad; ++pass) {
     const int r = radices[pass];
     switch (r) {
-      case 10: dif_pass<10>(a, N, len, tw, tid, nbat); break;
-      case 8: dif_pass<8>(a, N, len, tw, tid, nbat); break;
-      case 6: dif_pass<6>(a, N, len, tw, tid, nbat); break;
-      case 5: dif_pass<5>(a, N, len, tw, tid, nbat); break;
-      case 4: dif_pass<4>(a, N, len, tw, tid, nbat); break;
-      case 3: dif_pass<3>(a, N, len, tw, tid, nbat); break;
-      default: dif_pass<2>(a, N, len, tw, tid, nbat); break;
+      case 10: dif_pass<10>(a, N, ld, len, tw, tid, nbat); break;
+      case 8: dif_pass<8>(a, N, ld, len, tw, tid, nbat); break;
+      case 6: dif_pass<6>(a, N, ld, len, tw, tid, nbat); break;
+      case 5: dif_pass<5>(a, N, ld, len, tw, tid, nbat); break;
+      case 4: dif_pass<4>(a, N, ld, len, tw, tid, nbat); break;
+      case 3: dif_pass<3>(a, N, ld, len, tw, tid, nbat); break;
+      default: dif_pass<2>(a, N, ld, len, tw, tid, nbat); break;
     }
     len /= r;
   }
@@ -400,7 +401,8 @@ __global__ __launch_bounds__(SM_THREADS, (MODE == SM_SIGNAL ? 6 : 5)) void smoot
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cd* a = reinterpret_cast<cd*>(smem);
   const int C = P.c1, N1 = P.n1, N2 = P.n2;
-  cd* b = a + (size_t)C * N1;                              // second buffer (ping-pong plan only)
+  const int LD = P.ld1;                                    // column stride in LDS (N1 for the ping-pong plan)
+  cd* b = a + (size_t)C * LD;                              // second buffer (ping-pong plan only)
   cd* twl = P.inplace ? b : b + (size_t)C * N1;            // SM_TW entries
   unsigned bx, by;
   smooth_remap(bx, by);
@@ -423,13 +425,13 @@ __global__ __launch_bounds__(SM_THREADS, (MODE == SM_SIGNAL ? 6 : 5)) void smoot
     for (int u = 0; u < SM_UC; ++u) {
       const int i = base + tid + SM_THREADS * u;
       const cd v = smooth_value<MODE>(P, J, e, index_of(u), raw[u]);
-      if (i < total1) a[(i % C) * N1 + i / C] = v;
+      if (i < total1) a[(i % C) * LD + i / C] = v;
     }
   }
   __syncthreads();
   SM_STAMP(s1);
   const cd* r = a;
-  if (P.inplace) lds_fft_dif_inplace(a, N1, P.r1, P.nr1, twl, tid, C);
+  if (P.inplace) lds_fft_dif_inplace(a, N1, LD, P.r1, P.nr1, twl, tid, C);
   else r = lds_fft_stockham(a, b, N1, P.r1, P.nr1, twl, tid, C);
   SM_STAMP(s2);
   cd* w = work + (long long)e * P.n;
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(SM_THREADS, (MODE == SM_SIGNAL ? 6 : 5)) void smoot
     const int n2 = n2_0 + c;
     const int C2 = P.c2;
     w[(long long)(k1 / C2) * ((long long)N2 * C2) + (long long)n2 * C2 + k1 % C2] =
-        ira::cmul(r[c * N1 + (P.inplace ? dif_slot(k1, N1, P.r1, P.nr1) : k1)], twiddle_n(P, (unsigned)k1 * (unsigned)n2));
+        ira::cmul(r[c * LD + (P.inplace ? dif_slot(k1, N1, P.r1, P.nr1) : k1)], twiddle_n(P, (unsigned)k1 * (unsigned)n2));
   }
   if (P.stamp) {
     SM_STAMP(s3);
@@ -453,7 +455,8 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_rows_kernel(SmoothPlan P, S
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cd* a = reinterpret_cast<cd*>(smem);
   const int C = P.c2, N1 = P.n1, N2 = P.n2;
-  cd* b = a + (size_t)C * N2;                              // second buffer (ping-pong plan only)
+  const int LD = P.ld2;                                    // column stride in LDS (N2 for the ping-pong plan)
+  cd* b = a + (size_t)C * LD;                              // second buffer (ping-pong plan only)
   cd* twl = P.inplace ? b : b + (size_t)C * N2;
   unsigned bx, by;
   smooth_remap(bx, by);
@@ -475,13 +478,13 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_rows_kernel(SmoothPlan P, S
 #pragma unroll
     for (int u = 0; u < SM_U; ++u) {
       const int i = base + tid + SM_THREADS * u;
-      if (i < total2) a[(i % C) * N2 + i / C] = raw[u];
+      if (i < total2) a[(i % C) * LD + i / C] = raw[u];
     }
   }
   __syncthreads();
   SM_STAMP(s1);
   const cd* r = a;
-  if (P.inplace) lds_fft_dif_inplace(a, N2, P.r2, P.nr2, twl, tid, C);
+  if (P.inplace) lds_fft_dif_inplace(a, N2, LD, P.r2, P.nr2, twl, tid, C);
   else r = lds_fft_stockham(a, b, N2, P.r2, P.nr2, twl, tid, C);
   SM_STAMP(s2);
   const long long n = P.n;
@@ -489,7 +492,7 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_rows_kernel(SmoothPlan P, S
   for (int i = tid; i < N2 * C; i += SM_THREADS) {
     const int c = i % C, k2 = i / C;
     const long long k = (long long)(k1_0 + c) + (long long)N1 * k2;        // natural output index
-    cd v = r[c * N2 + (P.inplace ? dif_slot(k2, N2, P.r2, P.nr2) : k2)];
+    cd v = r[c * LD + (P.inplace ? dif_slot(k2, N2, P.r2, P.nr2) : k2)];
     if (OUT == SM_OUT_SPEC) {
       if (paired) {
         J.zpair[J.zpair_off[e] + k] = v;
@@ -566,6 +569,16 @@ int pick_columns(int len, int other, bool inplace) {
   return best;
 }
 
+// LDS column stride of the in-place plan.  The staging stores and the output loads walk a tile row by row, i.e. a quarter
+// wave touches 16 / C consecutive rows of each of the C columns: with a stride that is a multiple of 16 elements (256 B =
+// all 64 banks) the columns land on the same banks (2-way conflict at C = 2).  The pad shifts column c by c * 16 / C
+// sixteen-byte bank groups.
+int column_stride(int len, int c) {
+  if (c <= 1 || 16 % c != 0) return len;
+  const int want = 16 / c;
+  return len + ((want - len % 16) % 16 + 16) % 16;
+}
+
 bool smooth_split(long long n, int* n1_out, int* n2_out) {
   if (n < 64 || n > (long long)SM_MAX_N * SM_MAX_N) return false;
   long long m = n;
@@ -602,6 +615,8 @@ int32_t make_smooth_plan(int32_t n, const void* t1, const void* t2, const void* 
   P->c2 = pick_columns(n2, n1, P->inplace != 0);
   if (const char* ev = std::getenv("IRA_SMOOTH_C1")) { const int v = std::atoi(ev); if (v >= 1 && n2 % v == 0) P->c1 = v; }
   if (const char* ev = std::getenv("IRA_SMOOTH_C2")) { const int v = std::atoi(ev); if (v >= 1 && n1 % v == 0) P->c2 = v; }
+  P->ld1 = P->inplace ? column_stride(n1, P->c1) : n1;
+  P->ld2 = P->inplace ? column_stride(n2, P->c2) : n2;
   P->t1 = static_cast<const cd*>(t1); P->t2 = static_cast<const cd*>(t2); P->tf = static_cast<const cd*>(tf);
   P->stamp = std::getenv("IRA_SMOOTH_STAMP") != nullptr;
   return IRA_OK;
@@ -654,7 +669,7 @@ extern "C" int32_t ira_rfft_smooth(const float* x_dev, const int64_t* xoff_dev, 
   }
   hipStream_t st = (hipStream_t)stream;
   const size_t nbuf = P.inplace ? 1 : 2;
-  const size_t l1 = (nbuf * P.c1 * P.n1 + SM_TW) * sizeof(cd), l2 = (nbuf * P.c2 * P.n2 + SM_TW) * sizeof(cd);
+  const size_t l1 = (nbuf * P.c1 * P.ld1 + SM_TW) * sizeof(cd), l2 = (nbuf * P.c2 * P.ld2 + SM_TW) * sizeof(cd);
   SM_TRY(allow(smooth_cols_kernel<SM_SIGNAL>, l1));
   SM_TRY(allow(smooth_rows_kernel<SM_OUT_SPEC>, l2));
   cd* work = reinterpret_cast<cd*>(work_dev);
@@ -685,7 +700,7 @@ extern "C" int32_t ira_band_irfft_smooth(const double* spec_dev, const int64_t* 
   J.y = y_dev; J.y1_off = y1_off_dev; J.y2_off = y2_off_dev;
   hipStream_t st = (hipStream_t)stream;
   const size_t nbuf = P.inplace ? 1 : 2;
-  const size_t l1 = (nbuf * P.c1 * P.n1 + SM_TW) * sizeof(cd), l2 = (nbuf * P.c2 * P.n2 + SM_TW) * sizeof(cd);
+  const size_t l1 = (nbuf * P.c1 * P.ld1 + SM_TW) * sizeof(cd), l2 = (nbuf * P.c2 * P.ld2 + SM_TW) * sizeof(cd);
   SM_TRY(allow(smooth_cols_kernel<SM_SPECTRUM>, l1));
   SM_TRY(allow(smooth_rows_kernel<SM_OUT_BANDS>, l2));
   cd* work = reinterpret_cast<cd*>(work_dev);
