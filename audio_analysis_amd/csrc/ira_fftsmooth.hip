@@ -610,6 +610,25 @@ int32_t make_smooth_plan(int32_t n, const void* t1, const void* t2, const void* 
   P->nr1 = factor_radices(n1, P->r1);
   P->nr2 = factor_radices(n2, P->r2);
   if (P->nr1 < 0 || P->nr2 < 0) return IRA_E_UNSUPPORTED;
+  // tuning: IRA_SMOOTH_R1 / IRA_SMOOTH_R2 = comma-separated radix order for the n1- / n2-point transforms (product checked)
+  auto override_radices = [](const char* name, int len, int* out, int* cnt) {
+    const char* ev = std::getenv(name);
+    if (!ev) return;
+    int tmp[SM_MAX_RADICES], k = 0;
+    long long prod = 1;
+    for (const char* c = ev; *c && k < SM_MAX_RADICES;) {
+      const int r = std::atoi(c);
+      if (!(r == 2 || r == 3 || r == 4 || r == 5 || r == 6 || r == 8 || r == 10)) return;
+      tmp[k++] = r; prod *= r;
+      while (*c && *c != ',') ++c;
+      if (*c == ',') ++c;
+    }
+    if (prod != len) return;
+    for (int i = 0; i < k; ++i) out[i] = tmp[i];
+    *cnt = k;
+  };
+  override_radices("IRA_SMOOTH_R1", n1, P->r1, &P->nr1);
+  override_radices("IRA_SMOOTH_R2", n2, P->r2, &P->nr2);
   P->inplace = std::getenv("IRA_SMOOTH_PINGPONG") == nullptr;
   P->c1 = pick_columns(n1, n2, P->inplace != 0);
   P->c2 = pick_columns(n2, n1, P->inplace != 0);
