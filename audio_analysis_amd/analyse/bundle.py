@@ -48,6 +48,12 @@ def run_bundle_report(bundle_root: str | Path, settings: Optional[BundleRunSetti
     rs = settings.report_settings
     draw = bool(rs.render_plots) if rs is not None else True
     pool = PlotPool(settings.plot_workers) if (settings.plot_workers > 0 and draw) else None
+    # Abort semantics of the reference's serial loop (bundle.py:56-67): the first tap that cannot be analysed raises --
+    # whatever the exception type (ValueError from validation, FileNotFoundError / OSError from a missing or truncated
+    # tap) -- and every tap before it has its report on disk.  A failing group is therefore re-run tap by tap.  With
+    # several ranks, a rank that fails still joins the barrier (the others would otherwise wait for the collective's
+    # time-out) and re-raises afterwards; the index is not written then.
+    failure: Optional[BaseException] = None
     try:
         step = max(1, int(settings.taps_per_batch))
         for a in range(lo, hi, step):
@@ -55,16 +61,22 @@ def run_bundle_report(bundle_root: str | Path, settings: Optional[BundleRunSetti
             items = [(root / "taps" / f"{tap}.wav", reports / tap / tap) for tap in group]
             try:
                 run_reports_batched(items, rs, plot_pool=pool)
-            except ValueError:
+            except Exception:
                 if len(items) == 1:
                     raise
                 for item in items:                              # find the offending tap the way the reference would
                     run_reports_batched([item], rs, plot_pool=pool)
                 raise
+    except Exception as exc:                                    # noqa: BLE001 -- re-raised below, after the barrier
+        failure = exc
     finally:
         if pool is not None:
             pool.close()
-    _dist.barrier()
+    failed_somewhere = _dist.any_rank_true(failure is not None)
+    if failure is not None:
+        raise failure
+    if failed_somewhere:
+        raise RuntimeError("bundle report aborted: another rank failed on one of its taps")
 
     index = reports / "bundle_report.md"
     if rank == 0:
@@ -81,7 +93,7 @@ def run_bundle_report(bundle_root: str | Path, settings: Optional[BundleRunSetti
 
 
 def run_bundle_metrics(bundle_root: str | Path, settings=None, use_mono_downmix_for_stereo: bool = False,
-                       taps_per_step: int = 32):
+                       taps_per_step: int = 32, rank_world=None, gather: bool = True):
     """
     Batched metrics-only pass over a bundle (SURVEY.md section 8f rank 2 + section 8e): every rank ingests its block
     of taps natively (audio_analysis_amd.ingest: int16 upload, conversion on the device), runs the metrics-only full
@@ -100,13 +112,30 @@ def run_bundle_metrics(bundle_root: str | Path, settings=None, use_mono_downmix_
     meta = json.loads((root / "meta.json").read_text())
     taps: List[str] = list(meta.get("taps", []))
     rank, _, world = _dist.env_world()
-    lo, hi = _dist.shard_files(len(taps), rank, world)
+    if rank_world is not None:                       # caller-defined shard (rank, world) instead of the launcher's
+        rank, world = int(rank_world[0]), int(rank_world[1])
+    # Uniform bundles (what the recorder writes: every tap has meta.length_samples frames) shard as contiguous blocks of
+    # files; RAGGED bundles are sorted by size and dealt round-robin so that every rank gets the same share of samples
+    # (SURVEY.md section 8e).  Both channels of a file stay on one rank either way; rank 0 restores bundle order.
+    def _size(name):
+        try:
+            return (root / "taps" / f"{name}.wav").stat().st_size
+        except OSError:
+            return 0                                 # a missing tap raises in the ingest of the rank that owns it
+
+    sizes = [_size(t) for t in taps] if world > 1 else []
+    ragged = world > 1 and len(set(sizes)) > 1
+    if ragged:
+        mine = [taps[i] for i in _dist.balanced_assignment(sizes, world)[rank]]
+    else:
+        lo, hi = _dist.shard_files(len(taps), rank, world)
+        mine = taps[lo:hi]
     eng = get_engine()
     fr = FullReport(eng, settings or FullReportSettings())
     rows, labels = [], []
     step = max(1, int(taps_per_step))
     rate = int(meta.get("sample_rate_hz", 48_000) or 48_000)
-    groups = [taps[a : min(hi, a + step)] for a in range(lo, hi, step)]
+    groups = [mine[a : a + step] for a in range(0, len(mine), step)]
 
     def host_half(names):                            # headers + payload reads into pinned staging: no GPU call in here
         return TapSet(eng, [root / "taps" / f"{t}.wav" for t in names], rate, upload=False)
@@ -142,10 +171,17 @@ def run_bundle_metrics(bundle_root: str | Path, settings=None, use_mono_downmix_
     if pending is not None:
         rows.append(fr.finish(pending))
     local = np.concatenate(rows, axis=0) if rows else np.zeros((0, METRICS_WIDTH))
+    if not gather:                                   # this rank's (labels, records) only; the caller gathers
+        return labels, local
     records = _dist.gather_metrics(local, eng.device)
     if world > 1:
         import torch.distributed as td
         gathered = [None] * world if rank == 0 else None
         td.gather_object(labels, gathered, dst=0)
         labels = [x for part in gathered for x in part] if rank == 0 else None
+        if rank == 0 and ragged:
+            place = {name: i for i, name in enumerate(taps)}
+            order = np.argsort(np.array([place[name] for name, _ in labels], dtype=np.int64), kind="stable")
+            labels = [labels[i] for i in order]
+            records = records[order]
     return (labels, records) if rank == 0 else (None, None)

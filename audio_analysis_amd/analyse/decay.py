@@ -89,8 +89,8 @@ def _time_axis(n: int, sample_rate_hz: int) -> np.ndarray:
     return (np.arange(n, dtype=np.float32) / float(sample_rate_hz)).astype(np.float32)
 
 
-def _edc_on_device(eng, batch, sample_rate_hz: int, settings: DecayAnalysisSettings):
-    """Shared body: time selection + EDC kernel (+ optional host smoothing).  Returns device curve + bounds."""
+def _decay_bounds(eng, batch, sample_rate_hz: int, settings: DecayAnalysisSettings):
+    """Time selection of decay.py:135-147 for every channel of the batch -> (starts, lens)."""
     n = batch.length
     peaks = eng.peaks(batch) if settings.trim_to_peak else np.zeros(batch.count, dtype=np.int64)
     starts = np.empty(batch.count, dtype=np.int64)
@@ -100,6 +100,12 @@ def _edc_on_device(eng, batch, sample_rate_hz: int, settings: DecayAnalysisSetti
                                             settings.ignore_leading_seconds, None)
     if np.any(lens < 4):
         raise ValueError("Not enough samples after trimming/ignoring to compute EDC.")
+    return starts, lens
+
+
+def _edc_on_device(eng, batch, sample_rate_hz: int, settings: DecayAnalysisSettings):
+    """Shared body: time selection + EDC kernel (+ optional host smoothing).  Returns device curve + bounds."""
+    starts, lens = _decay_bounds(eng, batch, sample_rate_hz, settings)
     smooth = int(settings.edc_smoothing_window_samples or 0)
     if smooth > 1:
         # Optional, default-off: box smoothing of the unfloored f64 dB curve on the host (decay.py:161-164),
@@ -175,9 +181,18 @@ def decay_fit_specs(settings: DecayAnalysisSettings):
 def decay_device(eng, batch, sample_rate_hz: int, settings: DecayAnalysisSettings):
     """Device-resident decay analysis of a batch: EDC curves + fit/crossing records stay in HBM."""
     specs, ranges = decay_fit_specs(settings)
-    edc, edc_off, starts, lens = _edc_on_device(eng, batch, sample_rate_hz, settings)
-    fits_dev, cross_dev = eng.curve_fits(edc, edc_off, lens, 1.0, float(sample_rate_hz), ranges, 8,
-                                         cross=(0.0, -10.0))
+    if int(settings.edc_smoothing_window_samples or 0) > 1:
+        # optional dB smoothing changes the curve the fits see: materialise it, then fit the curve (ira_curve_fits)
+        edc, edc_off, starts, lens = _edc_on_device(eng, batch, sample_rate_hz, settings)
+        fits_dev, cross_dev = eng.curve_fits(edc, edc_off, lens, 1.0, float(sample_rate_hz), ranges, 8,
+                                             cross=(0.0, -10.0))
+    else:
+        # fused path (ira_edc_fits): crossings and fits come straight from the samples; the curve is written once for
+        # the caller and not read back
+        starts, lens = _decay_bounds(eng, batch, sample_rate_hz, settings)
+        fits_dev, cross_dev, edc, edc_off = eng.edc_fits(batch.x, batch.off + starts, lens, settings.edc_epsilon,
+                                                         settings.edc_floor_db, 1.0, float(sample_rate_hz), ranges, 8,
+                                                         cross=(0.0, -10.0), want_edc=True)
     return dict(edc=edc, edc_off=edc_off, starts=starts, lens=lens, fits=fits_dev, cross=cross_dev, specs=specs)
 
 

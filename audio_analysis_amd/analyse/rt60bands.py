@@ -272,8 +272,10 @@ def rt60_bands_device(eng, batch, sample_rate_hz: int, settings: Rt60BandsAnalys
         seg_off_a, seg_len_a = np.array(seg_off, np.int64), np.array(seg_len, np.int64)
         if np.any(seg_len_a < 4):
             raise ValueError("Not enough samples after trimming/ignoring to compute EDC.")
-        edc, edc_off = eng.edc_db(y, seg_off_a, seg_len_a, dec.edc_epsilon, dec.edc_floor_db)
-        fit_dev, _ = eng.curve_fits(edc, edc_off, seg_len_a, 1.0, float(sample_rate_hz), ranges, 8)
+        # fused EDC -> crossings -> fits (ira_edc_fits): a band's EDC curve only feeds its fits (reference
+        # rt60bands.py:272-321), so it is never written
+        fit_dev, _, _, _ = eng.edc_fits(y, seg_off_a, seg_len_a, dec.edc_epsilon, dec.edc_floor_db, 1.0,
+                                        float(sample_rate_hz), ranges, 8)
         ci, bi = np.array(seg_c), np.array(seg_b)
         have[ci, bi] = True
 

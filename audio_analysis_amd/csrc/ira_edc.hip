@@ -174,10 +174,24 @@ __global__ void edc_carry_kernel(const int64_t* __restrict__ len, int nseg, doub
     if (c == nchunks - 1) {
       // edc[0] exactly as the emit pass forms it: last tile's local-0 value + (local carry + chunk carry)
       const double v = sc[q + c] + (sc[2 * q + c] + carry);
-      sc[4 * q - 1] = fmax(v, eps);
+      sc[4 * q - 1] = (v != v) ? v : fmax(v, eps);
     }
     carry = sc[c] + carry;
   }
+}
+
+// dB value of one suffix sum: 10 log10(max(sum, eps) / norm) through the table log2 (ira_log.h): ~30 instructions per
+// sample instead of ~110 for an f64 divide + log10, same value to ~1e-14 dB; sum == norm gives exactly 0 dB.
+// Shared by the emit pass and the fused fit kernel so that both see the same float32 curve bit for bit.
+// numpy.maximum semantics: a NaN operand gives NaN (fmax would drop it).  A NaN sample makes the reference's whole
+// curve NaN (decay.py:151-166), an infinite one NaN before it and the floor after it.
+__device__ __forceinline__ double np_max(double a, double b) { return (a != a) ? a : fmax(a, b); }
+
+__device__ __forceinline__ double edc_db64(double sum, double eps, double norm, double lnorm, bool fast,
+                                           const ira::LogTabEntry* ltab) {
+  const double v = np_max(sum, eps);
+  if (fast && v > 1e-300 && v < 1e300) return 3.0102999566398120 * (ira::log2_table(v, ltab) - lnorm);
+  return 10.0 * log10(v / norm);
 }
 
 __global__ __launch_bounds__(EDC_THREADS) void edc_emit_kernel(
@@ -217,12 +231,9 @@ __global__ __launch_bounds__(EDC_THREADS) void edc_emit_kernel(
 #pragma unroll
     for (int r = 0; r < EDC_PER_THREAD; ++r) {
       const int i = i0 + r;
-      const double v = fmax(s[r] + c, eps);
-      double db;
-      if (fast && v > 1e-300 && v < 1e300) db = 3.0102999566398120 * (ira::log2_table(v, ltab) - lnorm);
-      else db = 10.0 * log10(v / norm);
+      const double db = edc_db64(s[r] + c, eps, norm, lnorm, fast, ltab);
       if (dst64 && i < tl) dst64[lo + i] = db;  // unfloored f64 (host-side optional smoothing, decay.py:161-164)
-      o4[r] = (float)fmax(db, floor_db);
+      o4[r] = (float)np_max(db, floor_db);
     }
     if (dst) {
       if (i0 + EDC_PER_THREAD <= tl) {
@@ -567,19 +578,303 @@ __global__ void curve_fit_kernel(const float* __restrict__ ybase, const int64_t*
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// a3-a6 fused (ira_edc_fits): crossings and decay-line fits straight from the SAMPLES.
+//
+// After edc_sums / edc_carry every 16384-sample chunk of a segment knows the energy behind it (its carry) and its
+// own total, i.e. the interval of EDC values it spans -- and an EDC is monotone.  So the chunk that holds a dB
+// crossing is known WITHOUT the curve, and the regression only needs the curve between the two crossings of a
+// range.  One workgroup per segment:
+//   phase A  for every target level, start at the first chunk (in time) that is not certainly above it and re-scan
+//            chunks (the emit pass's own scan code and dB conversion -> the identical float32 values) until the
+//            first index with edc_db <= target is found; the chunk's dB values sit in LDS, so y[idx-1], y[idx]
+//            for the interpolation come from there;
+//   phase B  re-scan the chunks between the crossings once and accumulate shifted first and second moments of
+//            every range in float64 (one sweep instead of the three passes of curve_fit_kernel).
+// Nothing reads an EDC array: a band EDC that only feeds its fits (rt60bands.py:272-321) is never written, and
+// the decay block's curve is written by the emit pass for the caller but not read back here.
+// ------------------------------------------------------------------------------------------------
+constexpr int EF_CHUNK = EDC_CHUNK_TILES * EDC_TILE;   // 16384 samples = 64 KB of float32 dB values in LDS
+
+struct EdcFitRange {
+  double ts, te, tmid, ymid;
+  long long a0, a1;
+  float ts32, te32;
+  int ok, pad;
+};
+
+struct EdcFitShared {
+  EdcShared scan;
+  EdcFitRange rng[FIT_MAX_RANGES];
+  double part[EDC_THREADS / IRA_WAVE][FIT_MAX_RANGES][6];
+  ira::LogTabEntry ltab[ira::LOGTAB_N];
+  float db[EF_CHUNK];
+  unsigned long long found[FIT_MAX_TARGETS];      // local index of the first crossing in the chunk in LDS
+  long long idx[FIT_MAX_TARGETS];                 // first index with edc_db <= target; n = never
+  float y_at[FIT_MAX_TARGETS], y_prev[FIT_MAX_TARGETS];
+  float tgt32[FIT_MAX_TARGETS];
+  int first_chunk[FIT_MAX_TARGETS];               // chunk (counted from the END) where the search starts; -1 = never
+};
+
+// dB curve of chunk c (tiles 4c .. 4c+3 counted from the end of the segment) into sh.db, in time order.
+// Same scan, same association of the carries and same conversion as edc_emit_kernel.
+__device__ __forceinline__ void edc_chunk_to_lds(const float* __restrict__ src, long long n, int c, double chunk_carry,
+                                                 double eps, double floor_db, double norm, double lnorm, bool fast,
+                                                 EdcFitShared& sh, long long& cstart, int& clen) {
+  const long long ntiles = (n + EDC_TILE - 1) / EDC_TILE;
+  const long long cend = n - (long long)c * EF_CHUNK;
+  cstart = cend - EF_CHUNK > 0 ? cend - EF_CHUNK : 0;
+  clen = (int)(cend - cstart);
+  double run = 0.0;
+  double s[EDC_PER_THREAD];
+  const long long t0 = (long long)c * EDC_CHUNK_TILES;
+  for (long long j = t0; j < t0 + EDC_CHUNK_TILES && j < ntiles; ++j) {
+    const long long hi = n - j * EDC_TILE;
+    const long long lo = hi - EDC_TILE > 0 ? hi - EDC_TILE : 0;
+    const int tl = (int)(hi - lo);
+    const double tot = tile_suffix_scan(src + lo, tl, sh.scan, s);
+    const double cc = run + chunk_carry;
+    const int i0 = EDC_PER_THREAD * threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < EDC_PER_THREAD; ++r) {
+      const int i = i0 + r;
+      if (i < tl) sh.db[(int)(lo - cstart) + i] = (float)np_max(edc_db64(s[r] + cc, eps, norm, lnorm, fast, sh.ltab), floor_db);
+    }
+    run = tot + run;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ double crossing_time_from_values(long long idx, long long n, float y_prev, float y_at,
+                                                            double target, const TimeAxis& ta) {
+  if (idx >= n) return __longlong_as_double(0x7ff8000000000000ll);  // NaN = "no crossing"
+  if (idx == 0) return (double)ta.at(0);
+  const double t0 = (double)ta.at(idx - 1);
+  const double t1 = (double)ta.at(idx);
+  const double y0 = (double)y_prev;
+  const double y1 = (double)y_at;
+  if (y1 == y0) return t1;
+  double frac = (target - y0) / (y1 - y0);
+  frac = fmin(fmax(frac, 0.0), 1.0);
+  return t0 + frac * (t1 - t0);
+}
+
+__global__ __launch_bounds__(EDC_THREADS) void edc_fit_kernel(
+    const float* __restrict__ x, const int64_t* __restrict__ off, const int64_t* __restrict__ len, double eps,
+    double floor_db, FitParams P, const double* __restrict__ scratch, double* __restrict__ fit_out,
+    double* __restrict__ cross_out) {
+  extern __shared__ __align__(16) unsigned char ef_smem[];
+  EdcFitShared& sh = *reinterpret_cast<EdcFitShared*>(ef_smem);
+  const int seg = blockIdx.x;
+  const long long n = len[seg];
+  const int tid = threadIdx.x;
+  const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+  const TimeAxis ta{nullptr, P.t_mul, P.t_div};
+  double* fo = fit_out ? fit_out + (int64_t)seg * P.nranges * IRA_FIT_DOUBLES : nullptr;
+  double* co = cross_out ? cross_out + (int64_t)seg * P.ncross : nullptr;
+  const int ntargets = 2 * P.nranges + P.ncross;
+  if (n <= 0) {
+    if (tid == 0) {
+      for (int r = 0; r < P.nranges; ++r)
+        for (int k = 0; k < IRA_FIT_DOUBLES; ++k) fo[r * IRA_FIT_DOUBLES + k] = (k == 0) ? 0.0 : qnan;
+      for (int j = 0; j < P.ncross && co; ++j) co[j] = qnan;
+    }
+    return;
+  }
+  ira::build_log_table(sh.ltab, tid);
+  const float* src = x + off[seg];
+  const int q = IRA_EDC_SCRATCH_DOUBLES / 4;
+  const double* sc = scratch + (int64_t)seg * IRA_EDC_SCRATCH_DOUBLES;
+  const long long ntiles = (n + EDC_TILE - 1) / EDC_TILE;
+  const int nchunks = (int)((ntiles + EDC_CHUNK_TILES - 1) / EDC_CHUNK_TILES);
+  const double norm = sc[4 * q - 1];
+  const bool fast = norm > 1e-300 && norm < 1e300;
+  __syncthreads();
+  const double lnorm = fast ? ira::log2_table(norm, sh.ltab) : 0.0;
+
+  // ---- where each target's search starts -------------------------------------------------------------------------
+  if (tid < FIT_MAX_TARGETS) {
+    double tv = 0.0;
+    if (tid < 2 * P.nranges) tv = (tid & 1) ? P.lo[tid >> 1] : P.hi[tid >> 1];
+    else if (tid < ntargets) tv = P.cross[tid - 2 * P.nranges];
+    const float t32 = (float)tv;
+    sh.tgt32[tid] = t32;
+    sh.idx[tid] = n;
+    sh.y_at[tid] = 0.0f; sh.y_prev[tid] = 0.0f;
+    int first = -1;
+    if (tid < ntargets && !(t32 < (float)floor_db)) {      // the floored curve never goes below float32(floor_db)
+      // A value v has float32(dB(v)) > target for certain once dB(v) exceeds the target by two float32 ulps; in the
+      // linear domain: v > thr_hi.  Every value of chunk c is >= its carry (sums of non-negative terms are monotone
+      // in floating point), so carry > thr_hi rules the whole chunk out.  eps clamps from below the same way.
+      const double ulp2 = fmax(fabs((double)t32) * 2.384185791015625e-07, 1e-9);
+      const double thr_hi = norm * pow(10.0, ((double)t32 + ulp2) / 10.0) * (1.0 + 1e-12);
+      if (!(eps > thr_hi)) {
+        for (int c = nchunks - 1; c >= 0; --c)
+          if (!(sc[3 * q + c] > thr_hi)) { first = c; break; }
+      }
+    }
+    sh.first_chunk[tid] = first;
+  }
+  __syncthreads();
+
+  // ---- phase A: first-crossing indices ---------------------------------------------------------------------------
+  for (int c = nchunks - 1; c >= 0; --c) {
+    bool need = false, open = false;
+    for (int k = 0; k < ntargets; ++k) {
+      const bool unfound = sh.first_chunk[k] >= 0 && sh.idx[k] >= n;
+      open = open || unfound;
+      need = need || (unfound && sh.first_chunk[k] >= c);
+    }
+    if (!open) break;
+    if (!need) continue;                                   // uniform: every thread reads the same shared state
+    long long cstart; int clen;
+    edc_chunk_to_lds(src, n, c, sc[3 * q + c], eps, floor_db, norm, lnorm, fast, sh, cstart, clen);
+    if (tid < FIT_MAX_TARGETS) sh.found[tid] = 0xffffffffffffffffull;
+    __syncthreads();
+    for (int k = 0; k < ntargets; ++k) {
+      if (!(sh.first_chunk[k] >= c && sh.idx[k] >= n)) continue;      // uniform
+      const float t32 = sh.tgt32[k];
+      int f = clen;
+      for (int i = tid; i < clen; i += EDC_THREADS)
+        if (sh.db[i] <= t32) { f = i; break; }             // ascending per thread: its first hit is its smallest
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const int other = __shfl_xor(f, o, 64);
+        f = other < f ? other : f;
+      }
+      if ((tid & 63) == 0 && f < clen) atomicMin(&sh.found[k], (unsigned long long)f);
+    }
+    __syncthreads();
+    if (tid < ntargets && sh.first_chunk[tid] >= c && sh.idx[tid] >= n && sh.found[tid] != 0xffffffffffffffffull) {
+      const int f = (int)sh.found[tid];
+      sh.idx[tid] = cstart + f;
+      sh.y_at[tid] = sh.db[f];
+      if (f > 0) sh.y_prev[tid] = sh.db[f - 1];
+      else if (cstart > 0) {
+        // the sample before this chunk is the LAST sample of chunk c+1: its suffix sum is its own energy + (0 + carry)
+        const double v = (double)src[cstart - 1];
+        const double e = v * v;
+        sh.y_prev[tid] = (float)np_max(edc_db64(e + (0.0 + sc[3 * q + c + 1]), eps, norm, lnorm, fast, sh.ltab), floor_db);
+      }
+    }
+    __syncthreads();
+  }
+
+  if (co && tid == 0) {
+    for (int j = 0; j < P.ncross; ++j) {
+      const int k = 2 * P.nranges + j;
+      co[j] = crossing_time_from_values(sh.idx[k], n, sh.y_prev[k], sh.y_at[k], P.cross[j], ta);
+    }
+  }
+  if (P.nranges == 0) return;
+
+  // ---- phase B: one sweep over the chunks between the crossings, shifted moments per range --------------------------
+  // Range parameters live in LDS and the running sums in per-wave LDS slots: per-thread accumulators for every range
+  // would not fit the 128 registers a 1024-thread workgroup leaves per lane.
+  if (tid < FIT_MAX_RANGES) {
+    EdcFitRange g;
+    g.ok = 0; g.ts = g.te = qnan; g.tmid = g.ymid = 0.0; g.ts32 = g.te32 = 0.0f; g.a0 = 0; g.a1 = -1; g.pad = 0;
+    if (tid < P.nranges) {
+      const int r = tid;
+      const long long i_hi = sh.idx[2 * r], i_lo = sh.idx[2 * r + 1];
+      g.ts = crossing_time_from_values(i_hi, n, sh.y_prev[2 * r], sh.y_at[2 * r], P.hi[r], ta);
+      g.te = crossing_time_from_values(i_lo, n, sh.y_prev[2 * r + 1], sh.y_at[2 * r + 1], P.lo[r], ta);
+      g.ok = !(isnan(g.ts) || isnan(g.te) || g.te <= g.ts) ? 1 : 0;
+      if (g.ok) {
+        g.ts32 = (float)g.ts; g.te32 = (float)g.te;
+        g.a0 = i_hi - 2 > 0 ? i_hi - 2 : 0;
+        g.a1 = i_lo + 2 < n - 1 ? i_lo + 2 : n - 1;
+        g.tmid = 0.5 * (g.ts + g.te);
+        g.ymid = 0.5 * (P.hi[r] + P.lo[r]);
+      }
+    }
+    sh.rng[tid] = g;
+  }
+  for (int i = tid; i < (EDC_THREADS / IRA_WAVE) * FIT_MAX_RANGES * 6; i += EDC_THREADS) (&sh.part[0][0][0])[i] = 0.0;
+  __syncthreads();
+  long long lo_all = n, hi_all = -1;
+  for (int r = 0; r < P.nranges; ++r) {
+    if (!sh.rng[r].ok) continue;
+    lo_all = sh.rng[r].a0 < lo_all ? sh.rng[r].a0 : lo_all;
+    hi_all = sh.rng[r].a1 > hi_all ? sh.rng[r].a1 : hi_all;
+  }
+  if (hi_all >= lo_all) {
+    const int c_first = (int)((n - 1 - lo_all) / EF_CHUNK);      // earliest chunk in time (largest number)
+    const int c_last = (int)((n - 1 - hi_all) / EF_CHUNK);
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int c = c_first; c >= c_last; --c) {
+      long long cstart; int clen;
+      edc_chunk_to_lds(src, n, c, sc[3 * q + c], eps, floor_db, norm, lnorm, fast, sh, cstart, clen);
+      for (int r = 0; r < P.nranges; ++r) {
+        const EdcFitRange g = sh.rng[r];                     // uniform
+        if (!g.ok || g.a1 < cstart || g.a0 >= cstart + clen) continue;
+        double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0, m4 = 0.0, m5 = 0.0;
+        for (int i = tid; i < clen; i += EDC_THREADS) {
+          const long long gi = cstart + i;
+          const float tf = ta.at(gi);
+          if (gi >= g.a0 && gi <= g.a1 && tf >= g.ts32 && tf <= g.te32) {
+            const double u = (double)tf - g.tmid, w = (double)sh.db[i] - g.ymid;
+            m0 += 1.0; m1 += u; m2 += w; m3 += u * u; m4 += u * w; m5 += w * w;
+          }
+        }
+        m0 = ira::wave_sum(m0); m1 = ira::wave_sum(m1); m2 = ira::wave_sum(m2);
+        m3 = ira::wave_sum(m3); m4 = ira::wave_sum(m4); m5 = ira::wave_sum(m5);
+        if (lane == 0) {
+          double* pp = sh.part[wave][r];
+          pp[0] += m0; pp[1] += m1; pp[2] += m2; pp[3] += m3; pp[4] += m4; pp[5] += m5;
+        }
+      }
+      __syncthreads();                                       // sh.db is rewritten by the next chunk
+    }
+  }
+  if (tid < P.nranges) {
+    const int r = tid;
+    const EdcFitRange g = sh.rng[r];
+    double* o = fo + r * IRA_FIT_DOUBLES;
+    if (!g.ok) {
+      o[0] = 0.0; o[1] = g.ts; o[2] = g.te; for (int k = 3; k < IRA_FIT_DOUBLES; ++k) o[k] = qnan;
+    } else {
+      double cnt = 0.0, su = 0.0, sw = 0.0, suu = 0.0, suw = 0.0, sww = 0.0;
+      for (int w = 0; w < EDC_THREADS / IRA_WAVE; ++w) {
+        const double* pp = sh.part[w][r];
+        cnt += pp[0]; su += pp[1]; sw += pp[2]; suu += pp[3]; suw += pp[4]; sww += pp[5];
+      }
+      const long long npts = (long long)cnt;
+      if (npts < P.min_points) {
+        o[0] = 0.0; o[1] = g.ts; o[2] = g.te; for (int k = 3; k < 7; ++k) o[k] = qnan; o[7] = (double)npts;
+      } else {
+        // centred moments from the shifted sums (shift = mid-range: the subtractions lose nothing that matters in f64)
+        const double um = su / cnt, wm = sw / cnt;
+        const double stt = suu - su * um, sty = suw - su * wm, syy = sww - sw * wm;
+        const double slope = sty / stt;
+        const double tm = g.tmid + um, ym = g.ymid + wm;
+        const double icpt = ym - slope * tm;
+        const double sres = syy - slope * sty;               // residual sum of squares of the least-squares line
+        const bool neg = slope < 0.0;                        // also false for NaN (stt == 0)
+        o[0] = neg ? 1.0 : 0.0;
+        o[1] = g.ts; o[2] = g.te; o[3] = slope; o[4] = icpt;
+        o[5] = syy > 0.0 ? 1.0 - fmax(sres, 0.0) / syy : 0.0;
+        o[6] = -60.0 / slope;
+        o[7] = (double)npts;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int32_t ira_peak_index(const float* x_dev, const int64_t* off_dev, const int64_t* len_dev, int32_t nseg,
-                                  int64_t* peak_dev, float* peak_abs_dev, void* stream) {
+                                  int64_t max_len, int64_t* peak_dev, float* peak_abs_dev, void* stream) {
   IRA_CHECK_PTR(x_dev); IRA_CHECK_PTR(off_dev); IRA_CHECK_PTR(len_dev); IRA_CHECK_PTR(peak_dev);
   if (nseg <= 0) return nseg == 0 ? IRA_OK : IRA_E_SIZE;
+  // indices travel in the low 32 bits of the atomicMax key; grid.y carries the segment
+  if (nseg > 65535 || max_len < 0 || max_len > 0xFFFFFFFFll) return IRA_E_SIZE;
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(peak_dev, 0, sizeof(int64_t) * (size_t)nseg, st);
   if (e != hipSuccess) return ira_hip_status(e);
-  // chunk count is sized for the longest supported segment (2^31 samples would be 131072 chunks); the host
-  // passes lengths on the device only, so launch a fixed generous grid and let empty chunks exit at once.
-  const int max_chunks = 2048;  // 33.5 M samples per segment
-  peak_partial_kernel<<<dim3(max_chunks, nseg), PEAK_THREADS, 0, st>>>(
+  // the grid covers the LONGEST segment (the host knows the lengths); shorter segments' spare chunks exit at once
+  const int64_t chunks = max_len > 0 ? (max_len + PEAK_CHUNK - 1) / PEAK_CHUNK : 1;
+  peak_partial_kernel<<<dim3((unsigned)chunks, nseg), PEAK_THREADS, 0, st>>>(
       x_dev, off_dev, len_dev, reinterpret_cast<unsigned long long*>(peak_dev));
   peak_decode_kernel<<<(nseg + 255) / 256, 256, 0, st>>>(reinterpret_cast<unsigned long long*>(peak_dev),
                                                            peak_abs_dev, nseg);
@@ -602,6 +897,45 @@ extern "C" int32_t ira_edc_db(const float* x_dev, const int64_t* off_dev, const 
   edc_carry_kernel<<<(nseg + 63) / 64, 64, 0, st>>>(len_dev, nseg, eps, scratch_dev);
   edc_emit_kernel<<<dim3(nchunks, nseg), EDC_THREADS, 0, st>>>(x_dev, off_dev, len_dev, eps, floor_db, edc_db_dev,
                                                                edc_db64_dev, edc_off_dev, scratch_dev);
+  IRA_RETURN_LAUNCH();
+}
+
+extern "C" int32_t ira_edc_fits(const float* x_dev, const int64_t* off_dev, const int64_t* len_dev, int32_t nseg,
+                                int64_t max_len, double eps, double floor_db, float t_mul, float t_div,
+                                const double* ranges_hi_lo, int32_t nranges, int32_t min_points,
+                                const double* cross_targets, int32_t ncross, double* fit_out_dev,
+                                double* cross_out_dev, float* edc_db_dev, const int64_t* edc_off_dev,
+                                double* scratch_dev, void* stream) {
+  IRA_CHECK_PTR(x_dev); IRA_CHECK_PTR(off_dev); IRA_CHECK_PTR(len_dev); IRA_CHECK_PTR(scratch_dev);
+  if (nranges < 0 || nranges > FIT_MAX_RANGES || ncross < 0 || ncross > FIT_MAX_CROSS) return IRA_E_SIZE;
+  if (nranges > 0) { IRA_CHECK_PTR(ranges_hi_lo); IRA_CHECK_PTR(fit_out_dev); }
+  if (ncross > 0) { IRA_CHECK_PTR(cross_targets); IRA_CHECK_PTR(cross_out_dev); }
+  if (edc_db_dev != nullptr) IRA_CHECK_PTR(edc_off_dev);
+  if (nseg <= 0) return nseg == 0 ? IRA_OK : IRA_E_SIZE;
+  if (max_len <= 0 || max_len > (int64_t)EDC_MAX_CHUNKS * EDC_CHUNK_TILES * EDC_TILE) return IRA_E_SIZE;
+  if (nseg > 65535) return IRA_E_SIZE;
+  FitParams P{};
+  for (int r = 0; r < nranges; ++r) { P.hi[r] = ranges_hi_lo[2 * r]; P.lo[r] = ranges_hi_lo[2 * r + 1]; }
+  for (int j = 0; j < ncross; ++j) P.cross[j] = cross_targets[j];
+  P.nranges = nranges; P.ncross = ncross; P.min_points = min_points; P.rel_to_peak = 0;
+  P.floor_db = floor_db; P.min_peak_above_floor = 0.0; P.t_mul = t_mul; P.t_div = t_div; P.t_axis = nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t ntiles = (max_len + EDC_TILE - 1) / EDC_TILE;
+  const int nchunks = (int)((ntiles + EDC_CHUNK_TILES - 1) / EDC_CHUNK_TILES);
+  {   // > 64 KB of dynamic LDS needs the opt-in (idempotent, host-side only)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(edc_fit_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(EdcFitShared));
+    if (e != hipSuccess) return ira_hip_status(e);
+  }
+  edc_sums_kernel<<<dim3(nchunks, nseg), EDC_THREADS, 0, st>>>(x_dev, off_dev, len_dev, scratch_dev);
+  edc_carry_kernel<<<(nseg + 63) / 64, 64, 0, st>>>(len_dev, nseg, eps, scratch_dev);
+  if (nranges + ncross > 0)
+    edc_fit_kernel<<<nseg, EDC_THREADS, sizeof(EdcFitShared), st>>>(x_dev, off_dev, len_dev, eps, floor_db, P,
+                                                                     scratch_dev, fit_out_dev,
+                                                                     ncross > 0 ? cross_out_dev : nullptr);
+  if (edc_db_dev != nullptr)
+    edc_emit_kernel<<<dim3(nchunks, nseg), EDC_THREADS, 0, st>>>(x_dev, off_dev, len_dev, eps, floor_db, edc_db_dev,
+                                                                 nullptr, edc_off_dev, scratch_dev);
   IRA_RETURN_LAUNCH();
 }
 

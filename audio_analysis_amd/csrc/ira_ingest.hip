@@ -18,37 +18,38 @@ struct WavInfo {
   int64_t frames = 0, data_offset = 0;
 };
 
-// Returns IRA_OK, IRA_E_UNSUPPORTED (a valid WAV that is not 16-bit PCM) or IRA_E_SIZE (not a readable RIFF/WAVE file).
+// Returns IRA_OK, IRA_E_UNSUPPORTED (a valid WAV that is not 16-bit PCM), IRA_E_FORMAT (not RIFF/WAVE) or IRA_E_IO
+// (truncated).
 int32_t parse_wav(FILE* f, WavInfo* w) {
   unsigned char hdr[12];
-  if (std::fread(hdr, 1, 12, f) != 12) return IRA_E_SIZE;
-  if (std::memcmp(hdr, "RIFF", 4) != 0 || std::memcmp(hdr + 8, "WAVE", 4) != 0) return IRA_E_SIZE;
+  if (std::fread(hdr, 1, 12, f) != 12) return IRA_E_FORMAT;
+  if (std::memcmp(hdr, "RIFF", 4) != 0 || std::memcmp(hdr + 8, "WAVE", 4) != 0) return IRA_E_FORMAT;
   bool have_fmt = false;
   uint16_t block_align = 0;
   for (;;) {
     unsigned char ch[8];
-    if (std::fread(ch, 1, 8, f) != 8) return IRA_E_SIZE;
+    if (std::fread(ch, 1, 8, f) != 8) return IRA_E_IO;
     uint32_t size;
     std::memcpy(&size, ch + 4, 4);
     if (std::memcmp(ch, "fmt ", 4) == 0) {
       unsigned char fm[16];
-      if (size < 16 || std::fread(fm, 1, 16, f) != 16) return IRA_E_SIZE;
+      if (size < 16 || std::fread(fm, 1, 16, f) != 16) return IRA_E_IO;
       uint16_t fmt, chans, bits;
       uint32_t rate;
       std::memcpy(&fmt, fm, 2); std::memcpy(&chans, fm + 2, 2); std::memcpy(&rate, fm + 4, 4);
       std::memcpy(&block_align, fm + 12, 2); std::memcpy(&bits, fm + 14, 2);
       if (fmt == 0xFFFE && size >= 40) {                       // WAVE_FORMAT_EXTENSIBLE: the sub-format's first two bytes
         unsigned char ext[24];
-        if (std::fread(ext, 1, 24, f) != 24) return IRA_E_SIZE;
+        if (std::fread(ext, 1, 24, f) != 24) return IRA_E_IO;
         std::memcpy(&fmt, ext + 8, 2);
-        if (std::fseek(f, (long)(size - 40 + (size & 1)), SEEK_CUR) != 0) return IRA_E_SIZE;
+        if (std::fseek(f, (long)(size - 40 + (size & 1)), SEEK_CUR) != 0) return IRA_E_IO;
       } else if (std::fseek(f, (long)(size - 16 + (size & 1)), SEEK_CUR) != 0) {
-        return IRA_E_SIZE;
+        return IRA_E_IO;
       }
       w->format = fmt; w->channels = chans; w->sample_rate = (int32_t)rate; w->bits = bits;
       have_fmt = true;
     } else if (std::memcmp(ch, "data", 4) == 0) {
-      if (!have_fmt) return IRA_E_SIZE;
+      if (!have_fmt) return IRA_E_FORMAT;
       w->data_offset = std::ftell(f);
       if (w->format != 1 || w->bits != 16 || w->channels < 1 || w->channels > 2) {
         w->frames = block_align ? (int64_t)size / block_align : 0;           // header facts for the caller's validation
@@ -57,7 +58,7 @@ int32_t parse_wav(FILE* f, WavInfo* w) {
       w->frames = (int64_t)size / (2 * w->channels);
       return IRA_OK;
     } else {
-      if (std::fseek(f, (long)(size + (size & 1)), SEEK_CUR) != 0) return IRA_E_SIZE;   // LIST, fact, ... (word aligned)
+      if (std::fseek(f, (long)(size + (size & 1)), SEEK_CUR) != 0) return IRA_E_IO;   // LIST, fact, ... (word aligned)
     }
   }
 }
@@ -91,7 +92,7 @@ extern "C" int32_t ira_wav_probe(const char* path, int32_t* sample_rate, int32_t
   IRA_CHECK_PTR(path); IRA_CHECK_PTR(sample_rate); IRA_CHECK_PTR(channels); IRA_CHECK_PTR(frames);
   IRA_CHECK_PTR(data_offset);
   FILE* f = std::fopen(path, "rb");
-  if (!f) return IRA_E_SIZE;
+  if (!f) return IRA_E_IO;
   WavInfo w;
   const int32_t rc = parse_wav(f, &w);
   std::fclose(f);
@@ -104,11 +105,11 @@ extern "C" int32_t ira_wav_read_pcm16(const char* path, int64_t data_offset, int
   IRA_CHECK_PTR(path); IRA_CHECK_PTR(dst_host);
   if (frames < 0 || channels < 1 || channels > 2 || data_offset < 0) return IRA_E_SIZE;
   FILE* f = std::fopen(path, "rb");
-  if (!f) return IRA_E_SIZE;
+  if (!f) return IRA_E_IO;
   int32_t rc = IRA_OK;
-  if (std::fseek(f, (long)data_offset, SEEK_SET) != 0) rc = IRA_E_SIZE;
+  if (std::fseek(f, (long)data_offset, SEEK_SET) != 0) rc = IRA_E_IO;
   const size_t want = (size_t)frames * (size_t)channels;
-  if (rc == IRA_OK && std::fread(dst_host, sizeof(int16_t), want, f) != want) rc = IRA_E_SIZE;
+  if (rc == IRA_OK && std::fread(dst_host, sizeof(int16_t), want, f) != want) rc = IRA_E_IO;
   std::fclose(f);
   return rc;
 }

@@ -45,6 +45,20 @@ __device__ __forceinline__ float db_of4(double re, double im, double floor_pow, 
   return (float)(3.0102999566398120 * ira::log2_table(p, tab));
 }
 
+// Linear magnitude the reference's aggregation starts from: 10^(float32(dB)/20) with dB = 20 log10 max(|X|, floor)
+// (modalcloud.py:186-190 applied to the float32 STFT of :150-156).  With dB = 10 log10 p in float64 and d = float32(dB) - dB
+// (|d| <= 4e-6 dB) this is sqrt(p) * 10^(d/20) = sqrt(p) (1 + t + t^2/2), t = d ln(10)/20 <= 5e-7 (next term 2e-20):
+// a square root and two fused multiply-adds instead of a float64 exp10 (~50 instructions), same value to ~1e-15.
+__device__ __forceinline__ double lin_of4(double re, double im, double floor_pow, float floor_db, double floor_lin32,
+                                          const ira::LogTabEntry* tab) {
+  const double p = fma(re, re, im * im);
+  if (!(p > floor_pow)) return floor_lin32;                                    // also catches NaN, like db_of4
+  if (!(p < 1.0e300)) return exp10((double)(float)(20.0 * log10(hypot(re, im))) * 0.05);
+  const double db = 3.0102999566398120 * ira::log2_table(p, tab);
+  const double t = ((double)(float)db - db) * 0.11512925464970228;
+  return sqrt(p) * fma(t, fma(t, 0.5, 1.0), 1.0);
+}
+
 __global__ __launch_bounds__(TL4) void stft4_kernel(
     const float* __restrict__ x, const int64_t* __restrict__ off, const int32_t* __restrict__ nframes, int hop,
     const double* __restrict__ window, const cdd* __restrict__ tw, double floor_lin, float floor_db,
@@ -209,19 +223,41 @@ __global__ __launch_bounds__(TL4) void stft4_kernel(
   // ---- fused modal-cloud aggregation (reference modalcloud.py:176-207): the frame's dB values never leave the CU.
   // float32 dB (the reference's STFT output type) -> linear magnitude 10^(dB/20) in float64 -> LDS; then log bin b is
   // the mean of its rows, added in ascending order, -> 20 log10(max(., 1e-30)) -> float32 at out[b * T + frame].
-  __syncthreads();                                          // every lane has finished reading E3
+  // Only the rows some log bin reads are converted: 20 Hz .. 20 kHz is rows 4 .. 3413 of 4097, a sixth of the
+  // conversions (the costliest part of the frame) is skipped.
+  __shared__ int lb_range[2];
+  if (q < 2) lb_range[q] = q == 0 ? F4 : 0;
+  __syncthreads();                                          // every lane has finished reading E3 (and sees lb_range)
+  {
+    int lo = F4, hi = 0;
+    for (int b = q; b < lb_nbins; b += TL4) {
+      const int c = lb_count[b];
+      if (c > 0) {
+        const int f0 = lb_kbase + lb_first[b];
+        lo = f0 < lo ? f0 : lo;
+        hi = f0 + c > hi ? f0 + c : hi;
+      }
+    }
+    atomicMin(&lb_range[0], lo);
+    atomicMax(&lb_range[1], hi);
+  }
+  __syncthreads();
+  const int k_lo = lb_range[0], k_hi = lb_range[1];
+  const double floor_lin32 = exp10((double)floor_db * 0.05);
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int k = q + TL4 * i;
+    const bool need_a = k >= k_lo && k < k_hi, need_b = (M4 - k) >= k_lo && (M4 - k) < k_hi;
+    if (!need_a && !need_b) continue;
     const cdd e = {0.5 * (zkr[i] + zpr[i]), 0.5 * (zki[i] - zpi[i])};
     const cdd d = {0.5 * (zkr[i] - zpr[i]), 0.5 * (zki[i] + zpi[i])};
     const cdd o = {d.im, -d.re};
     const cdd wk = ira::cmul(wlane, tw[TL4 * i]);
     const cdd pp = ira::cmul(wk, o);
-    exd[k] = exp10((double)db_of4(e.re + pp.re, e.im + pp.im, floor_pow, floor_db, ltab) * 0.05);
-    exd[M4 - k] = exp10((double)db_of4(e.re - pp.re, e.im - pp.im, floor_pow, floor_db, ltab) * 0.05);
+    if (need_a) exd[k] = lin_of4(e.re + pp.re, e.im + pp.im, floor_pow, floor_db, floor_lin32, ltab);
+    if (need_b) exd[M4 - k] = lin_of4(e.re - pp.re, e.im - pp.im, floor_pow, floor_db, floor_lin32, ltab);
   }
-  if (q == 0) exd[M4 / 2] = exp10((double)db_of4(midr, midi, floor_pow, floor_db, ltab) * 0.05);
+  if (q == 0 && M4 / 2 >= k_lo && M4 / 2 < k_hi) exd[M4 / 2] = lin_of4(midr, midi, floor_pow, floor_db, floor_lin32, ltab);
   __syncthreads();
   float* co = out + out_off[seg];
   for (int b = q; b < lb_nbins; b += TL4) {

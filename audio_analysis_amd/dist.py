@@ -89,6 +89,39 @@ def _gather_metrics(local: np.ndarray, device=None) -> Optional[np.ndarray]:
     return np.concatenate([r[:c].cpu().numpy() for r, c in zip(recv, all_counts)], axis=0)
 
 
+def any_rank_true(flag: bool) -> bool:
+    """Logical OR of a per-rank flag over all ranks (also the barrier of the bundle runner: every rank reaches it, the
+    failing ones included).  Single process: the flag itself."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return bool(flag)
+    on_gpu = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(int(t.item()))
+
+
+def balanced_assignment(sizes, world: int):
+    """
+    Ragged bundles: sort the files by size, largest first, and deal them round-robin, so that
+    every rank gets the same number of files (+-1) and nearly the same number of samples.  Returns one ascending index
+    array per rank (files keep their bundle order inside a rank); deterministic (stable sort), a partition of
+    range(len(sizes)).  Equal sizes degenerate to an interleaved deal; callers keep shard_files' contiguous blocks then.
+    """
+    sizes = np.asarray(sizes, dtype=np.int64)
+    order = np.argsort(-sizes, kind="stable")
+    return [np.sort(order[r::world]) for r in range(int(world))]
+
+
+def restore_order(assignment) -> np.ndarray:
+    """Row permutation that puts records gathered in rank order (assignment[0] rows, then assignment[1] ...) back into
+    file order: gathered[restore_order(assignment)] is in bundle order."""
+    flat = np.concatenate([np.asarray(a, dtype=np.int64) for a in assignment]) if len(assignment) else np.zeros(0, np.int64)
+    return np.argsort(flat, kind="stable")
+
+
 def barrier() -> None:
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

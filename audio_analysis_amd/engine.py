@@ -279,8 +279,9 @@ class Engine:
         with t.cuda.stream(side):
             pk = self.empty(b.count, t.int64)
             pa = self.empty(b.count, t.float32)
-            check(self.lib.ira_peak_index(_ptr(b.x), _ptr(b.off_dev), _ptr(b.len_dev), b.count, _ptr(pk), _ptr(pa),
-                                          self.stream), "ira_peak_index")
+            check(self.lib.ira_peak_index(_ptr(b.x), _ptr(b.off_dev), _ptr(b.len_dev), b.count,
+                                          int(b.length.max()) if b.count else 0, _ptr(pk), _ptr(pa), self.stream),
+                  "ira_peak_index")
             hk = t.empty(pk.shape, dtype=pk.dtype, pin_memory=True)
             ha = t.empty(pa.shape, dtype=pa.dtype, pin_memory=True)
             hk.copy_(pk, non_blocking=True)
@@ -302,8 +303,9 @@ class Engine:
             t = self.torch
             pk = self.empty(b.count, t.int64)
             pa = self.empty(b.count, t.float32)
-            check(self.lib.ira_peak_index(_ptr(b.x), _ptr(b.off_dev), _ptr(b.len_dev), b.count, _ptr(pk), _ptr(pa),
-                                          self.stream), "ira_peak_index")
+            check(self.lib.ira_peak_index(_ptr(b.x), _ptr(b.off_dev), _ptr(b.len_dev), b.count,
+                                          int(b.length.max()) if b.count else 0, _ptr(pk), _ptr(pa), self.stream),
+                  "ira_peak_index")
             b.peak = pk.cpu().numpy()[: b.count].copy()
             b.peak_abs = pa.cpu().numpy()[: b.count].copy()
         return b.peak
@@ -331,6 +333,36 @@ class Engine:
         if want_f64:
             return out, edc_off, out64
         return out, edc_off
+
+    # ------------------------------------------------------------------ a3-a6 fused
+    def edc_fits(self, x_dev, seg_off: np.ndarray, seg_len: np.ndarray, eps: float, floor_db: float,
+                 t_mul: float, t_div: float, ranges: Sequence[Tuple[float, float]], min_points: int,
+                 cross: Sequence[float] = (), want_edc: bool = False):
+        """Schroeder EDC crossings + decay-line fits straight from the samples (ira_edc_fits).
+        Returns (fits (n, nranges, 8) f64 device | None, cross (n, ncross) f64 device | None, edc f32 device | None,
+        edc_off host int64): the EDC curve is only written when want_edc."""
+        t = self.torch
+        n = int(seg_off.size)
+        seg_len = np.ascontiguousarray(seg_len, dtype=np.int64)
+        if np.any(seg_len > 511 * 4 * EDC_TILE):
+            raise ValueError("segment too long for the EDC kernel (> 8.3 M samples)")
+        nr, nc = len(ranges), len(cross)
+        edc_off = np.zeros(n, dtype=np.int64)
+        if n > 1:
+            edc_off[1:] = np.cumsum(seg_len[:-1])
+        fit = self.empty(n * max(nr, 1) * FIT_DOUBLES, t.float64)
+        cr = self.empty(n * max(nc, 1), t.float64)
+        out = self.empty(int(seg_len.sum()), t.float32) if want_edc else None
+        scratch = self.empty(n * EDC_SCRATCH_DOUBLES, t.float64)
+        flat = [v for r in ranges for v in r]
+        d_off, d_len = self.to_dev(np.ascontiguousarray(seg_off, np.int64)), self.to_dev(seg_len)
+        d_eoff = self.to_dev(edc_off) if want_edc else None
+        check(self.lib.ira_edc_fits(_ptr(x_dev), _ptr(d_off), _ptr(d_len), n, int(seg_len.max()) if n else 0,
+                                    float(eps), float(floor_db), float(t_mul), float(t_div), _lib.dbl_array(flat), nr,
+                                    int(min_points), _lib.dbl_array(list(cross)), nc, _ptr(fit), _ptr(cr), _ptr(out),
+                                    _ptr(d_eoff), _ptr(scratch), self.stream), "ira_edc_fits")
+        return (fit[: n * nr * FIT_DOUBLES].view(n, nr, FIT_DOUBLES) if nr else None,
+                cr[: n * nc].view(n, nc) if nc else None, out, edc_off)
 
     # ------------------------------------------------------------------ a4/a5/a16
     def curve_fits(self, y_dev, off: np.ndarray, lens: np.ndarray, t_mul: float, t_div: float,
@@ -978,6 +1010,6 @@ class Engine:
         pk = self.empty(n, t.int64)
         pa = self.empty(n, t.float32)
         d_o, d_l = self.to_dev(np.ascontiguousarray(off, np.int64)), self.to_dev(np.ascontiguousarray(lens, np.int64))
-        check(self.lib.ira_peak_index(_ptr(x_dev), _ptr(d_o), _ptr(d_l), n, _ptr(pk), _ptr(pa), self.stream),
-              "ira_peak_index")
+        check(self.lib.ira_peak_index(_ptr(x_dev), _ptr(d_o), _ptr(d_l), n, int(np.max(lens)) if n else 0, _ptr(pk),
+                                      _ptr(pa), self.stream), "ira_peak_index")
         return pa.cpu().numpy()[:n].astype(np.float64)

@@ -1,0 +1,126 @@
+"""
+Host -> device feed for batched runs: channel batches that live in PINNED host memory are uploaded on a dedicated
+copy stream into a small ring of device buffers, one batch ahead of the step that analyses them, so that the PCIe
+transfer of batch k+1 runs under the kernels of batch k (SURVEY.md section 8d puts the host-to-device copy inside the
+unit of work: the reference re-loads the file in every report block, report.py:222-398 -> io.py:181-221).
+
+Two wire formats:
+  float32  4 bytes per sample, copied straight into the batch buffer;
+  int16    2 bytes per sample (what a PCM16 tap holds, recorder.hpp:49-53), converted on the device by
+           ira_pcm16_to_channels (x/32768 clipped: io.py:46-64) on the copy stream, behind the upload.
+
+A ChannelBatch handed out by push() carries the event recorded behind its upload (+ conversion): the peak pick and
+every report lane wait for THAT event only (pipeline.FullReport.submit), never for the copy stream as a whole.
+
+Ring discipline (host-ordered, no device-side fences needed): with `depth` device buffers the caller may have at most
+depth-1 batches pushed and not yet finished -- push() of batch k+depth-1 ... reuses the buffer of batch k-1, whose step
+the caller has already finished (FullReport.finish waits for every lane of that step).  run_pipelined() below keeps to
+that: push(k+1), submit(k), finish(k-1).
+"""
+from __future__ import annotations
+
+from typing import Callable, Iterable, Iterator, Optional, Sequence, Tuple
+
+import numpy as np
+
+from ._lib import check
+from .engine import ChannelBatch, Engine
+
+
+class HostBatch:
+    """One batch of equal- or ragged-length mono channels in pinned host memory (flat, channel after channel)."""
+
+    def __init__(self, eng: Engine, channels: Sequence[np.ndarray] | np.ndarray, pcm16: bool = False):
+        t = eng.torch
+        if isinstance(channels, np.ndarray) and channels.ndim == 2:
+            lens = np.full(channels.shape[0], channels.shape[1], dtype=np.int64)
+            flat = channels.reshape(-1)
+        else:
+            lens = np.array([int(c.size) for c in channels], dtype=np.int64)
+            flat = np.concatenate([np.asarray(c).reshape(-1) for c in channels]) if len(lens) else np.zeros(0, np.float32)
+        self.length = lens
+        self.off = np.zeros(lens.size, dtype=np.int64)
+        if lens.size > 1:
+            self.off[1:] = np.cumsum(lens[:-1])
+        self.total = int(lens.sum())
+        self.pcm16 = bool(pcm16)
+        if self.pcm16:
+            if flat.dtype != np.int16:
+                raise ValueError("pcm16 host batches hold int16 samples")
+            self.pinned = t.empty(max(self.total, 1), dtype=t.int16, pin_memory=True)
+        else:
+            flat = flat.astype(np.float32, copy=False)
+            self.pinned = t.empty(max(self.total, 1), dtype=t.float32, pin_memory=True)
+        self.pinned.numpy()[: self.total] = flat
+
+    @property
+    def nbytes(self) -> int:
+        return self.total * (2 if self.pcm16 else 4)
+
+
+class DeviceFeed:
+    def __init__(self, eng: Engine, max_samples: int, depth: int = 4):
+        t = eng.torch
+        self.eng = eng
+        self.depth = int(depth)
+        self.copy_stream = t.cuda.Stream(device=eng.device)
+        self._x = [eng.empty(max_samples, t.float32) for _ in range(self.depth)]
+        self._pcm = None
+        self._max = int(max_samples)
+        self._k = 0
+
+    def push(self, hb: HostBatch) -> ChannelBatch:
+        """Enqueue the upload (and int16 conversion) of a host batch on the copy stream; returns at once."""
+        eng, t = self.eng, self.eng.torch
+        if hb.total > self._max:
+            raise ValueError("host batch larger than the feed's device buffers")
+        slot = self._k % self.depth
+        self._k += 1
+        x = self._x[slot]
+        with t.cuda.stream(self.copy_stream):
+            if hb.pcm16:
+                if self._pcm is None:
+                    self._pcm = [eng.empty(self._max, t.int16) for _ in range(self.depth)]
+                pcm = self._pcm[slot]
+                pcm[: hb.total].copy_(hb.pinned[: hb.total], non_blocking=True)
+                # mono channels laid end to end convert like ONE mono file of `total` frames
+                check(eng.lib.ira_pcm16_to_channels(int(pcm.data_ptr()), int(hb.total), 1, 0, int(x.data_ptr()),
+                                                    eng.stream), "ira_pcm16_to_channels")
+            else:
+                x[: hb.total].copy_(hb.pinned[: hb.total], non_blocking=True)
+            batch = eng.wrap(x, hb.off, hb.length)          # offsets/lengths + the ready event, all on the copy stream
+        return batch
+
+
+def run_pipelined(report, feed: DeviceFeed, host_batches: Iterable[HostBatch],
+                  on_records: Optional[Callable[[np.ndarray], None]] = None) -> int:
+    """
+    Software pipeline over batches: upload k+1 | kernels of k | read-back of k-1.  Every batch that enters is
+    uploaded, analysed (FullReport.submit) and finished (records handed to on_records) before this returns.
+    Returns the number of batches processed.
+    """
+    it: Iterator[HostBatch] = iter(host_batches)
+    count = 0
+    pending = None
+    try:
+        nxt = feed.push(next(it))
+    except StopIteration:
+        return 0
+    while nxt is not None:
+        cur = nxt
+        try:
+            nxt = feed.push(next(it))                      # batch k+1 starts crossing PCIe now
+        except StopIteration:
+            nxt = None
+        handle = report.submit(cur)                        # waits for batch k's upload + peak pick only
+        if pending is not None:
+            rec = report.finish(pending)
+            if on_records is not None:
+                on_records(rec)
+        pending = handle
+        count += 1
+    if pending is not None:
+        rec = report.finish(pending)
+        if on_records is not None:
+            on_records(rec)
+    return count

@@ -31,6 +31,22 @@ from ._lib import check
 from .engine import ChannelBatch, Engine
 
 IRA_E_UNSUPPORTED = -3
+IRA_E_IO = -4
+IRA_E_FORMAT = -5
+
+
+def _raise_like_scipy(rc: int, path: Path) -> None:
+    """Errors of the reference's reader for the same files (scipy.io.wavfile.read behind analyse/io.py:200): a missing
+    or unreadable file is an OSError (FileNotFoundError when it does not exist), a file that is not RIFF/WAVE a
+    ValueError.  bundle.run_bundle_report's abort semantics (reference bundle.py:56-67) depend on the types."""
+    import errno
+    import os
+    if rc == IRA_E_IO:
+        if not path.exists():
+            raise FileNotFoundError(errno.ENOENT, os.strerror(errno.ENOENT), str(path))
+        raise OSError(errno.EIO, "could not read WAV file (truncated or unreadable)", str(path))
+    if rc == IRA_E_FORMAT:
+        raise ValueError(f"File format of {path} not understood. Only 'RIFF' / 'WAVE' files are supported.")
 
 
 @dataclass(frozen=True)
@@ -52,6 +68,7 @@ def probe_tap(path: str | Path) -> TapInfo:
     rc = lib.ira_wav_probe(str(p).encode(), C.addressof(rate), C.addressof(ch), C.addressof(frames), C.addressof(off))
     if rc == IRA_E_UNSUPPORTED:
         return TapInfo(p, int(rate.value), int(ch.value), int(frames.value), int(off.value), False)
+    _raise_like_scipy(rc, p)
     check(rc, f"ira_wav_probe({p})")
     return TapInfo(p, int(rate.value), int(ch.value), int(frames.value), int(off.value), True)
 
@@ -65,8 +82,9 @@ def read_tap_pcm16(info: TapInfo, dst: Optional[np.ndarray] = None) -> np.ndarra
         dst = np.empty((info.frames, info.channels), dtype=np.int16)
     if dst.dtype != np.int16 or dst.size != info.frames * info.channels or not dst.flags.c_contiguous:
         raise ValueError("dst must be a C-contiguous int16 array of frames*channels values")
-    check(lib.ira_wav_read_pcm16(str(info.path).encode(), info.data_offset, info.frames, info.channels,
-                                 dst.ctypes.data), f"ira_wav_read_pcm16({info.path})")
+    rc = lib.ira_wav_read_pcm16(str(info.path).encode(), info.data_offset, info.frames, info.channels, dst.ctypes.data)
+    _raise_like_scipy(rc, info.path)
+    check(rc, f"ira_wav_read_pcm16({info.path})")
     return dst
 
 

@@ -29,6 +29,8 @@ extern "C" {
 #define IRA_E_NULL (-1)       /* a required pointer was NULL */
 #define IRA_E_SIZE (-2)       /* a size/shape argument is out of the supported range */
 #define IRA_E_UNSUPPORTED (-3)
+#define IRA_E_IO (-4)         /* a file could not be opened or read (host-side ingest entry points only) */
+#define IRA_E_FORMAT (-5)     /* a file is not RIFF/WAVE (host-side ingest entry points only) */
 #define IRA_E_HIP_BASE (-1000)
 
 #define IRA_ABI_VERSION 1
@@ -40,9 +42,10 @@ const char* ira_error_string(int32_t code);
  * peak_dev[s] = argmax_n |x[off[s]+n]|, n < len[s]; the FIRST maximum wins (bit-exact integer).
  * Replaces np.argmax(np.abs(x)) at reference analyse/decay.py:136, spectrogram.py:181,
  * waterfall.py:359, modalcloud.py:299, frequency_response.py:186, filterplot.py:125,
- * zplane.py:197, rt60bands.py:335.  Also returns the peak magnitude (zplane.py:211). */
+ * zplane.py:197, rt60bands.py:335.  Also returns the peak magnitude (zplane.py:211).
+ * max_len = longest segment (sizes the grid; every sample of every segment is visited; < 2^32); nseg <= 65535. */
 int32_t ira_peak_index(const float* x_dev, const int64_t* off_dev, const int64_t* len_dev,
-                       int32_t nseg, int64_t* peak_dev, float* peak_abs_dev, void* stream);
+                       int32_t nseg, int64_t max_len, int64_t* peak_dev, float* peak_abs_dev, void* stream);
 
 /* ---- a3: Schroeder energy-decay curve ----------------------------------------------------------
  * For each segment: e = x^2 (f64) -> reverse cumulative sum -> max(.,eps) -> /edc[0] -> 10 log10
@@ -85,6 +88,23 @@ int32_t ira_curve_fits(const float* y_dev, const int64_t* off_dev, const int64_t
                        int32_t ncross, int32_t rel_to_peak, double floor_db,
                        double min_peak_above_floor, double* fit_out_dev, double* cross_out_dev,
                        void* stream);
+
+/* ---- a3-a6 fused: Schroeder EDC -> crossings -> decay-line fits, straight from the samples --------------------------
+ * The same results as ira_edc_db followed by ira_curve_fits (analytic time axis t[i] = float32(i)*t_mul/t_div, no
+ * rel_to_peak), without reading an EDC array: per segment the chunk sums locate each target level, only the
+ * chunks around the crossings and between them are re-scanned (identical float32 dB values, same code as the emit
+ * pass), and the regression is one sweep of shifted float64 moments.  Replaces, for one segment, the call chain
+ * compute_schroeder_edc_db -> _interpolated_crossing_time_seconds -> fit_decay_slope_over_db_range of
+ * analyse_decay_for_channel (reference analyse/decay.py:268-329) and of every band of
+ * _compute_band_metrics_from_samples (analyse/rt60bands.py:272-321), whose EDC curve is never a result.
+ * edc_db_dev (optional, may be NULL): also write the float32 dB curve at edc_off_dev[s] (the decay block returns it).
+ * fit_out_dev / cross_out_dev: records exactly as ira_curve_fits writes them.  ranges_hi_lo / cross_targets: HOST arrays.
+ * scratch_dev: nseg * IRA_EDC_SCRATCH_DOUBLES doubles.  max_len as for ira_edc_db. */
+int32_t ira_edc_fits(const float* x_dev, const int64_t* off_dev, const int64_t* len_dev, int32_t nseg,
+                     int64_t max_len, double eps, double floor_db, float t_mul, float t_div,
+                     const double* ranges_hi_lo, int32_t nranges, int32_t min_points,
+                     const double* cross_targets, int32_t ncross, double* fit_out_dev, double* cross_out_dev,
+                     float* edc_db_dev, const int64_t* edc_off_dev, double* scratch_dev, void* stream);
 
 /* ---- a11: STFT magnitude in dB -------------------------------------------------------------------
  * Valid framing (no padding), frame f of segment s starts at off[s] + f*hop, nframes[s] frames.
@@ -342,7 +362,8 @@ int32_t ira_diffusion_stereo(const float* x_dev, const int64_t* loff_dev, const 
  * include/analysis/recorder.hpp:55-90) ----------------------------------------------------------------------------
  * ira_wav_probe: HOST call; walks the RIFF chunks of `path` and reports rate / channels / frames and the byte offset
  *   of the sample data.  IRA_OK for mono/stereo PCM16, IRA_E_UNSUPPORTED for any other valid WAV encoding (use the
- *   Python reader), IRA_E_SIZE if the file cannot be read as RIFF/WAVE.
+ *   Python reader), IRA_E_IO if the file cannot be opened or is shorter than
+ *   its header says, IRA_E_FORMAT if it is not RIFF/WAVE (scipy.io.wavfile.read raises FileNotFoundError / ValueError there).
  * ira_wav_read_pcm16: HOST call; reads frames*channels interleaved int16 into dst_host (ideally pinned memory).
  * ira_pcm16_to_channels: DEVICE; interleaved int16 -> planar float32 channels (out[c*frames + i]) with the
  *   reference's conversion x/32768 clipped to [-1, 1] (analyse/io.py:46-64, :98-113), or with mono_downmix (stereo

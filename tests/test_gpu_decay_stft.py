@@ -173,3 +173,58 @@ def test_frame_major_stft_is_the_exact_transpose(golden):
     # unsupported configuration falls back to the reference layout
     st2 = sp.SpectrogramAnalysisSettings(n_fft=2048, hop_length=256)
     assert not sp.spectrogram_device(eng, b, SR, st2, frame_major=True)["frame_major"]
+
+
+def test_fused_edc_fits_match_the_curve_path():
+    """ira_edc_fits (crossings + fits straight from the samples, no EDC read back) against ira_edc_db + ira_curve_fits on the
+    SAME device: crossing times bit-identical (same float32 curve, same first index), regression fields to 1e-9 (one
+    sweep of shifted moments vs three centred passes), emitted curve bit-identical.  Ragged lengths around the
+    4096-sample tile / 16384-sample chunk edges, degenerate segments included."""
+    from audio_analysis_amd.engine import get_engine
+    from audio_analysis_amd.synth import synth_ir
+    eng = get_engine()
+    rng = np.random.default_rng(11)
+    chans = []
+    for i, n in enumerate([4, 9, 100, 4095, 4096, 4097, 16383, 16384, 16385, 16384 * 3 + 5, 96000, 250001]):
+        x = synth_ir(40 + i, 0, max(n, 300), rt60_seconds=0.02 + 0.25 * rng.random(), pre_delay=0)[:n]
+        chans.append(x.astype(np.float32))
+    chans.append(np.zeros(5000, np.float32))                                   # digital silence
+    chans.append(np.full(20000, 0.25, np.float32))                             # DC
+    last = np.zeros(30000, np.float32); last[-1] = 1.0                         # all the energy in the last sample
+    chans.append(last)
+    slow = synth_ir(77, 0, 480000, rt60_seconds=8.0, pre_delay=0)             # -35 dB is never reached in 10 s
+    chans.append(slow)
+    nan = synth_ir(78, 0, 50000, rt60_seconds=0.2, pre_delay=0).copy(); nan[1234] = np.nan
+    chans.append(nan)
+    b = eng.upload(chans)
+    ranges = [(0.0, -10.0), (-5.0, -25.0), (-5.0, -35.0)]
+    cross = (0.0, -10.0)
+    edc, edc_off = eng.edc_db(b.x, b.off, b.length, 1e-20, -120.0)
+    f_ref, c_ref = eng.curve_fits(edc, edc_off, b.length, 1.0, 48000.0, ranges, 8, cross=cross)
+    f_new, c_new, edc2, edc_off2 = eng.edc_fits(b.x, b.off, b.length, 1e-20, -120.0, 1.0, 48000.0, ranges, 8,
+                                                cross=cross, want_edc=True)
+    f_nc, c_nc, none, _ = eng.edc_fits(b.x, b.off, b.length, 1e-20, -120.0, 1.0, 48000.0, ranges, 8, cross=cross)
+    assert none is None
+    e1, e2 = edc.cpu().numpy(), edc2.cpu().numpy()
+    tot = int(b.length.sum())
+    np.testing.assert_array_equal(e1[:tot].view(np.uint32), e2[:tot].view(np.uint32))
+    assert np.array_equal(edc_off, edc_off2)
+    fr, fn, fq = f_ref.cpu().numpy(), f_new.cpu().numpy(), f_nc.cpu().numpy()
+    cr, cn, cq = c_ref.cpu().numpy(), c_new.cpu().numpy(), c_nc.cpu().numpy()
+    np.testing.assert_array_equal(fn.view(np.uint64), fq.view(np.uint64))      # writing the curve changes nothing
+    np.testing.assert_array_equal(cn.view(np.uint64), cq.view(np.uint64))
+    np.testing.assert_array_equal(np.isnan(cr), np.isnan(cn))
+    np.testing.assert_array_equal(cr[~np.isnan(cr)], cn[~np.isnan(cn)])        # crossing times: bit-identical
+    assert fr.shape == fn.shape == (len(chans), 3, 8)
+    for i in range(len(chans)):
+        for j in range(3):
+            a, g = fn[i, j], fr[i, j]
+            assert a[0] == g[0], (i, j, a, g)
+            for k in (1, 2):                                                   # start / end times
+                assert (np.isnan(a[k]) and np.isnan(g[k])) or a[k] == g[k], (i, j, k, a, g)
+            assert (np.isnan(a[7]) and np.isnan(g[7])) or a[7] == g[7], (i, j, a, g)   # points in the mask
+            if g[0] == 1.0:
+                assert _rel(a[3], g[3]) < 1e-9 and _rel(a[6], g[6]) < 1e-9, (i, j, a, g)
+                assert abs(a[4] - g[4]) < 1e-9 * max(1.0, abs(g[4])) and abs(a[5] - g[5]) < 1e-10, (i, j, a, g)
+            elif not np.isnan(g[3]):
+                assert _rel(a[3], g[3]) < 1e-9 or (a[3] == 0.0 and g[3] == 0.0), (i, j, a, g)

@@ -46,7 +46,7 @@ def test_argument_validation_without_gpu():
     """Entry points reject bad arguments before touching the device (no compute calls here)."""
     from audio_analysis_amd import _lib
     lib = _lib.load()
-    assert lib.ira_peak_index(0, 0, 0, 1, 0, 0, 0) == -1                      # IRA_E_NULL
+    assert lib.ira_peak_index(0, 0, 0, 1, 16, 0, 0, 0) == -1                      # IRA_E_NULL
     assert lib.ira_stft_mag_db(1, 1, 1, 1, 1, 1000, 512, 1, 1, 32, -120.0, 1, 1, 0, 0, 0) == -2   # n_fft not a power of 2
     assert lib.ira_stft_mag_db(1, 1, 1, 1, 1, 4096, 512, 1, 1, 16, -120.0, 1, 1, 0, 0, 0) == -3  # precision
     assert lib.ira_poly_roots(1, 1, 5000, 1e-14, 1, 1, 0) == -2
@@ -202,6 +202,50 @@ def test_shard_files_partitions_everything():
             assert max(hi - lo for lo, hi in blocks) <= -(-f // w) if f else True
 
 
+def test_balanced_assignment_for_ragged_bundles():
+    """ragged bundles are sorted by size and dealt round-robin; gathered records go back to file order."""
+    from audio_analysis_amd.dist import balanced_assignment, restore_order
+    rng = np.random.default_rng(5)
+    for f in (0, 1, 5, 64, 1001):
+        sizes = rng.integers(1000, 2_000_000, size=f)
+        for w in (1, 2, 3, 8):
+            parts = balanced_assignment(sizes, w)
+            assert len(parts) == w
+            flat = np.concatenate(parts) if f else np.zeros(0, np.int64)
+            assert sorted(flat.tolist()) == list(range(f))                       # a partition
+            assert all(np.all(np.diff(p) > 0) for p in parts if p.size > 1)       # bundle order inside a rank
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+            if f >= 8 * w:
+                loads = np.array([sizes[p].sum() for p in parts], dtype=np.float64)
+                contiguous = np.array([sizes[lo:hi].sum() for lo, hi in
+                                       [(r * -(-f // w), min(f, (r + 1) * -(-f // w))) for r in range(w)]], dtype=np.float64)
+                assert loads.max() / loads.mean() <= max(1.05, contiguous.max() / contiguous.mean())
+            # gathered in rank order -> back to file order
+            gathered = np.concatenate([np.asarray(p) for p in parts]) if f else np.zeros(0, np.int64)
+            assert np.array_equal(gathered[restore_order(parts)], np.arange(f))
+            assert all(np.array_equal(a, b) for a, b in zip(parts, balanced_assignment(sizes, w)))   # deterministic
+
+
+def test_ingest_errors_have_the_reference_reader_types(tmp_path):
+    """A missing tap is FileNotFoundError, a non-RIFF file ValueError, a truncated one OSError -- what scipy's reader
+    raises behind the reference's load_wav_file (io.py:200); the bundle runner's abort semantics key on them."""
+    from audio_analysis_amd import ingest
+    with pytest.raises(FileNotFoundError):
+        ingest.probe_tap(tmp_path / "nope.wav")
+    bad = tmp_path / "bad.wav"
+    bad.write_bytes(b"this is not a wave file at all, not even close")
+    with pytest.raises(ValueError):
+        ingest.probe_tap(bad)
+    import struct
+    hdr = b"RIFF" + struct.pack("<I", 36 + 4000) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 2, 48000, 192000, 4, 16)
+    short = tmp_path / "short.wav"
+    short.write_bytes(hdr + b"data" + struct.pack("<I", 4000) + b"\0" * 100)      # payload shorter than the header says
+    info = ingest.probe_tap(short)
+    assert info.native and info.frames == 1000
+    with pytest.raises(OSError):
+        ingest.read_tap_pcm16(info)
+
+
 _WORKER = r"""
 import os, sys
 sys.path.insert(0, os.environ["REPO"])
@@ -213,6 +257,7 @@ full[2, 5] = np.nan
 lo, hi = D.shard_files(11, rank, world)
 got = D.gather_metrics(full[lo:hi])
 t = D.max_over_ranks(1.0 + rank)
+assert D.any_rank_true(rank == 1) is True and D.any_rank_true(False) is False
 D.barrier()
 if rank == 0:
     assert got.shape == full.shape and got.tobytes() == full.tobytes(), "gather is not byte-identical"
