@@ -56,49 +56,60 @@ __global__ void peak_decode_kernel(unsigned long long* __restrict__ keys, float*
 }
 
 // ------------------------------------------------------------------------------------------------
-// a3: Schroeder EDC.  1024-thread workgroups walk 4096-sample tiles from the END of the segment towards its
-// start (the direction numpy.cumsum(e[::-1]) accumulates in) with a wave-shuffle suffix scan per tile; a first
-// pass collects per-chunk sums, a second re-scans with the carries, now knowing edc[0], and emits
-// 10*log10(max(edc,eps)/edc[0]) floored, as float32.  Both passes run the SAME scan code.
+// a3: Schroeder EDC.  A segment is cut into 4096-sample tiles counted from its END (the direction
+// numpy.cumsum(e[::-1]) accumulates in); one 256-thread workgroup scans one tile: every thread owns 16 consecutive
+// samples (four 16-byte loads issued together: one memory round trip per tile), forms their suffix sums serially,
+// the wave combines thread totals with shuffles and the four waves meet through LDS -- one barrier per tile.
+//   edc_sums_kernel   (tiles x segments)   tile totals
+//   edc_carry_kernel  (1 wave / segment)   carry[j] = energy behind tile j, and the normaliser edc[0]
+//   edc_emit_kernel   (tiles x segments)   re-scan, add the carry, 10*log10(max(edc,eps)/edc[0]) floored -> float32
+// Every kernel (the fused fit kernel below included) runs the SAME scan code and forms a value as
+// (suffix sum inside the tile) + carry[j], so the normaliser is bit-identical to the value the emit pass produces at
+// index 0 (=> edc_db[0] is exactly 0 dB, which the 0 dB crossing needs) and the fit kernel sees the emitted curve.
 // ------------------------------------------------------------------------------------------------
-constexpr int EDC_THREADS = 1024;
-constexpr int EDC_PER_THREAD = 4;
+constexpr int EDC_THREADS = 256;
+constexpr int EDC_PER_THREAD = 16;
 constexpr int EDC_TILE = EDC_THREADS * EDC_PER_THREAD;
+constexpr int EDC_WAVES = EDC_THREADS / IRA_WAVE;
+// scratch per segment: tot[0 .. T) | carry[0 .. T) | ... | norm (last double); T <= EDC_MAX_TILES
+constexpr int EDC_MAX_TILES = IRA_EDC_SCRATCH_DOUBLES / 2 - 1;
+static_assert(EDC_TILE == 4096, "the host sizes its checks with 4096-sample tiles");
 
 struct EdcShared {
-  double wave_tot[EDC_THREADS / IRA_WAVE];
-  double total;
+  double wave_tot[2][EDC_WAVES];     // double-buffered by tile parity: one barrier per tile is enough
 };
 
 typedef float edc_f4 __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access, 4-byte alignment
 
-// Suffix sums of one tile.  local index i in [0, tile_len); thread t owns i = 4t..4t+3 and reads them with one
-// 16-byte load (consecutive threads = consecutive 16-byte pieces: fully coalesced, no LDS staging).
-// On return s[0..3] hold the inclusive suffix sums (within the tile) at the thread's four positions and the
-// function result is the suffix sum at local index 0 (thread 0's s[0], broadcast), i.e. the tile total in
-// exactly the association order the emit pass uses.  Two barriers per tile.
-__device__ __forceinline__ double tile_suffix_scan(const float* __restrict__ src, int tile_len, EdcShared& sh,
-                                                   double s[EDC_PER_THREAD]) {
-  const int t = threadIdx.x;
-  const int i0 = EDC_PER_THREAD * t;
-  float x[EDC_PER_THREAD];
+// The thread's 16 samples of a tile of tile_len valid samples (zeros beyond): local indices 16t .. 16t+15.
+__device__ __forceinline__ void tile_load(const float* __restrict__ src, int tile_len, float x[EDC_PER_THREAD]) {
+  const int i0 = EDC_PER_THREAD * threadIdx.x;
   if (i0 + EDC_PER_THREAD <= tile_len) {
-    const edc_f4 v = *reinterpret_cast<const edc_f4*>(src + i0);
-    x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+#pragma unroll
+    for (int j = 0; j < EDC_PER_THREAD / 4; ++j) {
+      const edc_f4 v = *reinterpret_cast<const edc_f4*>(src + i0 + 4 * j);
+      x[4 * j] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
+    }
   } else {
 #pragma unroll
     for (int r = 0; r < EDC_PER_THREAD; ++r) x[r] = (i0 + r < tile_len) ? src[i0 + r] : 0.0f;
   }
-  double e[EDC_PER_THREAD];
-#pragma unroll
-  for (int r = 0; r < EDC_PER_THREAD; ++r) {
-    const double v = (double)x[r];
-    e[r] = v * v;
+}
+
+// Inclusive suffix sums (within the tile) of the squared samples at the thread's 16 positions.  parity = tile
+// counter & 1 of the calling loop (selects the LDS buffer).  s[0] of thread 0 is the tile total.
+__device__ __forceinline__ void tile_suffix_scan(const float x[EDC_PER_THREAD], EdcShared& sh, int parity,
+                                                 double s[EDC_PER_THREAD]) {
+  const int t = threadIdx.x;
+  {
+    const double v = (double)x[EDC_PER_THREAD - 1];
+    s[EDC_PER_THREAD - 1] = v * v;
   }
-  s[3] = e[3];
-  s[2] = e[2] + s[3];
-  s[1] = e[1] + s[2];
-  s[0] = e[0] + s[1];
+#pragma unroll
+  for (int r = EDC_PER_THREAD - 2; r >= 0; --r) {
+    const double v = (double)x[r];
+    s[r] = v * v + s[r + 1];
+  }
   // inclusive suffix scan of thread totals across the wave (towards higher lanes)
   const int lane = t & 63, wave = t >> 6;
   double incl = s[0];
@@ -109,84 +120,76 @@ __device__ __forceinline__ double tile_suffix_scan(const float* __restrict__ src
   }
   double excl = __shfl_down(incl, 1, 64);  // sum over the lanes after this one
   if (lane == 63) excl = 0.0;
-  if (lane == 0) sh.wave_tot[wave] = incl;
+  if (lane == 0) sh.wave_tot[parity][wave] = incl;
   __syncthreads();
   double later_waves = 0.0;
-  for (int w = EDC_THREADS / IRA_WAVE - 1; w > wave; --w) later_waves += sh.wave_tot[w];
+#pragma unroll
+  for (int w = EDC_WAVES - 1; w > 0; --w)
+    if (w > wave) later_waves += sh.wave_tot[parity][w];
   excl += later_waves;
 #pragma unroll
   for (int r = 0; r < EDC_PER_THREAD; ++r) s[r] += excl;
-  if (t == 0) sh.total = s[0];
-  __syncthreads();
-  // No trailing barrier: the next tile writes wave_tot only after every thread has passed the barrier above (its
-  // wave_tot reads precede it), and rewrites total only after its own first barrier (this read precedes that).
-  return sh.total;
 }
-
-// The scan is split over many workgroups so that a small batch still fills the chip:
-//   edc_sums_kernel   (chunks x segments)  per 16384-sample chunk (4 tiles, counted from the END of the segment):
-//                     chunk total, plus the last tile's total and the local carry in front of it
-//   edc_carry_kernel  (1 thread / segment) sequential carries over the chunks and the normaliser edc[0]
-//   edc_emit_kernel   (chunks x segments)  re-scan with the carries and emit the dB curve
-// Every value is formed as  s + (local_run + chunk_carry)  in all three kernels, so the normaliser is bit-identical
-// to the value the emit pass produces at index 0 (=> edc_db[0] is exactly 0 dB, which the 0 dB crossing needs).
-constexpr int EDC_CHUNK_TILES = 4;
-constexpr int EDC_MAX_CHUNKS = IRA_EDC_SCRATCH_DOUBLES / 4 - 1;   // scratch: totals | last-tile totals | local carries | carries(+norm)
 
 __global__ __launch_bounds__(EDC_THREADS) void edc_sums_kernel(
     const float* __restrict__ x, const int64_t* __restrict__ off, const int64_t* __restrict__ len,
     double* __restrict__ scratch) {
   __shared__ EdcShared sh;
-  const int seg = blockIdx.y, chunk = blockIdx.x;
+  const int seg = blockIdx.y;
+  const int64_t j = blockIdx.x;
   const int64_t n = len[seg];
   const int64_t ntiles = (n + EDC_TILE - 1) / EDC_TILE;
-  const int64_t t0 = (int64_t)chunk * EDC_CHUNK_TILES;
-  if (t0 >= ntiles) return;
-  const float* src = x + off[seg];
-  double* sc = scratch + (int64_t)seg * IRA_EDC_SCRATCH_DOUBLES;
-  double run = 0.0, before = 0.0, tot = 0.0;
+  if (j >= ntiles) return;
+  const int64_t hi = n - j * EDC_TILE;
+  const int64_t lo = hi - EDC_TILE > 0 ? hi - EDC_TILE : 0;
+  float xv[EDC_PER_THREAD];
+  tile_load(x + off[seg] + lo, (int)(hi - lo), xv);
   double s[EDC_PER_THREAD];
-  for (int64_t j = t0; j < t0 + EDC_CHUNK_TILES && j < ntiles; ++j) {
-    const int64_t hi = n - j * EDC_TILE;
-    const int64_t lo = hi - EDC_TILE > 0 ? hi - EDC_TILE : 0;
-    before = run;
-    tot = tile_suffix_scan(src + lo, (int)(hi - lo), sh, s);
-    run = tot + run;
-  }
-  if (threadIdx.x == 0) {
-    const int q = IRA_EDC_SCRATCH_DOUBLES / 4;
-    sc[chunk] = run; sc[q + chunk] = tot; sc[2 * q + chunk] = before;
-  }
+  tile_suffix_scan(xv, sh, 0, s);
+  if (threadIdx.x == 0) scratch[(int64_t)seg * IRA_EDC_SCRATCH_DOUBLES + j] = s[0];
 }
 
-__global__ void edc_carry_kernel(const int64_t* __restrict__ len, int nseg, double eps, double* __restrict__ scratch) {
-  const int seg = blockIdx.x * blockDim.x + threadIdx.x;
+// numpy.maximum semantics: a NaN operand gives NaN (fmax would drop it).  A NaN sample makes the reference's whole
+// curve NaN (decay.py:151-166), an infinite one NaN before it and the floor after it.
+__device__ __forceinline__ double np_max(double a, double b) { return (a != a) ? a : fmax(a, b); }
+
+// One wave per segment: exclusive prefix sums of the tile totals (in blocks of 64 with a shuffle scan; any fixed
+// association will do, every later kernel reads THESE carries) and the normaliser edc[0] = tot[T-1] + carry[T-1],
+// which is exactly how the emit pass forms the value at index 0.
+__global__ __launch_bounds__(IRA_WAVE) void edc_carry_kernel(const int64_t* __restrict__ len, int nseg, double eps,
+                                                             double* __restrict__ scratch) {
+  const int seg = blockIdx.x;
   if (seg >= nseg) return;
   const int64_t n = len[seg];
   if (n <= 0) return;
-  const int q = IRA_EDC_SCRATCH_DOUBLES / 4;
+  const int q = IRA_EDC_SCRATCH_DOUBLES / 2;
   double* sc = scratch + (int64_t)seg * IRA_EDC_SCRATCH_DOUBLES;
-  const int64_t ntiles = (n + EDC_TILE - 1) / EDC_TILE;
-  const int nchunks = (int)((ntiles + EDC_CHUNK_TILES - 1) / EDC_CHUNK_TILES);
-  double carry = 0.0;
-  for (int c = 0; c < nchunks; ++c) {
-    sc[3 * q + c] = carry;
-    if (c == nchunks - 1) {
-      // edc[0] exactly as the emit pass forms it: last tile's local-0 value + (local carry + chunk carry)
-      const double v = sc[q + c] + (sc[2 * q + c] + carry);
-      sc[4 * q - 1] = (v != v) ? v : fmax(v, eps);
+  const int ntiles = (int)((n + EDC_TILE - 1) / EDC_TILE);
+  const int lane = threadIdx.x;
+  double base = 0.0;
+  for (int j0 = 0; j0 < ntiles; j0 += IRA_WAVE) {
+    const int j = j0 + lane;
+    const double tot = j < ntiles ? sc[j] : 0.0;
+    double incl = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const double dn = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += dn;
     }
-    carry = sc[c] + carry;
+    double excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 0.0;
+    const double carry = base + excl;
+    if (j < ntiles) {
+      sc[q + j] = carry;
+      if (j == ntiles - 1) sc[IRA_EDC_SCRATCH_DOUBLES - 1] = np_max(tot + carry, eps);
+    }
+    base = base + __shfl(incl, 63, 64);
   }
 }
 
 // dB value of one suffix sum: 10 log10(max(sum, eps) / norm) through the table log2 (ira_log.h): ~30 instructions per
 // sample instead of ~110 for an f64 divide + log10, same value to ~1e-14 dB; sum == norm gives exactly 0 dB.
 // Shared by the emit pass and the fused fit kernel so that both see the same float32 curve bit for bit.
-// numpy.maximum semantics: a NaN operand gives NaN (fmax would drop it).  A NaN sample makes the reference's whole
-// curve NaN (decay.py:151-166), an infinite one NaN before it and the floor after it.
-__device__ __forceinline__ double np_max(double a, double b) { return (a != a) ? a : fmax(a, b); }
-
 __device__ __forceinline__ double edc_db64(double sum, double eps, double norm, double lnorm, bool fast,
                                            const ira::LogTabEntry* ltab) {
   const double v = np_max(sum, eps);
@@ -200,52 +203,46 @@ __global__ __launch_bounds__(EDC_THREADS) void edc_emit_kernel(
     const double* __restrict__ scratch) {
   __shared__ EdcShared sh;
   __shared__ ira::LogTabEntry ltab[ira::LOGTAB_N];
-  const int seg = blockIdx.y, chunk = blockIdx.x;
+  const int seg = blockIdx.y;
+  const int64_t j = blockIdx.x;
   const int64_t n = len[seg];
   const int64_t ntiles = (n + EDC_TILE - 1) / EDC_TILE;
-  const int64_t t0 = (int64_t)chunk * EDC_CHUNK_TILES;
-  if (t0 >= ntiles) return;
+  if (j >= ntiles) return;
+  const int64_t hi = n - j * EDC_TILE;
+  const int64_t lo = hi - EDC_TILE > 0 ? hi - EDC_TILE : 0;
+  const int tl = (int)(hi - lo);
+  float xv[EDC_PER_THREAD];
+  tile_load(x + off[seg] + lo, tl, xv);
   ira::build_log_table(ltab, threadIdx.x);
-  __syncthreads();
-  const float* src = x + off[seg];
-  float* dst = out ? out + out_off[seg] : nullptr;
-  double* dst64 = out64 ? out64 + out_off[seg] : nullptr;
-  const int q = IRA_EDC_SCRATCH_DOUBLES / 4;
   const double* sc = scratch + (int64_t)seg * IRA_EDC_SCRATCH_DOUBLES;
-  const double chunk_carry = sc[3 * q + chunk];
-  const double norm = sc[4 * q - 1];
-  // 10 log10(v / norm) = 10 log10(2) (log2 v - log2 norm) with the table log2 (ira_log.h): ~30 instructions per sample
-  // instead of ~110 for an f64 divide + log10, same value to ~1e-14 dB.  v == norm at index 0 gives exactly 0 dB.
+  const double carry = sc[IRA_EDC_SCRATCH_DOUBLES / 2 + j];
+  const double norm = sc[IRA_EDC_SCRATCH_DOUBLES - 1];
+  double s[EDC_PER_THREAD];
+  tile_suffix_scan(xv, sh, 0, s);                      // its barrier also publishes the log table
   const bool fast = norm > 1e-300 && norm < 1e300;
   const double lnorm = fast ? ira::log2_table(norm, ltab) : 0.0;
-  double run = 0.0;
-  double s[EDC_PER_THREAD];
-  for (int64_t j = t0; j < t0 + EDC_CHUNK_TILES && j < ntiles; ++j) {
-    const int64_t hi = n - j * EDC_TILE;
-    const int64_t lo = hi - EDC_TILE > 0 ? hi - EDC_TILE : 0;
-    const int tl = (int)(hi - lo);
-    const double tot = tile_suffix_scan(src + lo, tl, sh, s);
-    const double c = run + chunk_carry;
-    const int i0 = EDC_PER_THREAD * threadIdx.x;
-    float o4[EDC_PER_THREAD];
+  float* dst = out ? out + out_off[seg] + lo : nullptr;
+  double* dst64 = out64 ? out64 + out_off[seg] + lo : nullptr;
+  const int i0 = EDC_PER_THREAD * threadIdx.x;
+  float o[EDC_PER_THREAD];
 #pragma unroll
-    for (int r = 0; r < EDC_PER_THREAD; ++r) {
-      const int i = i0 + r;
-      const double db = edc_db64(s[r] + c, eps, norm, lnorm, fast, ltab);
-      if (dst64 && i < tl) dst64[lo + i] = db;  // unfloored f64 (host-side optional smoothing, decay.py:161-164)
-      o4[r] = (float)np_max(db, floor_db);
-    }
-    if (dst) {
-      if (i0 + EDC_PER_THREAD <= tl) {
-        const edc_f4 v = {o4[0], o4[1], o4[2], o4[3]};
-        *reinterpret_cast<edc_f4*>(dst + lo + i0) = v;
-      } else {
+  for (int r = 0; r < EDC_PER_THREAD; ++r) {
+    const double db = edc_db64(s[r] + carry, eps, norm, lnorm, fast, ltab);
+    if (dst64 && i0 + r < tl) dst64[i0 + r] = db;      // unfloored f64 (optional dB smoothing, decay.py:161-164)
+    o[r] = (float)np_max(db, floor_db);
+  }
+  if (dst) {
+    if (i0 + EDC_PER_THREAD <= tl) {
 #pragma unroll
-        for (int r = 0; r < EDC_PER_THREAD; ++r)
-          if (i0 + r < tl) dst[lo + i0 + r] = o4[r];
+      for (int jj = 0; jj < EDC_PER_THREAD / 4; ++jj) {
+        const edc_f4 v = {o[4 * jj], o[4 * jj + 1], o[4 * jj + 2], o[4 * jj + 3]};
+        *reinterpret_cast<edc_f4*>(dst + i0 + 4 * jj) = v;
       }
+    } else {
+#pragma unroll
+      for (int r = 0; r < EDC_PER_THREAD; ++r)
+        if (i0 + r < tl) dst[i0 + r] = o[r];
     }
-    run = tot + run;
   }
 }
 
@@ -581,21 +578,19 @@ __global__ void curve_fit_kernel(const float* __restrict__ ybase, const int64_t*
 // ------------------------------------------------------------------------------------------------
 // a3-a6 fused (ira_edc_fits): crossings and decay-line fits straight from the SAMPLES.
 //
-// After edc_sums / edc_carry every 16384-sample chunk of a segment knows the energy behind it (its carry) and its
-// own total, i.e. the interval of EDC values it spans -- and an EDC is monotone.  So the chunk that holds a dB
-// crossing is known WITHOUT the curve, and the regression only needs the curve between the two crossings of a
-// range.  One workgroup per segment:
-//   phase A  for every target level, start at the first chunk (in time) that is not certainly above it and re-scan
-//            chunks (the emit pass's own scan code and dB conversion -> the identical float32 values) until the
-//            first index with edc_db <= target is found; the chunk's dB values sit in LDS, so y[idx-1], y[idx]
-//            for the interpolation come from there;
-//   phase B  re-scan the chunks between the crossings once and accumulate shifted first and second moments of
-//            every range in float64 (one sweep instead of the three passes of curve_fit_kernel).
+// After edc_sums / edc_carry every 4096-sample tile of a segment knows the energy behind it (its carry), i.e. a
+// lower bound of every EDC value inside it -- and an EDC is monotone.  So the tile that holds a dB crossing is
+// known WITHOUT the curve, and the regression only needs the curve between the two crossings of a range.  One
+// 256-thread workgroup per segment (four to five of them share a CU and hide each other's memory round trips):
+//   phase A  the carries are staged in LDS; each target level binary-searches the first tile (in time) that is not
+//            certainly above it; tiles are then re-scanned (the emit pass's own scan code and dB conversion -> the
+//            identical float32 values) until the first index with edc_db <= target is found; the tile's dB values sit
+//            in LDS, so y[idx-1], y[idx] for the interpolation come from there;
+//   phase B  the tiles between the crossings are re-scanned once and shifted first and second moments of every
+//            range accumulated in float64 (one sweep instead of the three passes of curve_fit_kernel).
 // Nothing reads an EDC array: a band EDC that only feeds its fits (rt60bands.py:272-321) is never written, and
 // the decay block's curve is written by the emit pass for the caller but not read back here.
 // ------------------------------------------------------------------------------------------------
-constexpr int EF_CHUNK = EDC_CHUNK_TILES * EDC_TILE;   // 16384 samples = 64 KB of float32 dB values in LDS
-
 struct EdcFitRange {
   double ts, te, tmid, ymid;
   long long a0, a1;
@@ -605,43 +600,35 @@ struct EdcFitRange {
 
 struct EdcFitShared {
   EdcShared scan;
-  EdcFitRange rng[FIT_MAX_RANGES];
-  double part[EDC_THREADS / IRA_WAVE][FIT_MAX_RANGES][6];
   ira::LogTabEntry ltab[ira::LOGTAB_N];
-  float db[EF_CHUNK];
-  unsigned long long found[FIT_MAX_TARGETS];      // local index of the first crossing in the chunk in LDS
+  double carry[EDC_MAX_TILES + 1];
+  float db[EDC_TILE];
+  EdcFitRange rng[FIT_MAX_RANGES];
+  double part[EDC_WAVES][FIT_MAX_RANGES][6];
+  unsigned long long found[FIT_MAX_TARGETS];      // local index of the first crossing in the tile in LDS
   long long idx[FIT_MAX_TARGETS];                 // first index with edc_db <= target; n = never
   float y_at[FIT_MAX_TARGETS], y_prev[FIT_MAX_TARGETS];
   float tgt32[FIT_MAX_TARGETS];
-  int first_chunk[FIT_MAX_TARGETS];               // chunk (counted from the END) where the search starts; -1 = never
+  int first_tile[FIT_MAX_TARGETS];                // tile (counted from the END) where the search starts; -1 = never
 };
 
-// dB curve of chunk c (tiles 4c .. 4c+3 counted from the end of the segment) into sh.db, in time order.
-// Same scan, same association of the carries and same conversion as edc_emit_kernel.
-__device__ __forceinline__ void edc_chunk_to_lds(const float* __restrict__ src, long long n, int c, double chunk_carry,
-                                                 double eps, double floor_db, double norm, double lnorm, bool fast,
-                                                 EdcFitShared& sh, long long& cstart, int& clen) {
-  const long long ntiles = (n + EDC_TILE - 1) / EDC_TILE;
-  const long long cend = n - (long long)c * EF_CHUNK;
-  cstart = cend - EF_CHUNK > 0 ? cend - EF_CHUNK : 0;
-  clen = (int)(cend - cstart);
-  double run = 0.0;
+// dB curve of tile j (counted from the end of the segment) into sh.db, in time order.  Same scan, same carry and same
+// conversion as edc_emit_kernel.  The caller alternates `parity` between consecutive calls.
+__device__ __forceinline__ void edc_tile_to_lds(const float* __restrict__ src, long long n, int j, double eps,
+                                                double floor_db, double norm, double lnorm, bool fast, int parity,
+                                                EdcFitShared& sh, long long& tstart, int& tlen) {
+  const long long hi = n - (long long)j * EDC_TILE;
+  tstart = hi - EDC_TILE > 0 ? hi - EDC_TILE : 0;
+  tlen = (int)(hi - tstart);
+  float xv[EDC_PER_THREAD];
+  tile_load(src + tstart, tlen, xv);
   double s[EDC_PER_THREAD];
-  const long long t0 = (long long)c * EDC_CHUNK_TILES;
-  for (long long j = t0; j < t0 + EDC_CHUNK_TILES && j < ntiles; ++j) {
-    const long long hi = n - j * EDC_TILE;
-    const long long lo = hi - EDC_TILE > 0 ? hi - EDC_TILE : 0;
-    const int tl = (int)(hi - lo);
-    const double tot = tile_suffix_scan(src + lo, tl, sh.scan, s);
-    const double cc = run + chunk_carry;
-    const int i0 = EDC_PER_THREAD * threadIdx.x;
+  tile_suffix_scan(xv, sh.scan, parity, s);
+  const double carry = sh.carry[j];
+  const int i0 = EDC_PER_THREAD * threadIdx.x;
 #pragma unroll
-    for (int r = 0; r < EDC_PER_THREAD; ++r) {
-      const int i = i0 + r;
-      if (i < tl) sh.db[(int)(lo - cstart) + i] = (float)np_max(edc_db64(s[r] + cc, eps, norm, lnorm, fast, sh.ltab), floor_db);
-    }
-    run = tot + run;
-  }
+  for (int r = 0; r < EDC_PER_THREAD; ++r)
+    if (i0 + r < tlen) sh.db[i0 + r] = (float)np_max(edc_db64(s[r] + carry, eps, norm, lnorm, fast, sh.ltab), floor_db);
   __syncthreads();
 }
 
@@ -683,11 +670,10 @@ __global__ __launch_bounds__(EDC_THREADS) void edc_fit_kernel(
   }
   ira::build_log_table(sh.ltab, tid);
   const float* src = x + off[seg];
-  const int q = IRA_EDC_SCRATCH_DOUBLES / 4;
   const double* sc = scratch + (int64_t)seg * IRA_EDC_SCRATCH_DOUBLES;
-  const long long ntiles = (n + EDC_TILE - 1) / EDC_TILE;
-  const int nchunks = (int)((ntiles + EDC_CHUNK_TILES - 1) / EDC_CHUNK_TILES);
-  const double norm = sc[4 * q - 1];
+  const int ntiles = (int)((n + EDC_TILE - 1) / EDC_TILE);
+  for (int j = tid; j < ntiles; j += EDC_THREADS) sh.carry[j] = sc[IRA_EDC_SCRATCH_DOUBLES / 2 + j];
+  const double norm = sc[IRA_EDC_SCRATCH_DOUBLES - 1];
   const bool fast = norm > 1e-300 && norm < 1e300;
   __syncthreads();
   const double lnorm = fast ? ira::log2_table(norm, sh.ltab) : 0.0;
@@ -704,73 +690,85 @@ __global__ __launch_bounds__(EDC_THREADS) void edc_fit_kernel(
     int first = -1;
     if (tid < ntargets && !(t32 < (float)floor_db)) {      // the floored curve never goes below float32(floor_db)
       // A value v has float32(dB(v)) > target for certain once dB(v) exceeds the target by two float32 ulps; in the
-      // linear domain: v > thr_hi.  Every value of chunk c is >= its carry (sums of non-negative terms are monotone
-      // in floating point), so carry > thr_hi rules the whole chunk out.  eps clamps from below the same way.
+      // linear domain: v > thr_hi.  Every value of tile j is >= its carry (sums of non-negative terms are monotone
+      // in floating point), so carry > thr_hi rules the whole tile out; eps clamps from below the same way.  Carries
+      // grow with j (towards the start of the segment): the first tile IN TIME that is not ruled out is the LARGEST j
+      // with !(carry[j] > thr_hi) -- binary search; a NaN normaliser rules nothing out (search from the start).
       const double ulp2 = fmax(fabs((double)t32) * 2.384185791015625e-07, 1e-9);
       const double thr_hi = norm * pow(10.0, ((double)t32 + ulp2) / 10.0) * (1.0 + 1e-12);
       if (!(eps > thr_hi)) {
-        for (int c = nchunks - 1; c >= 0; --c)
-          if (!(sc[3 * q + c] > thr_hi)) { first = c; break; }
+        if (!(thr_hi == thr_hi)) {
+          first = ntiles - 1;
+        } else {
+          int lo_j = 0, hi_j = ntiles - 1;                  // carry[0] = 0 is never above a positive threshold
+          while (lo_j < hi_j) {
+            const int mid = (lo_j + hi_j + 1) >> 1;
+            if (!(sh.carry[mid] > thr_hi)) lo_j = mid; else hi_j = mid - 1;
+          }
+          first = lo_j;
+        }
       }
     }
-    sh.first_chunk[tid] = first;
+    sh.first_tile[tid] = first;
   }
   __syncthreads();
 
   // ---- phase A: first-crossing indices ---------------------------------------------------------------------------
-  for (int c = nchunks - 1; c >= 0; --c) {
+  int parity = 0;
+  int j_top = -1;
+  for (int k = 0; k < ntargets; ++k) j_top = sh.first_tile[k] > j_top ? sh.first_tile[k] : j_top;
+  for (int j = j_top; j >= 0; --j) {
     bool need = false, open = false;
     for (int k = 0; k < ntargets; ++k) {
-      const bool unfound = sh.first_chunk[k] >= 0 && sh.idx[k] >= n;
+      const bool unfound = sh.first_tile[k] >= 0 && sh.idx[k] >= n;
       open = open || unfound;
-      need = need || (unfound && sh.first_chunk[k] >= c);
+      need = need || (unfound && sh.first_tile[k] >= j);
     }
     if (!open) break;
     if (!need) continue;                                   // uniform: every thread reads the same shared state
-    long long cstart; int clen;
-    edc_chunk_to_lds(src, n, c, sc[3 * q + c], eps, floor_db, norm, lnorm, fast, sh, cstart, clen);
+    long long tstart; int tlen;
+    edc_tile_to_lds(src, n, j, eps, floor_db, norm, lnorm, fast, parity, sh, tstart, tlen);
+    parity ^= 1;
     if (tid < FIT_MAX_TARGETS) sh.found[tid] = 0xffffffffffffffffull;
     __syncthreads();
     for (int k = 0; k < ntargets; ++k) {
-      if (!(sh.first_chunk[k] >= c && sh.idx[k] >= n)) continue;      // uniform
+      if (!(sh.first_tile[k] >= j && sh.idx[k] >= n)) continue;      // uniform
       const float t32 = sh.tgt32[k];
-      int f = clen;
-      for (int i = tid; i < clen; i += EDC_THREADS)
+      int f = tlen;
+      for (int i = tid; i < tlen; i += EDC_THREADS)
         if (sh.db[i] <= t32) { f = i; break; }             // ascending per thread: its first hit is its smallest
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
         const int other = __shfl_xor(f, o, 64);
         f = other < f ? other : f;
       }
-      if ((tid & 63) == 0 && f < clen) atomicMin(&sh.found[k], (unsigned long long)f);
+      if ((tid & 63) == 0 && f < tlen) atomicMin(&sh.found[k], (unsigned long long)f);
     }
     __syncthreads();
-    if (tid < ntargets && sh.first_chunk[tid] >= c && sh.idx[tid] >= n && sh.found[tid] != 0xffffffffffffffffull) {
+    if (tid < ntargets && sh.first_tile[tid] >= j && sh.idx[tid] >= n && sh.found[tid] != 0xffffffffffffffffull) {
       const int f = (int)sh.found[tid];
-      sh.idx[tid] = cstart + f;
+      sh.idx[tid] = tstart + f;
       sh.y_at[tid] = sh.db[f];
       if (f > 0) sh.y_prev[tid] = sh.db[f - 1];
-      else if (cstart > 0) {
-        // the sample before this chunk is the LAST sample of chunk c+1: its suffix sum is its own energy + (0 + carry)
-        const double v = (double)src[cstart - 1];
-        const double e = v * v;
-        sh.y_prev[tid] = (float)np_max(edc_db64(e + (0.0 + sc[3 * q + c + 1]), eps, norm, lnorm, fast, sh.ltab), floor_db);
+      else if (tstart > 0) {
+        // the sample before this tile is the LAST sample of tile j+1: its suffix sum is its own energy + carry[j+1]
+        const double v = (double)src[tstart - 1];
+        sh.y_prev[tid] = (float)np_max(edc_db64(v * v + sh.carry[j + 1], eps, norm, lnorm, fast, sh.ltab), floor_db);
       }
     }
     __syncthreads();
   }
 
   if (co && tid == 0) {
-    for (int j = 0; j < P.ncross; ++j) {
-      const int k = 2 * P.nranges + j;
-      co[j] = crossing_time_from_values(sh.idx[k], n, sh.y_prev[k], sh.y_at[k], P.cross[j], ta);
+    for (int jc = 0; jc < P.ncross; ++jc) {
+      const int k = 2 * P.nranges + jc;
+      co[jc] = crossing_time_from_values(sh.idx[k], n, sh.y_prev[k], sh.y_at[k], P.cross[jc], ta);
     }
   }
   if (P.nranges == 0) return;
 
-  // ---- phase B: one sweep over the chunks between the crossings, shifted moments per range --------------------------
-  // Range parameters live in LDS and the running sums in per-wave LDS slots: per-thread accumulators for every range
-  // would not fit the 128 registers a 1024-thread workgroup leaves per lane.
+  // ---- phase B: one sweep over the tiles between the crossings, shifted moments per range ---------------------------
+  // Range parameters live in LDS and the running sums in per-wave LDS slots (registers are spent on the 16-sample scan).
   if (tid < FIT_MAX_RANGES) {
     EdcFitRange g;
     g.ok = 0; g.ts = g.te = qnan; g.tmid = g.ymid = 0.0; g.ts32 = g.te32 = 0.0f; g.a0 = 0; g.a1 = -1; g.pad = 0;
@@ -790,7 +788,7 @@ __global__ __launch_bounds__(EDC_THREADS) void edc_fit_kernel(
     }
     sh.rng[tid] = g;
   }
-  for (int i = tid; i < (EDC_THREADS / IRA_WAVE) * FIT_MAX_RANGES * 6; i += EDC_THREADS) (&sh.part[0][0][0])[i] = 0.0;
+  for (int i = tid; i < EDC_WAVES * FIT_MAX_RANGES * 6; i += EDC_THREADS) (&sh.part[0][0][0])[i] = 0.0;
   __syncthreads();
   long long lo_all = n, hi_all = -1;
   for (int r = 0; r < P.nranges; ++r) {
@@ -799,18 +797,19 @@ __global__ __launch_bounds__(EDC_THREADS) void edc_fit_kernel(
     hi_all = sh.rng[r].a1 > hi_all ? sh.rng[r].a1 : hi_all;
   }
   if (hi_all >= lo_all) {
-    const int c_first = (int)((n - 1 - lo_all) / EF_CHUNK);      // earliest chunk in time (largest number)
-    const int c_last = (int)((n - 1 - hi_all) / EF_CHUNK);
+    const int j_first = (int)((n - 1 - lo_all) / EDC_TILE);      // earliest tile in time (largest number)
+    const int j_last = (int)((n - 1 - hi_all) / EDC_TILE);
     const int lane = tid & 63, wave = tid >> 6;
-    for (int c = c_first; c >= c_last; --c) {
-      long long cstart; int clen;
-      edc_chunk_to_lds(src, n, c, sc[3 * q + c], eps, floor_db, norm, lnorm, fast, sh, cstart, clen);
+    for (int j = j_first; j >= j_last; --j) {
+      long long tstart; int tlen;
+      edc_tile_to_lds(src, n, j, eps, floor_db, norm, lnorm, fast, parity, sh, tstart, tlen);
+      parity ^= 1;
       for (int r = 0; r < P.nranges; ++r) {
         const EdcFitRange g = sh.rng[r];                     // uniform
-        if (!g.ok || g.a1 < cstart || g.a0 >= cstart + clen) continue;
+        if (!g.ok || g.a1 < tstart || g.a0 >= tstart + tlen) continue;
         double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0, m4 = 0.0, m5 = 0.0;
-        for (int i = tid; i < clen; i += EDC_THREADS) {
-          const long long gi = cstart + i;
+        for (int i = tid; i < tlen; i += EDC_THREADS) {
+          const long long gi = tstart + i;
           const float tf = ta.at(gi);
           if (gi >= g.a0 && gi <= g.a1 && tf >= g.ts32 && tf <= g.te32) {
             const double u = (double)tf - g.tmid, w = (double)sh.db[i] - g.ymid;
@@ -824,7 +823,7 @@ __global__ __launch_bounds__(EDC_THREADS) void edc_fit_kernel(
           pp[0] += m0; pp[1] += m1; pp[2] += m2; pp[3] += m3; pp[4] += m4; pp[5] += m5;
         }
       }
-      __syncthreads();                                       // sh.db is rewritten by the next chunk
+      __syncthreads();                                       // sh.db is rewritten by the next tile
     }
   }
   if (tid < P.nranges) {
@@ -835,7 +834,7 @@ __global__ __launch_bounds__(EDC_THREADS) void edc_fit_kernel(
       o[0] = 0.0; o[1] = g.ts; o[2] = g.te; for (int k = 3; k < IRA_FIT_DOUBLES; ++k) o[k] = qnan;
     } else {
       double cnt = 0.0, su = 0.0, sw = 0.0, suu = 0.0, suw = 0.0, sww = 0.0;
-      for (int w = 0; w < EDC_THREADS / IRA_WAVE; ++w) {
+      for (int w = 0; w < EDC_WAVES; ++w) {
         const double* pp = sh.part[w][r];
         cnt += pp[0]; su += pp[1]; sw += pp[2]; suu += pp[3]; suw += pp[4]; sww += pp[5];
       }
@@ -888,15 +887,14 @@ extern "C" int32_t ira_edc_db(const float* x_dev, const int64_t* off_dev, const 
   if (edc_db_dev == nullptr && edc_db64_dev == nullptr) return IRA_E_NULL;
   IRA_CHECK_PTR(edc_off_dev); IRA_CHECK_PTR(scratch_dev);
   if (nseg <= 0) return nseg == 0 ? IRA_OK : IRA_E_SIZE;
-  if (max_len <= 0 || max_len > (int64_t)EDC_MAX_CHUNKS * EDC_CHUNK_TILES * EDC_TILE) return IRA_E_SIZE;
+  if (max_len <= 0 || max_len > (int64_t)EDC_MAX_TILES * EDC_TILE) return IRA_E_SIZE;
   hipStream_t st = (hipStream_t)stream;
-  const int64_t ntiles = (max_len + EDC_TILE - 1) / EDC_TILE;
-  const int nchunks = (int)((ntiles + EDC_CHUNK_TILES - 1) / EDC_CHUNK_TILES);
+  const int ntiles = (int)((max_len + EDC_TILE - 1) / EDC_TILE);
   if (nseg > 65535) return IRA_E_SIZE;
-  edc_sums_kernel<<<dim3(nchunks, nseg), EDC_THREADS, 0, st>>>(x_dev, off_dev, len_dev, scratch_dev);
-  edc_carry_kernel<<<(nseg + 63) / 64, 64, 0, st>>>(len_dev, nseg, eps, scratch_dev);
-  edc_emit_kernel<<<dim3(nchunks, nseg), EDC_THREADS, 0, st>>>(x_dev, off_dev, len_dev, eps, floor_db, edc_db_dev,
-                                                               edc_db64_dev, edc_off_dev, scratch_dev);
+  edc_sums_kernel<<<dim3(ntiles, nseg), EDC_THREADS, 0, st>>>(x_dev, off_dev, len_dev, scratch_dev);
+  edc_carry_kernel<<<nseg, IRA_WAVE, 0, st>>>(len_dev, nseg, eps, scratch_dev);
+  edc_emit_kernel<<<dim3(ntiles, nseg), EDC_THREADS, 0, st>>>(x_dev, off_dev, len_dev, eps, floor_db, edc_db_dev,
+                                                              edc_db64_dev, edc_off_dev, scratch_dev);
   IRA_RETURN_LAUNCH();
 }
 
@@ -912,7 +910,7 @@ extern "C" int32_t ira_edc_fits(const float* x_dev, const int64_t* off_dev, cons
   if (ncross > 0) { IRA_CHECK_PTR(cross_targets); IRA_CHECK_PTR(cross_out_dev); }
   if (edc_db_dev != nullptr) IRA_CHECK_PTR(edc_off_dev);
   if (nseg <= 0) return nseg == 0 ? IRA_OK : IRA_E_SIZE;
-  if (max_len <= 0 || max_len > (int64_t)EDC_MAX_CHUNKS * EDC_CHUNK_TILES * EDC_TILE) return IRA_E_SIZE;
+  if (max_len <= 0 || max_len > (int64_t)EDC_MAX_TILES * EDC_TILE) return IRA_E_SIZE;
   if (nseg > 65535) return IRA_E_SIZE;
   FitParams P{};
   for (int r = 0; r < nranges; ++r) { P.hi[r] = ranges_hi_lo[2 * r]; P.lo[r] = ranges_hi_lo[2 * r + 1]; }
@@ -920,22 +918,21 @@ extern "C" int32_t ira_edc_fits(const float* x_dev, const int64_t* off_dev, cons
   P.nranges = nranges; P.ncross = ncross; P.min_points = min_points; P.rel_to_peak = 0;
   P.floor_db = floor_db; P.min_peak_above_floor = 0.0; P.t_mul = t_mul; P.t_div = t_div; P.t_axis = nullptr;
   hipStream_t st = (hipStream_t)stream;
-  const int64_t ntiles = (max_len + EDC_TILE - 1) / EDC_TILE;
-  const int nchunks = (int)((ntiles + EDC_CHUNK_TILES - 1) / EDC_CHUNK_TILES);
-  {   // > 64 KB of dynamic LDS needs the opt-in (idempotent, host-side only)
+  const int ntiles = (int)((max_len + EDC_TILE - 1) / EDC_TILE);
+  if (sizeof(EdcFitShared) > 64 * 1024) {   // > 64 KB of dynamic LDS needs the opt-in (idempotent, host-side only)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(edc_fit_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(EdcFitShared));
     if (e != hipSuccess) return ira_hip_status(e);
   }
-  edc_sums_kernel<<<dim3(nchunks, nseg), EDC_THREADS, 0, st>>>(x_dev, off_dev, len_dev, scratch_dev);
-  edc_carry_kernel<<<(nseg + 63) / 64, 64, 0, st>>>(len_dev, nseg, eps, scratch_dev);
+  edc_sums_kernel<<<dim3(ntiles, nseg), EDC_THREADS, 0, st>>>(x_dev, off_dev, len_dev, scratch_dev);
+  edc_carry_kernel<<<nseg, IRA_WAVE, 0, st>>>(len_dev, nseg, eps, scratch_dev);
   if (nranges + ncross > 0)
     edc_fit_kernel<<<nseg, EDC_THREADS, sizeof(EdcFitShared), st>>>(x_dev, off_dev, len_dev, eps, floor_db, P,
                                                                      scratch_dev, fit_out_dev,
                                                                      ncross > 0 ? cross_out_dev : nullptr);
   if (edc_db_dev != nullptr)
-    edc_emit_kernel<<<dim3(nchunks, nseg), EDC_THREADS, 0, st>>>(x_dev, off_dev, len_dev, eps, floor_db, edc_db_dev,
-                                                                 nullptr, edc_off_dev, scratch_dev);
+    edc_emit_kernel<<<dim3(ntiles, nseg), EDC_THREADS, 0, st>>>(x_dev, off_dev, len_dev, eps, floor_db, edc_db_dev,
+                                                                nullptr, edc_off_dev, scratch_dev);
   IRA_RETURN_LAUNCH();
 }
 

@@ -85,6 +85,64 @@ __global__ __launch_bounds__(PCM_THREADS) void pcm16_kernel(const int16_t* __res
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ira_host_pull: the batch upload as a KERNEL that reads pinned host memory through the PCIe link and writes HBM.
+// A hipMemcpyAsync of a whole batch (123 MB for 64 x 10 s) holds the copy engine for ~2.2 ms, and every small
+// asynchronous upload of the analysis streams (offset / length / job tables) queues behind it: the analysis stalled for
+// exactly one transfer per step (measured: 8.6 ms per step with a copy-engine upload against 6.4 ms compute-only).  A
+// small grid of pull workgroups leaves the copy engine to the small tables, overlaps with the analysis kernels on the
+// other CUs, and -- for PCM16 taps -- converts while it copies, so the int16 staging buffer in HBM disappears.
+// Each lane keeps PULL_U 16-byte reads of host memory in flight (a PCIe round trip is ~1.5-2 us: ~100 KB must be in
+// flight to fill a Gen5 x16 link; 8 workgroups x 256 lanes x 4 x 16 B = 131 KB -- measured on MI355X, full report,
+// 64 x 10 s: 8 workgroups 9283 IRs/s, 16 8488, 32 7611, 48 7690: more reads in flight do not move the link faster but do
+// crowd the fabric queues the analysis kernels' HBM reads share, e.g. the peak pick went from 0.09 to 1.2 ms).
+// ------------------------------------------------------------------------------------------------
+constexpr int PULL_THREADS = 256;
+constexpr int PULL_U = 4;
+typedef int pull_i4 __attribute__((ext_vector_type(4)));
+typedef float pull_f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float pcm_conv(int v) { return fminf(fmaxf((float)v / 32768.0f, -1.0f), 1.0f); }
+
+// format 0: float32 -> float32 (n16 = number of 16-byte pieces); format 1: mono int16 -> float32 (8 samples per piece)
+template <int FORMAT>
+__global__ __launch_bounds__(PULL_THREADS) void host_pull_kernel(const pull_i4* __restrict__ src, float* __restrict__ dst,
+                                                                 long long n16) {
+  const long long stride = (long long)gridDim.x * PULL_THREADS;
+  for (long long base = (long long)blockIdx.x * PULL_THREADS + threadIdx.x; base < n16; base += stride * PULL_U) {
+    pull_i4 v[PULL_U];
+#pragma unroll
+    for (int u = 0; u < PULL_U; ++u) {
+      const long long i = base + stride * u;
+      v[u] = i < n16 ? __builtin_nontemporal_load(src + i) : pull_i4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int u = 0; u < PULL_U; ++u) {
+      const long long i = base + stride * u;
+      if (i >= n16) continue;
+      if (FORMAT == 0) {
+        reinterpret_cast<pull_i4*>(dst)[i] = v[u];
+      } else {
+        pull_f4 a, b;
+        a.x = pcm_conv((int)(short)(v[u].x & 0xFFFF)); a.y = pcm_conv(v[u].x >> 16);
+        a.z = pcm_conv((int)(short)(v[u].y & 0xFFFF)); a.w = pcm_conv(v[u].y >> 16);
+        b.x = pcm_conv((int)(short)(v[u].z & 0xFFFF)); b.y = pcm_conv(v[u].z >> 16);
+        b.z = pcm_conv((int)(short)(v[u].w & 0xFFFF)); b.w = pcm_conv(v[u].w >> 16);
+        reinterpret_cast<pull_f4*>(dst)[2 * i] = a;
+        reinterpret_cast<pull_f4*>(dst)[2 * i + 1] = b;
+      }
+    }
+  }
+}
+
+template <int FORMAT>
+__global__ void host_pull_tail_kernel(const void* __restrict__ src, float* __restrict__ dst, long long first, long long count) {
+  const long long i = first + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  if (FORMAT == 0) dst[i] = static_cast<const float*>(src)[i];
+  else dst[i] = pcm_conv((int)static_cast<const int16_t*>(src)[i]);
+}
+
 }  // namespace
 
 extern "C" int32_t ira_wav_probe(const char* path, int32_t* sample_rate, int32_t* channels, int64_t* frames,
@@ -124,5 +182,35 @@ extern "C" int32_t ira_pcm16_to_channels(const int16_t* pcm_dev, int64_t frames,
   const long long blocks = (frames + PCM_THREADS - 1) / PCM_THREADS;
   pcm16_kernel<<<(unsigned)blocks, PCM_THREADS, 0, (hipStream_t)stream>>>(pcm_dev, frames, channels, mono_downmix ? 1 : 0,
                                                                          out_dev);
+  IRA_RETURN_LAUNCH();
+}
+
+extern "C" int32_t ira_host_pull(const void* host_src, int64_t count, int32_t format, float* out_dev,
+                                 int32_t workgroups, void* stream) {
+  IRA_CHECK_PTR(host_src); IRA_CHECK_PTR(out_dev);
+  if (count < 0 || (format != 0 && format != 1)) return IRA_E_SIZE;
+  if (count == 0) return IRA_OK;
+  // the kernel dereferences the DEVICE view of the pinned allocation; a pointer that is not mapped host memory is refused
+  void* dev_view = nullptr;
+  if (hipHostGetDevicePointer(&dev_view, const_cast<void*>(host_src), 0) != hipSuccess || dev_view == nullptr) {
+    (void)hipGetLastError();
+    return IRA_E_UNSUPPORTED;
+  }
+  if ((reinterpret_cast<uintptr_t>(dev_view) & 15u) != 0 || (reinterpret_cast<uintptr_t>(out_dev) & 15u) != 0) return IRA_E_SIZE;
+  hipStream_t st = (hipStream_t)stream;
+  const int per = format == 0 ? 4 : 8;                        // samples per 16-byte piece
+  const long long n16 = count / per;
+  int wg = workgroups > 0 ? workgroups : 8;
+  if (wg > 1024) wg = 1024;
+  if (n16 > 0) {
+    const long long need = (n16 + (long long)PULL_THREADS * PULL_U - 1) / ((long long)PULL_THREADS * PULL_U);
+    if (need < wg) wg = (int)need;
+    if (format == 0) host_pull_kernel<0><<<wg, PULL_THREADS, 0, st>>>(static_cast<const pull_i4*>(dev_view), out_dev, n16);
+    else host_pull_kernel<1><<<wg, PULL_THREADS, 0, st>>>(static_cast<const pull_i4*>(dev_view), out_dev, n16);
+  }
+  if (n16 * per < count) {
+    if (format == 0) host_pull_tail_kernel<0><<<1, 64, 0, st>>>(dev_view, out_dev, n16 * per, count);
+    else host_pull_tail_kernel<1><<<1, 64, 0, st>>>(dev_view, out_dev, n16 * per, count);
+  }
   IRA_RETURN_LAUNCH();
 }

@@ -18,7 +18,7 @@ from . import _lib
 from ._lib import IraError, check
 
 FIT_DOUBLES = 8
-EDC_SCRATCH_DOUBLES = 2048
+EDC_SCRATCH_DOUBLES = 4096
 EDC_TILE = 4096
 
 
@@ -81,13 +81,27 @@ class _TimedLib:
 
 class HostFuture:
     """Result of Engine.fetch(): a device tensor on its way into pinned host memory.  get() is valid once the
-    stream it was enqueued on has reached the copy (Engine.sync(), or the event of the step it belongs to)."""
+    stream it was enqueued on has reached the copy (Engine.sync(), or the event of the step it belongs to).
+    The first get() (or the future's destruction) hands its slice of the fetch arena back to the engine."""
 
-    def __init__(self, pinned, shape):
-        self._pinned, self._shape = pinned, shape
+    def __init__(self, pinned, shape, owner=None, segment=None):
+        self._pinned, self._shape, self._owner, self._segment = pinned, shape, owner, segment
+
+    def _release(self):
+        if self._owner is not None:
+            self._owner._fetch_release(self._segment)
+            self._owner = None
 
     def get(self) -> np.ndarray:
-        return self._pinned.numpy().reshape(self._shape).copy()
+        out = self._pinned.numpy().reshape(self._shape).copy()
+        self._release()
+        return out
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
 
 
 def _TORCH_DTYPES(t):
@@ -170,28 +184,47 @@ class Engine:
 
     # Small results (fit records, statistics, roots) leave through a pinned arena with ASYNC copies, so that a step's
     # device->host traffic is enqueued with its kernels and read after ONE wait -- and so that the next step can be
-    # enqueued behind it (audio_analysis_amd.pipeline.FullReport.submit / finish).  The arena is a ring: at most
-    # _FETCH_BYTES / 3 may be outstanding per step with two steps in flight.
+    # enqueued behind it (audio_analysis_amd.pipeline.FullReport.submit / finish).  The arena is cut into segments that
+    # are filled front to back; a segment is reused only when every future carved from it has been read (or dropped):
+    # an unread result is never overwritten, however many steps are in flight or however large their records are.
+    # When no segment is free the copy gets a private pinned allocation (slower, never wrong).
     _FETCH_BYTES = 96 << 20
+    _FETCH_SEGMENTS = 6
+
+    def _fetch_release(self, segment: int) -> None:
+        self._fetch_out[segment] -= 1
 
     def fetch(self, tensor) -> HostFuture:
         t = self.torch
         tensor = tensor.contiguous()
         nbytes = int(tensor.numel()) * tensor.element_size()
-        if nbytes > self._FETCH_BYTES // 3:
+        seg_bytes = self._FETCH_BYTES // self._FETCH_SEGMENTS
+        if getattr(self, "_fetch_arena", None) is None:
+            self._fetch_arena = t.empty(self._FETCH_BYTES, dtype=t.uint8).pin_memory()
+            self._fetch_seg, self._fetch_pos = 0, 0
+            self._fetch_out = [0] * self._FETCH_SEGMENTS
+        pos = (self._fetch_pos + 63) & ~63
+        seg = self._fetch_seg
+        if nbytes <= seg_bytes and pos + nbytes > seg_bytes:
+            # current segment is full: move on to the next one if everything carved from it has been consumed
+            nxt = (seg + 1) % self._FETCH_SEGMENTS
+            if self._fetch_out[nxt] == 0:
+                seg, pos = nxt, 0
+                self._fetch_seg = nxt
+        if nbytes > seg_bytes or pos + nbytes > seg_bytes:
             host = t.empty(tensor.shape, dtype=tensor.dtype).pin_memory()
             host.copy_(tensor, non_blocking=True)
             return HostFuture(host, tuple(tensor.shape))
-        if getattr(self, "_fetch_arena", None) is None:
-            self._fetch_arena = t.empty(self._FETCH_BYTES, dtype=t.uint8).pin_memory()
-            self._fetch_pos = 0
-        pos = (self._fetch_pos + 63) & ~63
-        if pos + nbytes > self._FETCH_BYTES:
-            pos = 0
+        if pos == 0 and self._fetch_out[seg] != 0:           # only reachable on the very first wrap with stale futures
+            host = t.empty(tensor.shape, dtype=tensor.dtype).pin_memory()
+            host.copy_(tensor, non_blocking=True)
+            return HostFuture(host, tuple(tensor.shape))
         self._fetch_pos = pos + nbytes
-        host = self._fetch_arena[pos : pos + nbytes].view(tensor.dtype).view(tensor.shape)
+        self._fetch_out[seg] += 1
+        base = seg * seg_bytes + pos
+        host = self._fetch_arena[base : base + nbytes].view(tensor.dtype).view(tensor.shape)
         host.copy_(tensor, non_blocking=True)
-        return HostFuture(host, tuple(tensor.shape))
+        return HostFuture(host, tuple(tensor.shape), self, seg)
 
     _side = None
 
@@ -316,7 +349,7 @@ class Engine:
         """Schroeder EDC in dB for segments of x_dev.  Returns (edc flat f32 device, edc_off host int64[, f64])."""
         t = self.torch
         n = int(seg_off.size)
-        if np.any(seg_len > 511 * 4 * EDC_TILE):
+        if np.any(seg_len > 2047 * EDC_TILE):
             raise ValueError("segment too long for the EDC kernel (> 8.3 M samples)")
         edc_off = np.zeros(n, dtype=np.int64)
         if n > 1:
@@ -344,7 +377,7 @@ class Engine:
         t = self.torch
         n = int(seg_off.size)
         seg_len = np.ascontiguousarray(seg_len, dtype=np.int64)
-        if np.any(seg_len > 511 * 4 * EDC_TILE):
+        if np.any(seg_len > 2047 * EDC_TILE):
             raise ValueError("segment too long for the EDC kernel (> 8.3 M samples)")
         nr, nc = len(ranges), len(cross)
         edc_off = np.zeros(n, dtype=np.int64)

@@ -6,8 +6,12 @@ unit of work: the reference re-loads the file in every report block, report.py:2
 
 Two wire formats:
   float32  4 bytes per sample, copied straight into the batch buffer;
-  int16    2 bytes per sample (what a PCM16 tap holds, recorder.hpp:49-53), converted on the device by
-           ira_pcm16_to_channels (x/32768 clipped: io.py:46-64) on the copy stream, behind the upload.
+  int16    2 bytes per sample (what a PCM16 tap holds, recorder.hpp:49-53), converted to float32 (x/32768 clipped:
+           io.py:46-64) on the way.
+The transfer itself is a KERNEL (ira_host_pull): a few dozen workgroups read the pinned batch through the PCIe link and
+write HBM, converting PCM16 in the same pass.  A copy-engine transfer (hipMemcpyAsync) of a 123 MB batch holds the engine
+for 2.2 ms, and the small asynchronous table uploads of the analysis streams queue behind it -- measured, the analysis then
+stalls one whole transfer per step (8.6 instead of 6.4 ms).  DeviceFeed(pull=False) keeps the copy-engine path as the A/B.
 
 A ChannelBatch handed out by push() carries the event recorded behind its upload (+ conversion): the peak pick and
 every report lane wait for THAT event only (pipeline.FullReport.submit), never for the copy stream as a whole.
@@ -59,9 +63,11 @@ class HostBatch:
 
 
 class DeviceFeed:
-    def __init__(self, eng: Engine, max_samples: int, depth: int = 4):
+    def __init__(self, eng: Engine, max_samples: int, depth: int = 4, pull: bool = True, pull_workgroups: int = 8):
         t = eng.torch
         self.eng = eng
+        self.pull = bool(pull)                     # False: copy-engine upload (hipMemcpyAsync) -- the A/B of the pull kernel
+        self.pull_workgroups = int(pull_workgroups)
         self.depth = int(depth)
         self.copy_stream = t.cuda.Stream(device=eng.device)
         self._x = [eng.empty(max_samples, t.float32) for _ in range(self.depth)]
@@ -78,7 +84,20 @@ class DeviceFeed:
         self._k += 1
         x = self._x[slot]
         with t.cuda.stream(self.copy_stream):
-            if hb.pcm16:
+            done = False
+            if self.pull:
+                # pull kernel: reads the pinned batch through the PCIe link itself (and converts PCM16 on the way), so the
+                # copy engine stays free for the analysis streams' small table uploads (ira_host_pull in include/ira.h)
+                rc = eng.lib.ira_host_pull(int(hb.pinned.data_ptr()), int(hb.total), 1 if hb.pcm16 else 0,
+                                           int(x.data_ptr()), int(self.pull_workgroups), eng.stream)
+                if rc == -3:                                  # IRA_E_UNSUPPORTED: not mapped host memory
+                    self.pull = False
+                else:
+                    check(rc, "ira_host_pull")
+                    done = True
+            if done:
+                pass
+            elif hb.pcm16:
                 if self._pcm is None:
                     self._pcm = [eng.empty(self._max, t.int16) for _ in range(self.depth)]
                 pcm = self._pcm[slot]

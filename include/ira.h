@@ -53,9 +53,9 @@ int32_t ira_peak_index(const float* x_dev, const int64_t* off_dev, const int64_t
  * (edc_off_dev).  Replaces compute_schroeder_edc_db, reference analyse/decay.py:115-170
  * edc_db64_dev (optional, may be NULL): the same curve as float64 BEFORE the floor, for the optional
  * host-side dB smoothing of decay.py:161-164.  edc_db_dev may be NULL if only that is wanted.
- * max_len = longest segment (sizes the grid; up to 511*16384 samples).
+ * max_len = longest segment (sizes the grid; up to 2047 tiles of 4096 samples = 8.38 M samples).
  * scratch_dev: nseg * IRA_EDC_SCRATCH_DOUBLES doubles. */
-#define IRA_EDC_SCRATCH_DOUBLES 2048
+#define IRA_EDC_SCRATCH_DOUBLES 4096
 int32_t ira_edc_db(const float* x_dev, const int64_t* off_dev, const int64_t* len_dev, int32_t nseg,
                    int64_t max_len, double eps, double floor_db, float* edc_db_dev, double* edc_db64_dev,
                    const int64_t* edc_off_dev, double* scratch_dev, void* stream);
@@ -375,6 +375,16 @@ int32_t ira_wav_read_pcm16(const char* path, int64_t data_offset, int64_t frames
                            int16_t* dst_host);
 int32_t ira_pcm16_to_channels(const int16_t* pcm_dev, int64_t frames, int32_t channels, int32_t mono_downmix,
                               float* out_dev, void* stream);
+
+/* ira_host_pull: DEVICE kernel that reads PINNED (mapped) host memory over the PCIe link and writes HBM -- the batch upload
+ *   without the copy engine, so the analysis streams' small table uploads never queue behind a 100 MB transfer, and for
+ *   PCM16 the conversion of io.py:46-64 (x/32768 clipped) happens in the same pass.  host_src: host pointer of a pinned
+ *   allocation (hipHostMalloc / torch pin_memory), 16-byte aligned; count samples; format 0 = float32 copied as is,
+ *   1 = mono int16 -> float32; out_dev 16-byte aligned; workgroups = grid size (0 = 8: just enough reads in flight to
+ *   fill a Gen5 x16 link; more only crowd the fabric queues the analysis kernels' HBM reads go through).  IRA_E_UNSUPPORTED if host_src is not mapped host memory
+ *   (the caller then uses an ordinary asynchronous copy). */
+int32_t ira_host_pull(const void* host_src, int64_t count, int32_t format, float* out_dev, int32_t workgroups,
+                      void* stream);
 
 /* ---- Section 8f, rank 4: sweep deconvolution (reference analyse/deconvolve.py:124-193) -----------------------------------
  * The transforms are ira_rfft_any / ira_rfft_smooth (zero-padded to n_fft = next power of two, no window) and

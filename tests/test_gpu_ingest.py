@@ -161,3 +161,53 @@ def test_bundle_edge_cases_empty_and_mono(tmp_path, capsys):
                                          rp.ReportSettings(render_plots=False))
     assert md.replace(str(mono / "taps" / "m1.wav"), "@") == single.summary_markdown.replace(str(mono / "taps" / "m1.wav"), "@")
     assert (mono / "rep2" / "m2" / "m2_spectrogram_mono.png").stat().st_size > 1000
+
+
+def test_host_pull_upload_is_bit_exact_and_feeds_the_pipeline():
+    """ira_host_pull (the batch upload as a kernel reading pinned host memory) against plain copies: float32 bit for bit,
+    PCM16 converted exactly like ira_pcm16_to_channels (all 65536 codes, odd counts: the scalar tail), and DeviceFeed /
+    run_pipelined hand the same records back for pull and copy-engine uploads and both wire formats' own references."""
+    import torch
+    from audio_analysis_amd.engine import get_engine
+    from audio_analysis_amd.feed import DeviceFeed, HostBatch, run_pipelined
+    from audio_analysis_amd.pipeline import FullReport, FullReportSettings
+    from audio_analysis_amd.synth import synth_ir
+    from dataclasses import replace
+    eng = get_engine()
+    rng = np.random.default_rng(9)
+    for count in (1, 3, 4, 7, 8, 1000, 65536 + 5):
+        f = rng.standard_normal(count).astype(np.float32)
+        hp = torch.empty(count, dtype=torch.float32, pin_memory=True); hp.numpy()[:] = f
+        out = eng.empty(count + 8, torch.float32)
+        out.fill_(7.0)
+        assert eng.lib.ira_host_pull(int(hp.data_ptr()), count, 0, int(out.data_ptr()), 0, eng.stream) == 0
+        got = out.cpu().numpy()
+        assert np.array_equal(got[:count].view(np.uint32), f.view(np.uint32)) and np.all(got[count:] == 7.0)
+    codes = np.arange(-32768, 32768, dtype=np.int16)
+    pcm = np.concatenate([codes, codes[::-1], codes[:5]])
+    hp = torch.empty(pcm.size, dtype=torch.int16, pin_memory=True); hp.numpy()[:] = pcm
+    out = eng.empty(pcm.size, torch.float32)
+    assert eng.lib.ira_host_pull(int(hp.data_ptr()), pcm.size, 1, int(out.data_ptr()), 3, eng.stream) == 0
+    ref = np.clip(pcm.astype(np.float32) / np.float32(32768.0), -1.0, 1.0).astype(np.float32)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    # not pinned / not host memory -> refused, no launch
+    assert eng.lib.ira_host_pull(int(out.data_ptr()) + 4, 16, 0, int(out.data_ptr()), 0, eng.stream) in (-2, -3)
+    # the feed: ragged batches, pull vs copy engine, float32 and PCM16
+    settings = replace(FullReportSettings(), run_rt60_bands=False, run_modal_cloud=False, run_zplane=False,
+                       run_waterfall=False, run_filter=False)
+    rep = FullReport(eng, settings)
+    chans = [[synth_ir(300 + 4 * b + i, 0, 30000 + 1111 * i + 7 * b, rt60_seconds=0.08) for i in range(4)] for b in range(5)]
+    rows = {}
+    for pull in (True, False):
+        for pcm16 in (False, True):
+            feed = DeviceFeed(eng, 200000, depth=4, pull=pull)
+            hbs = [HostBatch(eng, [(c * np.float32(32767.0)).astype(np.int16) for c in cs] if pcm16 else cs, pcm16=pcm16)
+                   for cs in chans]
+            got = []
+            assert run_pipelined(rep, feed, hbs, got.append) == len(chans)
+            rows[(pull, pcm16)] = np.concatenate(got)
+    for pcm16 in (False, True):
+        a, b = rows[(True, pcm16)], rows[(False, pcm16)]
+        assert a.shape == (20, rows[(True, False)].shape[1]) and a.tobytes() == b.tobytes()
+    direct = np.concatenate([rep.run(eng.upload(cs)) for cs in chans])
+    assert direct.tobytes() == rows[(True, False)].tobytes()
