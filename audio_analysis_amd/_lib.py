@@ -48,6 +48,7 @@ PROTOTYPES = {
     "ira_wav_probe": (i32, [C.c_char_p, vp, vp, vp, vp]),
     "ira_wav_read_pcm16": (i32, [C.c_char_p, C.c_int64, C.c_int64, i32, vp]),
     "ira_pcm16_to_channels": (i32, [vp, C.c_int64, i32, i32, vp, vp]),
+    "ira_band_mask_values": (i32, [C.POINTER(f64), f64, C.c_int64, vp, vp]),
     "ira_host_pull": (i32, [vp, C.c_int64, i32, vp, i32, vp]),
     "ira_deconv_divide": (i32, [vp, vp, vp, vp, vp, i32, i32, f64, vp, vp]),
     "ira_deconv_finish": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, f64, vp, vp, vp]),
@@ -58,10 +59,11 @@ PROTOTYPES = {
     "ira_waterfall_rel": (i32, [vp, vp, vp, i32, i32, i32, i32, f64, vp, vp, vp]),
     "ira_logbin_aggregate": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp]),
     "ira_ar_partial_doubles": (C.c_int64, [i32, i32]),
-    "ira_ar_gram": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
-    "ira_ar_solve": (i32, [vp, vp, i32, i32, i32, f64, vp, vp, vp, vp]),
-    "ira_ar_refine": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, f64, i32, vp]),
-    "ira_ar_fit": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f64, vp, vp, vp, vp, vp]),
+    "ira_ar_gram": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp, i32, vp]),
+    "ira_ar_solve": (i32, [vp, vp, i32, i32, i32, f64, vp, vp, vp, i32, vp]),
+    "ira_ar_minnorm": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, f64, vp]),
+    "ira_ar_refine": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, f64, i32, i32, vp]),
+    "ira_ar_fit": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f64, vp, vp, vp, vp, i32, vp]),
     "ira_poly_roots": (i32, [vp, i32, i32, f64, vp, vp, vp]),
     "ira_fir_numerator": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, vp, vp]),
 }
@@ -80,16 +82,18 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not _LIB_PATH.exists():
+    import os
+    path = Path(os.environ["IRA_LIBRARY"]) if os.environ.get("IRA_LIBRARY") else _LIB_PATH   # profiling: the tuning build
+    if not path.exists():
         raise IraError(
-            f"{_LIB_PATH} not found. The HIP library is the product path and has no fallback; "
+            f"{path} not found. The HIP library is the product path and has no fallback; "
             "build it with `python -m audio_analysis_amd.build`."
         )
     # torch bundles its own libamdhip64; load it FIRST so libira.so resolves to the same HIP runtime instance
     # (two runtimes in one process do not share devices, streams or allocations).
     import torch  # noqa: F401
 
-    lib = C.CDLL(str(_LIB_PATH))
+    lib = C.CDLL(str(path))
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res

@@ -59,8 +59,8 @@ def select_stft_segments(eng, batch, sample_rate_hz: int, settings, what: str):
     n_fft, hop = int(settings.n_fft), int(settings.hop_length)
     if n_fft <= 0 or hop <= 0:
         raise ValueError("n_fft and hop_length must be positive.")
-    if n_fft & (n_fft - 1) or not 64 <= n_fft <= 16384:
-        raise ValueError("the GPU STFT supports power-of-two n_fft in [64, 16384]")
+    # any positive frame size, like the reference (numpy.fft.rfft): powers of two in [64, 16384] run on the STFT kernels,
+    # everything else on the arbitrary-length transforms (Engine._stft_generic)
     peaks = eng.peaks(batch) if settings.trim_to_peak else np.zeros(batch.count, dtype=np.int64)
     starts = np.empty(batch.count, dtype=np.int64)
     lens = np.empty(batch.count, dtype=np.int64)

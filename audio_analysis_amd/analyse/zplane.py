@@ -75,9 +75,19 @@ def _fit_ar_least_squares(x: np.ndarray, order: int, ridge_lambda: float = 0.0) 
         raise ValueError("AR fit needs at least two samples.")
     eng = get_engine()
     xd = eng.to_dev(x)
-    co, _ = eng.ar_fit(xd, np.zeros(1, np.int64), np.array([x.size], np.int32), None, p,
-                       float(ridge_lambda) if ridge_lambda and ridge_lambda > 0.0 else 0.0, x_is_f64=True)
+    co, info = eng.ar_fit(xd, np.zeros(1, np.int64), np.array([x.size], np.int32), None, p,
+                          float(ridge_lambda) if ridge_lambda and ridge_lambda > 0.0 else 0.0, x_is_f64=True)
+    _raise_if_not_finite(info.cpu().numpy()[:, 0])
     return co.cpu().numpy()[0].copy()
+
+
+AR_STATUS_NOT_FINITE = 3.0      # ira_ar_minnorm: the Gram matrix holds NaN / infinity
+
+
+def _raise_if_not_finite(status: np.ndarray) -> None:
+    """numpy.linalg.lstsq raises LinAlgError on NaN / infinite input (reference zplane.py:117); so does the drop-in API."""
+    if np.any(np.asarray(status) == AR_STATUS_NOT_FINITE):
+        raise np.linalg.LinAlgError("SVD did not converge in Linear Least Squares")
 
 
 def _derive_fir_numerator_from_ar(a: np.ndarray, h: np.ndarray, zero_order: int) -> np.ndarray:
@@ -117,15 +127,19 @@ def analyse_zplane_batch(
     """Numeric body of the reference's plot function for a whole batch of channels."""
     eng = get_engine()
     batch = eng.upload(list(channels))
-    poles, zeros = zplane_device(eng, batch, sample_rate_hz, settings)
+    poles, zeros, status = zplane_device(eng, batch, sample_rate_hz, settings, with_status=True)
+    _raise_if_not_finite(status)
     return [ChannelZPlaneResult(channel_name=name, sample_rate_hz=sample_rate_hz, poles=poles[i],
                                 zeros=zeros[i] if settings.derive_zeros else None)
             for i, name in enumerate(channel_names)]
 
 
-def zplane_device(eng, batch, sample_rate_hz: int, settings: ZPlaneAnalysisSettings, defer: bool = False):
+def zplane_device(eng, batch, sample_rate_hz: int, settings: ZPlaneAnalysisSettings, defer: bool = False,
+                  with_status: bool = False):
     """AR fit + roots for a device-resident batch; returns host lists (poles, zeros) of complex128 arrays
-    (or, with defer=True, a zero-argument callable producing them after all launches have been enqueued)."""
+    (or, with defer=True, a zero-argument callable producing them after all launches have been enqueued).
+    with_status adds the per-channel solver status (ira_ar_solve / ira_ar_minnorm info[0]: 0 solved, 2 refined, 4 minimum
+    norm over a rank-deficient Gram matrix, 3 not finite -- the reference's lstsq raises LinAlgError there)."""
     nch = batch.count
     peaks = eng.peaks(batch) if settings.trim_to_peak else np.zeros(nch, dtype=np.int64)
     skip = int(round(float(settings.ignore_leading_seconds) * sample_rate_hz))
@@ -162,7 +176,7 @@ def zplane_device(eng, batch, sample_rate_hz: int, settings: ZPlaneAnalysisSetti
             continue
         idx = np.nonzero(eff == p)[0]
         div = None if divisor is None else divisor[idx]
-        co, _ = eng.ar_fit(batch.x, seg_off[idx], seg_len[idx], div, int(p), ridge)
+        co, info = eng.ar_fit(batch.x, seg_off[idx], seg_len[idx], div, int(p), ridge)
         roots, cnt = eng.poly_roots(co, int(idx.size), int(p) + 1, 1e-14)
         zr = zc = None
         if settings.derive_zeros:
@@ -170,19 +184,27 @@ def zplane_device(eng, batch, sample_rate_hz: int, settings: ZPlaneAnalysisSetti
             b = eng.fir_numerator(co, int(p), batch.x, seg_off[idx], seg_len[idx], div, q)
             zr, zc = eng.poly_roots(b, int(idx.size), q + 1, 1e-14)
         if defer:
-            roots, cnt = eng.fetch(roots), eng.fetch(cnt)
+            roots, cnt, info = eng.fetch(roots), eng.fetch(cnt), eng.fetch(info)
             if zr is not None:
                 zr, zc = eng.fetch(zr), eng.fetch(zc)
-        pending.append((idx, roots, cnt, zr, zc))
+        pending.append((idx, roots, cnt, zr, zc, info))
+
+    status = np.zeros(nch, dtype=np.float64)
 
     def finish():
-        for idx, roots, cnt, zr, zc in pending:
+        for idx, roots, cnt, zr, zc, info in pending:
             for k, r in zip(idx, _to_complex(roots, cnt)):
                 poles[k] = r
             if zr is not None:
                 for k, r in zip(idx, _to_complex(zr, zc)):
                     zeros[k] = r
-        return poles, zeros
+            st = info.get() if hasattr(info, "get") else info.cpu().numpy()
+            status[idx] = st[:, 0]
+            for k in idx[st[:, 0] == AR_STATUS_NOT_FINITE]:
+                poles[k] = np.array([], dtype=np.complex128)       # no fit: the reference raises for this channel
+                if zeros[k] is not None:
+                    zeros[k] = np.array([], dtype=np.complex128)
+        return (poles, zeros, status) if with_status else (poles, zeros)
 
     return finish if defer else finish()
 

@@ -58,6 +58,26 @@ def _stale(obj: Path, deps) -> bool:
     return any(Path(d).stat().st_mtime > t for d in deps)
 
 
+def build_tuning(verbose: bool = True) -> Path:
+    """The TUNING build: the same sources with -DIRA_TUNING_BUILD, i.e. with the IRA_* environment knobs (ablations, tile
+    and radix overrides, A/B kernel selection) compiled in -> csrc/libira_tuning.so.  Never loaded by the product; point
+    IRA_LIBRARY at it to profile (audio_analysis_amd._lib honours that variable for this purpose only)."""
+    hipcc = _hipcc()
+    objs = []
+    out = CSRC / "libira_tuning.so"
+    tmp = CSRC / "_tuning"
+    tmp.mkdir(exist_ok=True)
+    for name, extra in SOURCES.items():
+        obj = tmp / (Path(name).stem + ".o")
+        cmd = [hipcc, *COMMON, "-DIRA_TUNING_BUILD", *extra, "-c", str(CSRC / name), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        objs.append(obj)
+    subprocess.run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, objs), "-o", str(out)], check=True)
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
     hipcc = _hipcc()
     headers = list(CSRC.glob("*.h")) + [CSRC.parent.parent / "include" / "ira.h"]
@@ -88,5 +108,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
 
 if __name__ == "__main__":
+    if "--tuning" in sys.argv:
+        print(build_tuning())
+        sys.exit(0)
     p = build(force="--force" in sys.argv, verbose=True)
     print(p)

@@ -21,7 +21,6 @@
 // Float32 is not an option for G: on coloured IRs a float32 Gram loses the poles entirely (SURVEY.md
 // section 7, hard part 1).
 #include <cmath>
-#include <cstdlib>
 
 #include "ira_common.h"
 
@@ -524,6 +523,181 @@ __global__ __launch_bounds__(SV_THREADS) void ar_solve_kernel(const double* __re
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Rank-deficient fits: the minimum-norm least-squares solution the reference's lstsq returns (zplane.py:117).
+// When a Cholesky pivot of G = A^T A is not positive (ar_solve_kernel status 1: a constant segment, digital silence
+// after a few taps, a segment shorter than ~2p ...) the pivot-patched solve means nothing, while numpy.linalg.lstsq
+// drops the null directions and returns the shortest solution.  For the flagged elements only (every other workgroup
+// exits at once): G and r are re-assembled from the lag record, G = V diag(lambda) V^T by cyclic Jacobi rotations in a
+// round-robin order (p/2 disjoint rotations per round, so rows, then columns, of all pairs rotate in parallel), and
+//   a = - V diag(1/lambda_k if lambda_k > cut else 0) V^T r,   cut = rel_cut * lambda_max.
+// lstsq cuts SINGULAR values at eps*max(M,N)*sigma_max, i.e. lambda at ~1e-20 lambda_max -- below the rounding noise
+// of a float64 Gram matrix (~p eps lambda_max): rel_cut (1e-12 by default) sits above that noise, so directions with
+// sigma/sigma_max between 1e-10 and 1e-6 are dropped here and kept there.  That band is the cond(A) > 1e6 regime in
+// which no normal-equation method holds 1e-4 anyway; exact rank deficiency is reproduced.
+// A and V live in global scratch (2 p^2 doubles per element): this is a rare path, not a fast one.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int MN_MAX_P = 512;
+constexpr int MN_MAX_SWEEPS = 40;
+
+__global__ __launch_bounds__(SV_THREADS) void ar_minnorm_kernel(const double* __restrict__ part,
+                                                                const int32_t* __restrict__ nlen, int p,
+                                                                double* __restrict__ scratch2,
+                                                                double* __restrict__ coeffs, double* __restrict__ info,
+                                                                int lag_nchunks_max, long long lag_rec_doubles,
+                                                                double rel_cut) {
+  __shared__ double vec[MN_MAX_P], yv[MN_MAX_P], rot_c[MN_MAX_P / 2], rot_s[MN_MAX_P / 2];
+  __shared__ int rot_i[MN_MAX_P / 2], rot_j[MN_MAX_P / 2];
+  __shared__ double red[SV_THREADS / 64];
+  __shared__ double off_s, diag_s;
+  __shared__ int bad_s;
+  const int e = blockIdx.x, tid = threadIdx.x;
+  if (info[IRA_AR_INFO_DOUBLES * e + 0] != 1.0) return;
+  const long long N = nlen[e];
+  double* A = scratch2 + (long long)e * 2 * p * p;
+  double* V = A + (long long)p * p;
+  // ---- G and r from the lag sums and the head/tail samples, exactly as ar_solve_kernel assembles them --------------------
+  {
+    const int nlag = p + 1;
+    const double* rec = part + (long long)e * lag_rec_doubles;
+    const double* head = rec + (long long)lag_nchunks_max * nlag;
+    const double* tail = head + nlag;
+    const int lchunks = lag_chunks(N, p);
+    for (int d = tid; d < nlag; d += SV_THREADS) {
+      double c = 0.0;
+      for (int ch = 0; ch < lchunks; ++ch) c += rec[(long long)ch * nlag + d];
+      if (d >= 1) vec[d - 1] = -c;
+      double run = c, comp = 0.0;
+      for (int a = 1; a + d <= p; ++a) {
+        const int m = a - 1;
+        const double t1 = head[p - 1 - m] * head[p - 1 - m - d];
+        const double t2 = -tail[m] * tail[m + d];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const double term = q == 0 ? t1 : t2;
+          const double t = run + term;
+          comp += (fabs(run) >= fabs(term)) ? (run - t) + term : (term - t) + run;
+          run = t;
+        }
+        const double v = run + comp;
+        const int r = a + d - 1, cidx = a - 1;
+        A[r * p + cidx] = v;
+        A[cidx * p + r] = v;
+      }
+    }
+  }
+  for (int idx = tid; idx < p * p; idx += SV_THREADS) V[idx] = (idx / p == idx % p) ? 1.0 : 0.0;
+  if (tid == 0) bad_s = 0;
+  __syncthreads();
+  {
+    int bad = 0;
+    for (int idx = tid; idx < p * p; idx += SV_THREADS) { const double v = A[idx]; if (!(v - v == 0.0)) bad = 1; }
+    for (int j = tid; j < p; j += SV_THREADS) { const double v = vec[j]; if (!(v - v == 0.0)) bad = 1; }
+    if (bad) bad_s = 1;                                             // benign race: every writer stores 1
+  }
+  __syncthreads();
+  double* co = coeffs + (long long)e * (p + 1);
+  if (bad_s) {
+    // a NaN or infinite sample: the reference's lstsq raises LinAlgError ("SVD did not converge"); status 3, NaN coefficients
+    const double qn = __longlong_as_double(0x7ff8000000000000ll);
+    for (int j = tid; j < p; j += SV_THREADS) co[j + 1] = qn;
+    if (tid == 0) { co[0] = 1.0; info[IRA_AR_INFO_DOUBLES * e + 0] = 3.0; }
+    return;
+  }
+  // ---- cyclic Jacobi, round-robin pairing (circle method: player m-1 fixed, the others rotate) ------------------------------
+  const int m = p + (p & 1);                                        // even number of players; index p (if any) is a bye
+  const int npairs = m / 2;
+  for (int sweep = 0; sweep < MN_MAX_SWEEPS; ++sweep) {
+    double offp = 0.0, diagp = 0.0;
+    for (int idx = tid; idx < p * p; idx += SV_THREADS) {
+      const int r = idx / p, c = idx - r * p;
+      const double v = A[idx];
+      if (r == c) diagp += v * v; else offp += v * v;
+    }
+    offp = ira::wave_sum(offp); diagp = ira::wave_sum(diagp);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = offp;
+    __syncthreads();
+    if (tid == 0) { double t = 0.0; for (int w = 0; w < SV_THREADS / 64; ++w) t += red[w]; off_s = t; }
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = diagp;
+    __syncthreads();
+    if (tid == 0) { double t = 0.0; for (int w = 0; w < SV_THREADS / 64; ++w) t += red[w]; diag_s = t; }
+    __syncthreads();
+    if (!(off_s > 1e-27 * diag_s) || !(off_s > 0.0)) break;        // off-diagonal norm below ~3e-14 of the diagonal's
+    for (int round = 0; round < m - 1; ++round) {
+      for (int k = tid; k < npairs; k += SV_THREADS) {
+        int i = (k == 0) ? m - 1 : (round + k) % (m - 1);
+        int j = (k == 0) ? round : (round - k + (m - 1)) % (m - 1);
+        if (i > j) { const int t = i; i = j; j = t; }
+        double c = 1.0, sn = 0.0;
+        if (j < p) {
+          const double aij = A[i * p + j];
+          if (aij != 0.0) {
+            const double tau = (A[j * p + j] - A[i * p + i]) / (2.0 * aij);
+            const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+            c = 1.0 / sqrt(1.0 + t * t);
+            sn = t * c;
+          }
+        }
+        rot_i[k] = i; rot_j[k] = j; rot_c[k] = c; rot_s[k] = sn;
+      }
+      __syncthreads();
+      // rows: A <- J^T A
+      for (int idx = tid; idx < npairs * p; idx += SV_THREADS) {
+        const int k = idx / p, col = idx - k * p;
+        const int i = rot_i[k], j = rot_j[k];
+        if (j >= p || rot_s[k] == 0.0) continue;
+        const double c = rot_c[k], sn = rot_s[k];
+        const double ai = A[i * p + col], aj = A[j * p + col];
+        A[i * p + col] = c * ai - sn * aj;
+        A[j * p + col] = sn * ai + c * aj;
+      }
+      __syncthreads();
+      // columns: A <- A J, V <- V J
+      for (int idx = tid; idx < npairs * p; idx += SV_THREADS) {
+        const int k = idx / p, row = idx - k * p;
+        const int i = rot_i[k], j = rot_j[k];
+        if (j >= p || rot_s[k] == 0.0) continue;
+        const double c = rot_c[k], sn = rot_s[k];
+        const double ai = A[row * p + i], aj = A[row * p + j];
+        A[row * p + i] = c * ai - sn * aj;
+        A[row * p + j] = sn * ai + c * aj;
+        const double vi = V[row * p + i], vj = V[row * p + j];
+        V[row * p + i] = c * vi - sn * vj;
+        V[row * p + j] = sn * vi + c * vj;
+      }
+      __syncthreads();
+    }
+  }
+  // ---- a = V diag(1/lambda | 0) V^T r -----------------------------------------------------------------------------------------
+  double lmax = 0.0;
+  for (int k = 0; k < p; ++k) lmax = fmax(lmax, A[k * p + k]);       // every thread: p global reads, rare path
+  const double cut = rel_cut * lmax;
+  for (int k = tid; k < p; k += SV_THREADS) {
+    const double lam = A[k * p + k];
+    double dot = 0.0;
+    for (int r = 0; r < p; ++r) dot += V[r * p + k] * vec[r];
+    yv[k] = (lam > cut && lam > 0.0) ? dot / lam : 0.0;
+  }
+  __syncthreads();
+  for (int r = tid; r < p; r += SV_THREADS) {
+    double acc = 0.0;
+    for (int k = 0; k < p; ++k) acc += V[r * p + k] * yv[k];
+    co[r + 1] = acc;
+  }
+  if (tid == 0) {
+    co[0] = 1.0;
+    int rank = 0;
+    double lmin = INFINITY;
+    for (int k = 0; k < p; ++k) { const double lam = A[k * p + k]; if (lam > cut && lam > 0.0) { ++rank; lmin = fmin(lmin, lam); } }
+    info[IRA_AR_INFO_DOUBLES * e + 0] = 4.0;                         // minimum-norm solution over `rank` directions
+    info[IRA_AR_INFO_DOUBLES * e + 1] = lmax;
+    info[IRA_AR_INFO_DOUBLES * e + 2] = rank ? lmin : 0.0;
+    info[IRA_AR_INFO_DOUBLES * e + 3] = (double)rank;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Aberth-Ehrlich: all roots of c[0] z^n + ... + c[n] (descending powers), float64 complex.
 // One workgroup per polynomial, one thread per root (n <= 1024).  Jacobi-style sweeps (all corrections from
 // the previous iterate) keep it deterministic.  Leading/trailing handling follows the reference: trailing
@@ -658,12 +832,9 @@ extern "C" int64_t ira_ar_partial_doubles(int32_t p, int32_t max_len) {
   return dense > lag ? dense : lag;
 }
 
-// IRA_AR_DENSE=1 selects the dense MFMA Gram (cross-check / A-B); gram and solve must agree on the record layout.
-// (read on every call so that a test can flip it between two fits)
-static bool ar_dense() {
-  const char* v = std::getenv("IRA_AR_DENSE");
-  return v != nullptr && v[0] != '\0' && v[0] != '0';
-}
+// flags & IRA_AR_DENSE_GRAM selects the dense MFMA Gram (cross-check / A-B); gram, solve and refine of one fit must be given
+// the same flags: they agree on the layout of the partial record through it.
+static inline bool ar_dense(int32_t flags) { return (flags & IRA_AR_DENSE_GRAM) != 0; }
 
 static int32_t ar_check(int32_t nb, int32_t max_len, int32_t order) {
   if (nb < 0) return IRA_E_SIZE;
@@ -674,12 +845,12 @@ static int32_t ar_check(int32_t nb, int32_t max_len, int32_t order) {
 
 extern "C" int32_t ira_ar_gram(const float* x_dev, const double* x64_dev, const int64_t* xoff_dev,
                                const int32_t* len_dev, const double* divisor_dev, int32_t nb, int32_t max_len,
-                               int32_t order, double* partial_dev, void* stream) {
+                               int32_t order, double* partial_dev, int32_t flags, void* stream) {
   if (x_dev == nullptr && x64_dev == nullptr) return IRA_E_NULL;
   IRA_CHECK_PTR(xoff_dev); IRA_CHECK_PTR(len_dev); IRA_CHECK_PTR(partial_dev);
   const int32_t rc = ar_check(nb, max_len, order);
   if (rc != IRA_OK || nb == 0) return rc;
-  if (!ar_dense()) {
+  if (!ar_dense(flags)) {
     const int lchunks = lag_chunks(max_len, order);
     const int ngroups = (order + 1 + 3) / 4;
     const int nsub = ngroups >= LAG_THREADS ? 1 : LAG_THREADS / ngroups;
@@ -706,7 +877,7 @@ extern "C" int32_t ira_ar_gram(const float* x_dev, const double* x64_dev, const 
 
 extern "C" int32_t ira_ar_solve(const double* partial_dev, const int32_t* len_dev, int32_t nb, int32_t max_len,
                                 int32_t order, double ridge, double* gscratch_dev, double* coeffs_dev,
-                                double* info_dev, void* stream) {
+                                double* info_dev, int32_t flags, void* stream) {
   IRA_CHECK_PTR(partial_dev); IRA_CHECK_PTR(len_dev); IRA_CHECK_PTR(coeffs_dev);
   const int32_t rc = ar_check(nb, max_len, order);
   if (rc != IRA_OK || nb == 0) return rc;
@@ -721,8 +892,22 @@ extern "C" int32_t ira_ar_solve(const double* partial_dev, const int32_t* len_de
   }
   ar_solve_kernel<<<nb, SV_THREADS, lds, (hipStream_t)stream>>>(partial_dev, len_dev, order, nchunks, ridge,
                                                                  gscratch_dev, coeffs_dev, info_dev,
-                                                                 ar_dense() ? 0 : 1, lag_chunks(max_len, order),
+                                                                 ar_dense(flags) ? 0 : 1, lag_chunks(max_len, order),
                                                                  lag_record_doubles(max_len, order), nullptr, 0.0);
+  IRA_RETURN_LAUNCH();
+}
+
+extern "C" int32_t ira_ar_minnorm(const double* partial_dev, const int32_t* len_dev, int32_t nb, int32_t max_len,
+                                  int32_t order, double* scratch2_dev, double* coeffs_dev, double* info_dev,
+                                  double rel_cut, void* stream) {
+  IRA_CHECK_PTR(partial_dev); IRA_CHECK_PTR(len_dev); IRA_CHECK_PTR(scratch2_dev); IRA_CHECK_PTR(coeffs_dev);
+  IRA_CHECK_PTR(info_dev);
+  const int32_t rc = ar_check(nb, max_len, order);
+  if (rc != IRA_OK || nb == 0) return rc;
+  if (order > MN_MAX_P || !(rel_cut > 0.0) || !(rel_cut < 1.0)) return IRA_E_SIZE;
+  ar_minnorm_kernel<<<nb, SV_THREADS, 0, (hipStream_t)stream>>>(partial_dev, len_dev, order, scratch2_dev, coeffs_dev,
+                                                                 info_dev, lag_chunks(max_len, order),
+                                                                 lag_record_doubles(max_len, order), rel_cut);
   IRA_RETURN_LAUNCH();
 }
 
@@ -730,7 +915,7 @@ extern "C" int32_t ira_ar_refine(const float* x_dev, const double* x64_dev, cons
                                  const int32_t* len_dev, const double* divisor_dev, int32_t nb, int32_t max_len,
                                  int32_t order, const double* partial_dev, double* gscratch_dev, double* coeffs_dev,
                                  double* info_dev, double* grad_dev, double cond_threshold, int32_t steps,
-                                 void* stream) {
+                                 int32_t flags, void* stream) {
   if (x_dev == nullptr && x64_dev == nullptr) return IRA_E_NULL;
   IRA_CHECK_PTR(xoff_dev); IRA_CHECK_PTR(len_dev); IRA_CHECK_PTR(partial_dev); IRA_CHECK_PTR(coeffs_dev);
   IRA_CHECK_PTR(info_dev); IRA_CHECK_PTR(grad_dev);
@@ -761,7 +946,7 @@ extern "C" int32_t ira_ar_refine(const float* x_dev, const double* x64_dev, cons
                                                                       divisor_dev, order, lchunks, coeffs_dev, info_dev,
                                                                       cond_threshold, grad_dev);
     ar_solve_kernel<<<nb, SV_THREADS, lds_s, st>>>(partial_dev, len_dev, order, nchunks, 0.0, gscratch_dev, coeffs_dev,
-                                                    info_dev, ar_dense() ? 0 : 1, lchunks,
+                                                    info_dev, ar_dense(flags) ? 0 : 1, lchunks,
                                                     lag_record_doubles(max_len, order), grad_dev, cond_threshold);
   }
   IRA_RETURN_LAUNCH();
@@ -770,10 +955,10 @@ extern "C" int32_t ira_ar_refine(const float* x_dev, const double* x64_dev, cons
 extern "C" int32_t ira_ar_fit(const float* x_dev, const double* x64_dev, const int64_t* xoff_dev,
                               const int32_t* len_dev, const double* divisor_dev, int32_t nb, int32_t max_len,
                               int32_t order, double ridge, double* partial_dev, double* gscratch_dev,
-                              double* coeffs_dev, double* info_dev, void* stream) {
-  int32_t rc = ira_ar_gram(x_dev, x64_dev, xoff_dev, len_dev, divisor_dev, nb, max_len, order, partial_dev, stream);
+                              double* coeffs_dev, double* info_dev, int32_t flags, void* stream) {
+  int32_t rc = ira_ar_gram(x_dev, x64_dev, xoff_dev, len_dev, divisor_dev, nb, max_len, order, partial_dev, flags, stream);
   if (rc != IRA_OK) return rc;
-  return ira_ar_solve(partial_dev, len_dev, nb, max_len, order, ridge, gscratch_dev, coeffs_dev, info_dev, stream);
+  return ira_ar_solve(partial_dev, len_dev, nb, max_len, order, ridge, gscratch_dev, coeffs_dev, info_dev, flags, stream);
 }
 
 extern "C" int32_t ira_poly_roots(const double* coeffs_dev, int32_t npoly, int32_t ncoef, double trail_eps,

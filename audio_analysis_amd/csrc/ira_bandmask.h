@@ -8,19 +8,32 @@ namespace ira {
 
 constexpr double kPiMask = 3.14159265358979323846;
 
-// cos(x) for 0 <= x <= pi in float64 (fdlibm's kernel polynomials after one Cody-Waite step by pi/2; error < 2 ulp of
-// float64, far below the float32 rounding it feeds).  The library cos() carries its large-argument reduction along:
-// inlined into the pass-1 input stage it cost 40 registers (121 instead of 79) and a wave per SIMD.
-__device__ __forceinline__ double cos_0_pi(double x) {
-  const double k = rint(x * 0.63661977236758134308);                       // 0, 1 or 2
-  double r = fma(-k, 1.57079632679489655800e+00, x);
-  r = fma(-k, 6.12323399573676603587e-17, r);
-  const double z = r * r;
-  const double c = 1.0 - (0.5 * z - z * (z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
-                   z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))))));
-  const double sn = r + (z * r) * (-1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
-                    z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)))));
-  return k == 0.0 ? c : (k == 1.0 ? -sn : -c);
+// numpy's float32 cosine, bit for bit.  The reference evaluates its raised-cosine ramps with numpy.cos on a float32 array
+// (rt60bands.py:116-124), and numpy's float32 sin/cos is NOT libm's cosf nor the correctly rounded cosine: it is its own
+// SIMD routine (numpy/_core/src/umath/loops_trigonometric: three-term Cody-Waite reduction by pi/2 with fused multiply-adds,
+// then a degree-8 / degree-9 minimax polynomial in float32, documented at <= 1.49 ulp) -- 17 % of its results differ from
+// the correctly rounded value by one ulp.  Same constants, same operation order, fmaf for every fused step (valid for
+// |x| < 71476, the routine's own fast-path limit; the ramps only pass 0 <= x <= pi).  Pinned by the reference's own mask
+// arrays: tests/golden/band_signals.npz, tests/test_gpu_longfft.py::test_band_masks_and_band_signals_vs_reference_goldens
+// (the round-1 version computed a correctly rounded cosine and was off by one ulp in one transition bin out of six).
+__device__ __forceinline__ float np_cos_f32(float x) {
+  const float q = rintf(x * 0x1.45f306p-1f);                                  // quadrant: round-to-nearest-even of x * 2/pi
+  float r = fmaf(q, -0x1.921fb0p+00f, x);
+  r = fmaf(q, -0x1.5110b4p-22f, r);
+  r = fmaf(q, -0x1.846988p-48f, r);
+  const float x2 = r * r;
+  float cp = fmaf(0x1.98e616p-16f, x2, -0x1.6c06dcp-10f);
+  cp = fmaf(cp, x2, 0x1.55553cp-05f);
+  cp = fmaf(cp, x2, -0x1.000000p-01f);
+  cp = fmaf(cp, x2, 0x1.000000p+00f);
+  float sp = fmaf(0x1.7d3bbcp-19f, x2, -0x1.a06bbap-13f);
+  sp = fmaf(sp, x2, 0x1.11119ap-07f);
+  sp = fmaf(sp, x2, -0x1.555556p-03f);
+  sp = fmaf(sp, x2, 0.0f);
+  sp = fmaf(sp, r, r);
+  const int iq = (int)q + 1;                                                   // cos(x) = sin(x + pi/2): one quadrant on
+  const float v = (iq & 1) ? cp : sp;
+  return (iq & 2) ? -v : v;
 }
 
 struct BandMask {
@@ -33,8 +46,7 @@ struct BandMask {
 // pass-1 input stage cost registers (and so resident workgroups) on every bin.
 __device__ __noinline__ float ramp_inside(float t) {
   const float arg = (float)kPiMask * t;
-  const float cs = (float)cos_0_pi((double)arg);  // float64 cosine rounded once: the correctly rounded float32 cosine
-  return 0.5f - 0.5f * cs;
+  return 0.5f - 0.5f * np_cos_f32(arg);
 }
 
 __device__ __forceinline__ float ramp_f32(float f, double x0, double x1) {

@@ -20,6 +20,24 @@ static inline int32_t ira_hip_status(hipError_t e) {
 // Launch epilogue: report launch-configuration errors without synchronising.
 #define IRA_RETURN_LAUNCH() return ira_hip_status(hipGetLastError())
 
+// Tuning / ablation knobs (IRA_* environment variables) exist only in the TUNING build (-DIRA_TUNING_BUILD:
+// `python -m audio_analysis_amd.build --tuning` -> csrc/libira_tuning.so, never loaded by the product).  In the product
+// library these helpers are constants: it reads no environment variable and keeps no state between calls -- every entry
+// point is a pure function of its arguments.
+#ifdef IRA_TUNING_BUILD
+#include <cstdlib>
+static inline int ira_tune_int(const char* name, int dflt) {
+  const char* v = std::getenv(name);
+  return v ? std::atoi(v) : dflt;
+}
+static inline const char* ira_tune_str(const char* name) { return std::getenv(name); }
+static inline bool ira_tune_flag(const char* name) { return std::getenv(name) != nullptr; }
+#else
+static inline constexpr int ira_tune_int(const char*, int dflt) { return dflt; }
+static inline constexpr const char* ira_tune_str(const char*) { return nullptr; }
+static inline constexpr bool ira_tune_flag(const char*) { return false; }
+#endif
+
 namespace ira {
 
 template <typename T>

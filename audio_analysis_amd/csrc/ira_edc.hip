@@ -301,7 +301,7 @@ __device__ __forceinline__ double crossing_time_from_index(const float* y, float
   const double y1 = (double)(y[idx] - peak);
   if (y1 == y0) return t1;
   double frac = (target - y0) / (y1 - y0);
-  frac = fmin(fmax(frac, 0.0), 1.0);
+  if (frac == frac) frac = fmin(fmax(frac, 0.0), 1.0);       // numpy.clip keeps NaN (a NaN neighbour: decay.py:192-196)
   return t0 + frac * (t1 - t0);
 }
 
@@ -612,16 +612,22 @@ struct EdcFitShared {
   int first_tile[FIT_MAX_TARGETS];                // tile (counted from the END) where the search starts; -1 = never
 };
 
-// dB curve of tile j (counted from the end of the segment) into sh.db, in time order.  Same scan, same carry and same
-// conversion as edc_emit_kernel.  The caller alternates `parity` between consecutive calls.
-__device__ __forceinline__ void edc_tile_to_lds(const float* __restrict__ src, long long n, int j, double eps,
+// Samples of tile j (counted from the end of the segment) into registers: issued one tile AHEAD of its use (phase B walks
+// consecutive tiles), so that the memory round trip of tile j-1 runs under the scan and the logarithms of tile j.
+__device__ __forceinline__ void edc_tile_fetch(const float* __restrict__ src, long long n, int j, float xv[EDC_PER_THREAD]) {
+  const long long hi = n - (long long)j * EDC_TILE;
+  const long long lo = hi - EDC_TILE > 0 ? hi - EDC_TILE : 0;
+  tile_load(src + lo, (int)(hi - lo), xv);
+}
+
+// dB curve of tile j from its pre-fetched samples into sh.db, in time order.  Same scan, same carry and same conversion
+// as edc_emit_kernel.  The caller alternates `parity` between consecutive calls.
+__device__ __forceinline__ void edc_tile_to_lds(const float xv[EDC_PER_THREAD], long long n, int j, double eps,
                                                 double floor_db, double norm, double lnorm, bool fast, int parity,
                                                 EdcFitShared& sh, long long& tstart, int& tlen) {
   const long long hi = n - (long long)j * EDC_TILE;
   tstart = hi - EDC_TILE > 0 ? hi - EDC_TILE : 0;
   tlen = (int)(hi - tstart);
-  float xv[EDC_PER_THREAD];
-  tile_load(src + tstart, tlen, xv);
   double s[EDC_PER_THREAD];
   tile_suffix_scan(xv, sh.scan, parity, s);
   const double carry = sh.carry[j];
@@ -642,11 +648,11 @@ __device__ __forceinline__ double crossing_time_from_values(long long idx, long 
   const double y1 = (double)y_at;
   if (y1 == y0) return t1;
   double frac = (target - y0) / (y1 - y0);
-  frac = fmin(fmax(frac, 0.0), 1.0);
+  if (frac == frac) frac = fmin(fmax(frac, 0.0), 1.0);       // numpy.clip keeps NaN (a NaN neighbour: decay.py:192-196)
   return t0 + frac * (t1 - t0);
 }
 
-__global__ __launch_bounds__(EDC_THREADS) void edc_fit_kernel(
+__global__ __launch_bounds__(EDC_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void edc_fit_kernel(
     const float* __restrict__ x, const int64_t* __restrict__ off, const int64_t* __restrict__ len, double eps,
     double floor_db, FitParams P, const double* __restrict__ scratch, double* __restrict__ fit_out,
     double* __restrict__ cross_out) {
@@ -727,7 +733,11 @@ __global__ __launch_bounds__(EDC_THREADS) void edc_fit_kernel(
     if (!open) break;
     if (!need) continue;                                   // uniform: every thread reads the same shared state
     long long tstart; int tlen;
-    edc_tile_to_lds(src, n, j, eps, floor_db, norm, lnorm, fast, parity, sh, tstart, tlen);
+    {
+      float xv[EDC_PER_THREAD];
+      edc_tile_fetch(src, n, j, xv);
+      edc_tile_to_lds(xv, n, j, eps, floor_db, norm, lnorm, fast, parity, sh, tstart, tlen);
+    }
     parity ^= 1;
     if (tid < FIT_MAX_TARGETS) sh.found[tid] = 0xffffffffffffffffull;
     __syncthreads();
@@ -800,9 +810,13 @@ __global__ __launch_bounds__(EDC_THREADS) void edc_fit_kernel(
     const int j_first = (int)((n - 1 - lo_all) / EDC_TILE);      // earliest tile in time (largest number)
     const int j_last = (int)((n - 1 - hi_all) / EDC_TILE);
     const int lane = tid & 63, wave = tid >> 6;
+    float xv[EDC_PER_THREAD];
+    edc_tile_fetch(src, n, j_first, xv);
     for (int j = j_first; j >= j_last; --j) {
       long long tstart; int tlen;
-      edc_tile_to_lds(src, n, j, eps, floor_db, norm, lnorm, fast, parity, sh, tstart, tlen);
+      float xn[EDC_PER_THREAD];
+      if (j > j_last) edc_tile_fetch(src, n, j - 1, xn);     // next tile's samples: in flight during this tile's work
+      edc_tile_to_lds(xv, n, j, eps, floor_db, norm, lnorm, fast, parity, sh, tstart, tlen);
       parity ^= 1;
       for (int r = 0; r < P.nranges; ++r) {
         const EdcFitRange g = sh.rng[r];                     // uniform
@@ -824,6 +838,10 @@ __global__ __launch_bounds__(EDC_THREADS) void edc_fit_kernel(
         }
       }
       __syncthreads();                                       // sh.db is rewritten by the next tile
+      if (j > j_last) {
+#pragma unroll
+        for (int r = 0; r < EDC_PER_THREAD; ++r) xv[r] = xn[r];
+      }
     }
   }
   if (tid < P.nranges) {

@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void half_split_kernel(Jobs J) {
 // of N2*16 bytes, and C is what fits in LDS: a SHORT column (small N1) buys wide pieces.  IRA_FFT_SPLIT overrides
 // log2(N1) for tuning; ira_fft_split() is the single source of truth the host sizes its tables from.
 int split_log2n1(int log2m) {
-  static const int forced = std::getenv("IRA_FFT_SPLIT") ? std::atoi(std::getenv("IRA_FFT_SPLIT")) : 0;
+  const int forced = ira_tune_int("IRA_FFT_SPLIT", 0);
   int l1 = (log2m + 1) / 2;
   if (forced > 0) l1 = forced;
   if (l1 < 2) l1 = 2;
@@ -501,7 +501,7 @@ int32_t make_plan(int log2m, const void* t1, const void* t2, const void* tf, Pla
   p->g.t1 = static_cast<const cd*>(t1);
   p->g.t2 = static_cast<const cd*>(t2);
   p->g.tf = static_cast<const cd*>(tf);
-  p->g.ablate = std::getenv("IRA_FFT_ABLATE") ? std::atoi(std::getenv("IRA_FFT_ABLATE")) : 0;
+  p->g.ablate = ira_tune_int("IRA_FFT_ABLATE", 0);
   const int N1 = 1 << p->g.log2n1, N2 = 1 << p->g.log2n2;
   // ~32 KB of LDS per workgroup (C = R = 2 at N1 = N2 = 1024): measured fastest on MI355X -- 4 workgroups per CU
   // hide each other's barriers (rfft_any, 64 x 2^20: C/R = 4/4 2.75 ms, 2/2 2.39 ms, 1/1 2.92 ms)
@@ -510,8 +510,8 @@ int32_t make_plan(int log2m, const void* t1, const void* t2, const void* tf, Pla
   if (C > N2) C = N2;
   int R = 1;
   while (R * 2 * N2 * (int)sizeof(cd) <= 32 * 1024 && R * 2 <= N1 && R < 16) R <<= 1;
-  if (const char* ev = std::getenv("IRA_FFT_C")) { const int v = std::atoi(ev); if (v >= 1 && v <= N2 && v <= 64 && (v & (v - 1)) == 0) C = v; }   // tuning (power of two: K1 relies on FL_THREADS % C == 0)
-  if (const char* ev = std::getenv("IRA_FFT_R")) { const int v = std::atoi(ev); if (v >= 1 && v <= N1) R = v; }
+  { const int v = ira_tune_int("IRA_FFT_C", 0); if (v >= 1 && v <= N2 && v <= 64 && (v & (v - 1)) == 0) C = v; }   // tuning (power of two: K1 relies on FL_THREADS % C == 0)
+  { const int v = ira_tune_int("IRA_FFT_R", 0); if (v >= 1 && v <= N1) R = v; }
   p->C = C;
   p->R = R;
   p->lds_cols = (size_t)C * (N1 + 1) * sizeof(cd);

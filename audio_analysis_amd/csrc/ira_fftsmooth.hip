@@ -10,6 +10,7 @@
 //                     X[k1 + N1*k2]                                                                 (runs of C2 values)
 // Inverse transforms run the same forward machinery on the conjugated input (conj(DFT(conj .)) / n).
 #include <cmath>
+#include <cstring>
 #include <cstdlib>
 
 #include "ira_bandmask.h"
@@ -587,7 +588,7 @@ bool smooth_split(long long n, int* n1_out, int* n2_out) {
   // Among the pairs n1 * n2 = n with both <= SM_MAX_N take the most balanced one (measured on MI355X for n = 480000:
   // 640 x 750 beats 960 x 500 and 480 x 1000 although the latter allow more columns per workgroup: the smaller LDS
   // footprint, i.e. more resident workgroups, matters more).  IRA_SMOOTH_N1 forces n1 (tuning).
-  static const int forced = std::getenv("IRA_SMOOTH_N1") ? std::atoi(std::getenv("IRA_SMOOTH_N1")) : 0;
+  const int forced = ira_tune_int("IRA_SMOOTH_N1", 0);
   long long best_score = -1;
   int best = 0;
   for (int d = 2; d <= SM_MAX_N; ++d) {
@@ -612,7 +613,7 @@ int32_t make_smooth_plan(int32_t n, const void* t1, const void* t2, const void* 
   if (P->nr1 < 0 || P->nr2 < 0) return IRA_E_UNSUPPORTED;
   // tuning: IRA_SMOOTH_R1 / IRA_SMOOTH_R2 = comma-separated radix order for the n1- / n2-point transforms (product checked)
   auto override_radices = [](const char* name, int len, int* out, int* cnt) {
-    const char* ev = std::getenv(name);
+    const char* ev = ira_tune_str(name);
     if (!ev) return;
     int tmp[SM_MAX_RADICES], k = 0;
     long long prod = 1;
@@ -629,15 +630,15 @@ int32_t make_smooth_plan(int32_t n, const void* t1, const void* t2, const void* 
   };
   override_radices("IRA_SMOOTH_R1", n1, P->r1, &P->nr1);
   override_radices("IRA_SMOOTH_R2", n2, P->r2, &P->nr2);
-  P->inplace = std::getenv("IRA_SMOOTH_PINGPONG") == nullptr;
+  P->inplace = !ira_tune_flag("IRA_SMOOTH_PINGPONG");
   P->c1 = pick_columns(n1, n2, P->inplace != 0);
   P->c2 = pick_columns(n2, n1, P->inplace != 0);
-  if (const char* ev = std::getenv("IRA_SMOOTH_C1")) { const int v = std::atoi(ev); if (v >= 1 && n2 % v == 0) P->c1 = v; }
-  if (const char* ev = std::getenv("IRA_SMOOTH_C2")) { const int v = std::atoi(ev); if (v >= 1 && n1 % v == 0) P->c2 = v; }
+  { const int v = ira_tune_int("IRA_SMOOTH_C1", 0); if (v >= 1 && n2 % v == 0) P->c1 = v; }
+  { const int v = ira_tune_int("IRA_SMOOTH_C2", 0); if (v >= 1 && n1 % v == 0) P->c2 = v; }
   P->ld1 = P->inplace ? column_stride(n1, P->c1) : n1;
   P->ld2 = P->inplace ? column_stride(n2, P->c2) : n2;
   P->t1 = static_cast<const cd*>(t1); P->t2 = static_cast<const cd*>(t2); P->tf = static_cast<const cd*>(tf);
-  P->stamp = std::getenv("IRA_SMOOTH_STAMP") != nullptr;
+  P->stamp = ira_tune_flag("IRA_SMOOTH_STAMP");
   return IRA_OK;
 }
 
@@ -652,10 +653,9 @@ hipError_t allow(K kernel, size_t bytes) {
 }  // namespace
 
 // n = n1 * n2 with both factors <= 1024 and n = 2^a 3^b 5^c: IRA_OK and the split; otherwise IRA_E_UNSUPPORTED (use the
-// Bluestein entry points).  IRA_NO_SMOOTH_FFT in the environment disables the direct path (A/B switch).
+// Bluestein entry points).  (The A/B switch is the caller's: Engine.smooth_ffts.)
 extern "C" int32_t ira_fft_smooth_split(int32_t n, int32_t* n1, int32_t* n2) {
   IRA_CHECK_PTR(n1); IRA_CHECK_PTR(n2);
-  if (std::getenv("IRA_NO_SMOOTH_FFT") != nullptr) return IRA_E_UNSUPPORTED;
   int a, b;
   if (!smooth_split(n, &a, &b)) return IRA_E_UNSUPPORTED;
   int r[SM_MAX_RADICES];
@@ -725,5 +725,26 @@ extern "C" int32_t ira_band_irfft_smooth(const double* spec_dev, const int64_t* 
   cd* work = reinterpret_cast<cd*>(work_dev);
   smooth_cols_kernel<SM_SPECTRUM><<<dim3(P.n2 / P.c1, nb), SM_THREADS, l1, st>>>(P, J, work);
   smooth_rows_kernel<SM_OUT_BANDS><<<dim3(P.n1 / P.c2, nb), SM_THREADS, l2, st>>>(P, J, work);
+  IRA_RETURN_LAUNCH();
+}
+
+
+// ---- a8 on its own: the band mask values the inverse transforms apply (float32, on the float32 frequency axis) -----------
+namespace {
+__global__ void band_mask_values_kernel(ira::BandMask band, double freq_val, long long nbins, float* __restrict__ out) {
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < nbins) out[k] = ira::mask_at(band, (float)((double)k * freq_val));
+}
+}  // namespace
+
+extern "C" int32_t ira_band_mask_values(const double* band_params8, double freq_val, int64_t nbins, float* mask_dev,
+                                        void* stream) {
+  IRA_CHECK_PTR(band_params8); IRA_CHECK_PTR(mask_dev);
+  if (nbins < 0) return IRA_E_SIZE;
+  if (nbins == 0) return IRA_OK;
+  ira::BandMask b;
+  static_assert(sizeof(ira::BandMask) == 8 * sizeof(double), "band parameter record is 8 doubles");
+  std::memcpy(&b, band_params8, sizeof(b));
+  band_mask_values_kernel<<<(unsigned)((nbins + 255) / 256), 256, 0, (hipStream_t)stream>>>(b, freq_val, nbins, mask_dev);
   IRA_RETURN_LAUNCH();
 }

@@ -23,17 +23,27 @@ __global__ __launch_bounds__(WF_THREADS) void waterfall_kernel(const float* __re
   const float* m = mag + mag_off[e];
   float* o = out + out_off[e];
   const int tid = threadIdx.x;
+  // numpy.max and numpy.clip keep NaN (waterfall.py:318-341): a NaN anywhere in the selection makes the global reference
+  // NaN and with it every relative value; in slice_max mode only the slices that hold one.
+  const float qnan = __uint_as_float(0x7fc00000u);
   float ref_global = -INFINITY;
   if (!slice_max) {
     float mx = -INFINITY;
+    int bad = 0;
     for (int i = tid; i < nsel * S; i += WF_THREADS) {
       const int k = i / S, s = i - k * S;
-      mx = fmaxf(mx, m[(int64_t)(k_lo + k) * S + s]);
+      const float v = m[(int64_t)(k_lo + k) * S + s];
+      bad |= (v != v);
+      mx = fmaxf(mx, v);
     }
     mx = ira::wave_max(mx);
-    if ((tid & 63) == 0) wred[tid >> 6] = mx;
+    bad = __any(bad) ? 1 : 0;
+    if ((tid & 63) == 0) wred[tid >> 6] = bad ? qnan : mx;
     __syncthreads();
-    for (int w = 0; w < WF_THREADS / IRA_WAVE; ++w) ref_global = fmaxf(ref_global, wred[w]);
+    for (int w = 0; w < WF_THREADS / IRA_WAVE; ++w) {
+      const float v = wred[w];
+      ref_global = (v != v || ref_global != ref_global) ? qnan : fmaxf(ref_global, v);
+    }
   } else {
     // per-slice maxima, 64 slices at a time
     for (int s0 = 0; s0 < S; s0 += 64) {
@@ -44,16 +54,18 @@ __global__ __launch_bounds__(WF_THREADS) void waterfall_kernel(const float* __re
       // thread handles slice (tid % ns) over a strided set of bins, then a serialised shared max
       const int s = tid % ns;
       float mx = -INFINITY;
-      for (int k = tid / ns; k < nsel; k += WF_THREADS / ns > 0 ? WF_THREADS / ns : 1)
-        mx = fmaxf(mx, m[(int64_t)(k_lo + k) * S + s0 + s]);
+      for (int k = tid / ns; k < nsel; k += WF_THREADS / ns > 0 ? WF_THREADS / ns : 1) {
+        const float v = m[(int64_t)(k_lo + k) * S + s0 + s];
+        mx = (v != v || mx != mx) ? qnan : fmaxf(mx, v);
+      }
       for (int turn = 0; turn < WF_THREADS; turn += ns) {
-        if (tid >= turn && tid < turn + ns) smax[s] = fmaxf(smax[s], mx);
+        if (tid >= turn && tid < turn + ns) smax[s] = (mx != mx || smax[s] != smax[s]) ? qnan : fmaxf(smax[s], mx);
         __syncthreads();
       }
       for (int i = tid; i < nsel * ns; i += WF_THREADS) {
         const int ss = i / nsel, k = i - ss * nsel;
         float rel = m[(int64_t)(k_lo + k) * S + s0 + ss] - smax[ss];
-        rel = fminf(fmaxf(rel, -dyn), 0.0f);
+        if (rel == rel) rel = fminf(fmaxf(rel, -dyn), 0.0f);
         o[(int64_t)(s0 + ss) * nsel + k] = rel;
       }
     }
@@ -62,7 +74,7 @@ __global__ __launch_bounds__(WF_THREADS) void waterfall_kernel(const float* __re
   for (int i = tid; i < nsel * S; i += WF_THREADS) {
     const int s = i / nsel, k = i - s * nsel;
     float rel = m[(int64_t)(k_lo + k) * S + s] - ref_global;
-    rel = fminf(fmaxf(rel, -dyn), 0.0f);
+    if (rel == rel) rel = fminf(fmaxf(rel, -dyn), 0.0f);
     o[(int64_t)s * nsel + k] = rel;
   }
 }

@@ -21,7 +21,8 @@ __global__ void mag_phase_kernel(const cd* __restrict__ spec, const int64_t* __r
   const cd* s = spec + spec_off[e];
   for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nb; k += (long long)gridDim.x * blockDim.x) {
     const cd v = s[k];
-    const double m = fmax(hypot(v.re, v.im), floor_lin);
+    const double a = hypot(v.re, v.im);
+    const double m = (a != a) ? a : fmax(a, floor_lin);          // numpy.maximum keeps NaN (frequency_response.py:215-218)
     mag_db[mag_off[e] + k] = (float)(20.0 * log10(m));
     if (phase) phase[phase_off[e] + k] = atan2(v.im, v.re);
   }

@@ -19,12 +19,14 @@ __device__ __forceinline__ float mag_to_db(T re, T im, T floor_lin);
 
 template <>
 __device__ __forceinline__ float mag_to_db<float>(float re, float im, float floor_lin) {
-  const float m = fmaxf(sqrtf(re * re + im * im), floor_lin);
+  const float a = sqrtf(re * re + im * im);
+  const float m = (a != a) ? a : fmaxf(a, floor_lin);            // numpy.maximum keeps NaN (spectrogram.py:153-156)
   return 20.0f * log10f(m);
 }
 template <>
 __device__ __forceinline__ float mag_to_db<double>(double re, double im, double floor_lin) {
-  const double m = fmax(hypot(re, im), floor_lin);
+  const double a = hypot(re, im);
+  const double m = (a != a) ? a : fmax(a, floor_lin);            // numpy.maximum keeps NaN (spectrogram.py:153-156)
   return (float)(20.0 * log10(m));
 }
 
@@ -144,8 +146,8 @@ extern "C" int32_t ira_stft_mag_db(const float* x_dev, const int64_t* off_dev, c
   while ((1 << log2n) < n_fft) ++log2n;
   hipStream_t st = (hipStream_t)stream;
   if (precision != 32 && precision != 64) return IRA_E_UNSUPPORTED;
-  static const bool force_generic = std::getenv("IRA_STFT_GENERIC") != nullptr;   // A/B switch for benchmarking
-  static const bool no_v3 = std::getenv("IRA_STFT_NO_V3") != nullptr;             // A/B switch for benchmarking
+  const bool force_generic = ira_tune_flag("IRA_STFT_GENERIC");   // A/B switch for benchmarking
+  const bool no_v3 = ira_tune_flag("IRA_STFT_NO_V3");             // A/B switch for benchmarking
   if (!force_generic && !no_v3) {
     const int32_t rc = ira_stft3_dispatch(x_dev, off_dev, nframes_dev, nseg, max_frames, n_fft, hop, window_dev,
                                           twiddle_dev, precision, floor_db, out_dev, out_off_dev, frame_sel_dev,

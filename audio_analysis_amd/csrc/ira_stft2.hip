@@ -246,6 +246,18 @@ __global__ __launch_bounds__(64 * TW * NT) void stft2_kernel(
       const cplx<T> zm = ex[C::M / 2 + (C::M / 32)];
       mid = power_to_db<T>(zm.re, zm.im, floor_lin, floor_db, ltab);
     }
+    {
+      // A NaN (or infinite) sample anywhere in the frame makes every bin of numpy's rfft NaN (spectrogram.py:150): it shows
+      // in Z[0] = sum of the packed inputs (0 * NaN at the Hann end points is NaN too).  One check per frame instead
+      // of a NaN test per bin: the floor test above maps NaN to the floor, which is right for every other frame.
+      const cplx<T> z0 = ex[0];
+      if (!(z0.re - z0.re == (T)0 && z0.im - z0.im == (T)0)) {
+        const float qn = __uint_as_float(0x7fc00000u);
+#pragma unroll
+        for (int i = 0; i < C::NPAIR; ++i) { lo[i] = qn; hi[i] = qn; }
+        mid = qn;
+      }
+    }
     if (fs == FS - 1) IRA_STAMP(4);
     if (FS == 2 && fs == 0) {
 #pragma unroll
@@ -325,7 +337,7 @@ int32_t launch2(const float* x, const int64_t* off, const int32_t* nframes, int3
     if (e != hipSuccess) return ira_hip_status(e);
   }
   const double floor_lin = std::pow(10.0, floor_db / 20.0);
-  static const int ablate = std::getenv("IRA_STFT2_ABLATE") ? std::atoi(std::getenv("IRA_STFT2_ABLATE")) : 0;
+  const int ablate = ira_tune_int("IRA_STFT2_ABLATE", 0);
   dim3 grid((max_frames + TB - 1) / TB, nseg);
   kern<<<grid, 64 * TW * NT, lds, st>>>(x, off, nframes, hop, static_cast<const T*>(window),
                                         static_cast<const cplx<T>*>(tw), (T)floor_lin, (float)floor_db, out, out_off,

@@ -229,7 +229,20 @@ __global__ __launch_bounds__(64 * NT3) void stft3_kernel(
     lo[i] = db_of(e.re + pp.re, e.im + pp.im, floor_pow, floor_db);
     hi[i] = db_of(e.re - pp.re, e.im - pp.im, floor_pow, floor_db);
   }
-  const float mid = db_of(midr, midi, floor_pow, floor_db);
+  float mid = db_of(midr, midi, floor_pow, floor_db);
+  {
+    // A NaN (or infinite) sample anywhere in the frame makes every bin of numpy's rfft NaN (spectrogram.py:150): it shows
+    // in Z[0] = sum of the packed inputs, which lane 0 holds as its first pair (0 * NaN at the Hann end points is NaN
+    // too).  One check per frame instead of a NaN test per bin (db_of's floor test maps NaN to the floor).
+    const float z0 = (zkr[0] - zkr[0]) + (zki[0] - zki[0]);              // 0 if finite, NaN otherwise
+    const float flag = __shfl(z0, 0, 64);
+    if (flag != 0.0f) {
+      const float qn = __uint_as_float(0x7fc00000u);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { lo[i] = qn; hi[i] = qn; }
+      mid = qn;
+    }
+  }
   IRA_STAMP(2);
 
   if (TF) {
@@ -302,11 +315,12 @@ int32_t launch3(const float* x, const int64_t* off, const int32_t* nframes, int3
   constexpr size_t lds_main = ((TF ? lds_ex : (lds_ex > lds_tile ? lds_ex : lds_tile)) + 15) & ~(size_t)15;
   constexpr size_t lds = lds_main + (size_t)2 * M3 * sizeof(float);          // + the window copy
   static_assert(lds <= 160 * 1024, "one workgroup must fit the CU's LDS");
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&stft3_kernel<NT3, TF>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const hipError_t attr = lds <= 64 * 1024 ? hipSuccess
+                                            : hipFuncSetAttribute(reinterpret_cast<const void*>(&stft3_kernel<NT3, TF>),
+                                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (attr != hipSuccess) return ira_hip_status(attr);
   const double floor_lin = std::pow(10.0, floor_db / 20.0);
-  static const int ablate = std::getenv("IRA_STFT3_ABLATE") ? std::atoi(std::getenv("IRA_STFT3_ABLATE")) : 0;   // diagnostics
+  const int ablate = ira_tune_int("IRA_STFT3_ABLATE", 0);   // diagnostics
   dim3 grid((max_frames + TB3 - 1) / TB3, nseg);
   stft3_kernel<NT3, TF><<<grid, 64 * NT3, lds, st>>>(x, off, nframes, hop, static_cast<const float*>(window),
                                             static_cast<const cf*>(tw), (float)floor_lin, (float)floor_db, out,
@@ -321,7 +335,7 @@ int32_t ira_stft3_dispatch(const float* x, const int64_t* off, const int32_t* nf
                            int32_t precision, double floor_db, float* out, const int64_t* out_off,
                            const int32_t* frame_sel, const int64_t* sel_off, hipStream_t st) {
   if (precision != 32 || n_fft != 4096) return IRA_E_UNSUPPORTED;
-  static const int nt = std::getenv("IRA_STFT3_NT") ? std::atoi(std::getenv("IRA_STFT3_NT")) : 16;   // tuning
+  const int nt = ira_tune_int("IRA_STFT3_NT", 16);   // tuning
   if (nt == 8)
     return launch3<8, false>(x, off, nframes, nseg, max_frames, hop, window, tw, floor_db, out, out_off, frame_sel, sel_off, st);
   if (nt == 4)

@@ -202,6 +202,13 @@ __global__ __launch_bounds__(TL4) void stft4_kernel(
   // ---- post: X[k] = E + P, X[M-k] = conj(E - P) with E = (Zk + conj Zp)/2, P = W_N^k (-i)(Zk - conj Zp)/2 ---------------
   const double floor_pow = floor_lin * floor_lin;
   const cdd wlane = tw[q];
+  // A NaN (or infinite) sample anywhere in the frame makes every bin of numpy's rfft NaN (modalcloud.py:150): it shows in
+  // Z[0] = sum of the packed inputs (lane 0, first pair; 0 * NaN at the Hann end points is NaN too).  One check per frame.
+  __shared__ int frame_bad;
+  if (q == 0) frame_bad = !((zkr[0] - zkr[0]) + (zki[0] - zki[0]) == 0.0) ? 1 : 0;
+  __syncthreads();
+  const bool bad_frame = frame_bad != 0;
+  const float qnan32 = __uint_as_float(0x7fc00000u);
   if (lb_nbins <= 0) {
     // ---- frame-major dB matrix ---------------------------------------------------------------------------------------
     float* fo = out + out_off[seg] + (int64_t)col * F4;
@@ -213,10 +220,10 @@ __global__ __launch_bounds__(TL4) void stft4_kernel(
       const cdd o = {d.im, -d.re};
       const cdd wk = ira::cmul(wlane, tw[TL4 * i]);        // W_N^k = W_N^q W_N^(128 i); second factor wave-uniform
       const cdd pp = ira::cmul(wk, o);
-      fo[k] = db_of4(e.re + pp.re, e.im + pp.im, floor_pow, floor_db, ltab);
-      fo[M4 - k] = db_of4(e.re - pp.re, e.im - pp.im, floor_pow, floor_db, ltab);       // k = 0 -> bin M (Nyquist)
+      fo[k] = bad_frame ? qnan32 : db_of4(e.re + pp.re, e.im + pp.im, floor_pow, floor_db, ltab);
+      fo[M4 - k] = bad_frame ? qnan32 : db_of4(e.re - pp.re, e.im - pp.im, floor_pow, floor_db, ltab);   // k = 0 -> bin M
     }
-    if (q == 0) fo[M4 / 2] = db_of4(midr, midi, floor_pow, floor_db, ltab);
+    if (q == 0) fo[M4 / 2] = bad_frame ? qnan32 : db_of4(midr, midi, floor_pow, floor_db, ltab);
     return;
   }
 
@@ -276,7 +283,7 @@ __global__ __launch_bounds__(TL4) void stft4_kernel(
       }
       v = (float)(20.0 * log10(fmax(acc / (double)c, 1e-30)));
     }
-    co[(int64_t)b * T_out + col] = v;
+    co[(int64_t)b * T_out + col] = (bad_frame && c > 0) ? qnan32 : v;      // mean of NaN magnitudes (modalcloud.py:186-200)
   }
 }
 

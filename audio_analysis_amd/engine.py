@@ -179,6 +179,28 @@ class Engine:
         src = self._ring[pos : pos + nbytes].view(_TORCH_DTYPES(t)[a.dtype.str]).view(a.shape)
         return src.to(self.device, non_blocking=True)
 
+    def to_dev_pack(self, *arrays):
+        """Several small host arrays -> ONE write into the pinned staging ring and ONE asynchronous H2D copy; returns the
+        device views in order (None entries stay None).  A call's job tables (offsets, lengths, indices ...) used to be
+        one copy each: 65 copy-engine operations of ~5 us per report step (profiles/r02_*: __amd_rocclr_copyBuffer), each
+        serialised with the kernels of its stream."""
+        t = self.torch
+        items = [(i, np.ascontiguousarray(a)) for i, a in enumerate(arrays) if a is not None]
+        total = sum(((a.nbytes + 15) & ~15) for _, a in items)
+        if not items or total == 0 or total > self._ASYNC_LIMIT or any(a.nbytes == 0 for _, a in items):
+            return [None if a is None else self.to_dev(a) for a in arrays]
+        blob = np.zeros(total, dtype=np.uint8)
+        spans, pos = [], 0
+        for i, a in items:
+            blob[pos : pos + a.nbytes] = a.view(np.uint8).reshape(-1)
+            spans.append((i, pos, a))
+            pos += (a.nbytes + 15) & ~15
+        dev = self.to_dev(blob)
+        out = [None] * len(arrays)
+        for i, pos, a in spans:
+            out[i] = dev[pos : pos + a.nbytes].view(_TORCH_DTYPES(t)[a.dtype.str]).view(a.shape)
+        return out
+
     def empty(self, n: int, dtype):
         return self.torch.empty(int(max(n, 1)), dtype=dtype, device=self.device)
 
@@ -266,10 +288,22 @@ class Engine:
             flat[o : o + n] = c.astype(np.float32, copy=False)
         return self.wrap(self.to_dev(flat), off, lens)
 
+    def subset(self, b: ChannelBatch, idx: np.ndarray) -> ChannelBatch:
+        """The channels idx of a batch as a batch of their own: same sample buffer, their offsets / lengths / peaks.
+        (Its ready event is recorded behind the new offset/length uploads; the samples themselves are already resident:
+        whoever knows the peaks has waited for the batch's upload.)"""
+        idx = np.asarray(idx, dtype=np.int64)
+        sub = self.wrap(b.x, b.off[idx], b.length[idx])
+        if b.peak is not None:
+            sub.peak = b.peak[idx].copy()
+            sub.peak_abs = b.peak_abs[idx].copy() if b.peak_abs is not None else None
+        return sub
+
     def wrap(self, x_dev, off: np.ndarray, lens: np.ndarray) -> ChannelBatch:
         off = np.ascontiguousarray(off, dtype=np.int64)
         lens = np.ascontiguousarray(lens, dtype=np.int64)
-        b = ChannelBatch(x=x_dev, off=off, length=lens, off_dev=self.to_dev(off), len_dev=self.to_dev(lens))
+        d_off, d_len = self.to_dev_pack(off, lens)
+        b = ChannelBatch(x=x_dev, off=off, length=lens, off_dev=d_off, len_dev=d_len)
         b.ready = self.torch.cuda.Event()
         b.ready.record(self.torch.cuda.current_stream(self.device))
         return b
@@ -359,7 +393,7 @@ class Engine:
         scratch = self.empty(n * EDC_SCRATCH_DOUBLES, t.float64)
         # NOTE: device temporaries must stay referenced until the call is enqueued (the caching allocator
         # would otherwise hand the same block to the next to_dev()).
-        d_off, d_len, d_eoff = self.to_dev(seg_off), self.to_dev(seg_len), self.to_dev(edc_off)
+        d_off, d_len, d_eoff = self.to_dev_pack(seg_off, seg_len, edc_off)
         check(self.lib.ira_edc_db(_ptr(x_dev), _ptr(d_off), _ptr(d_len), n, int(seg_len.max()), float(eps),
                                   float(floor_db), _ptr(out),
                                   _ptr(out64), _ptr(d_eoff), _ptr(scratch), self.stream), "ira_edc_db")
@@ -388,8 +422,8 @@ class Engine:
         out = self.empty(int(seg_len.sum()), t.float32) if want_edc else None
         scratch = self.empty(n * EDC_SCRATCH_DOUBLES, t.float64)
         flat = [v for r in ranges for v in r]
-        d_off, d_len = self.to_dev(np.ascontiguousarray(seg_off, np.int64)), self.to_dev(seg_len)
-        d_eoff = self.to_dev(edc_off) if want_edc else None
+        d_off, d_len, d_eoff = self.to_dev_pack(np.ascontiguousarray(seg_off, np.int64), seg_len,
+                                                edc_off if want_edc else None)
         check(self.lib.ira_edc_fits(_ptr(x_dev), _ptr(d_off), _ptr(d_len), n, int(seg_len.max()) if n else 0,
                                     float(eps), float(floor_db), float(t_mul), float(t_div), _lib.dbl_array(flat), nr,
                                     int(min_points), _lib.dbl_array(list(cross)), nc, _ptr(fit), _ptr(cr), _ptr(out),
@@ -409,7 +443,7 @@ class Engine:
         fit = self.empty(n * max(nr, 1) * FIT_DOUBLES, t.float64)
         cr = self.empty(n * max(nc, 1), t.float64)
         flat = [v for r in ranges for v in r]
-        d_off, d_len = self.to_dev(off), self.to_dev(lens)
+        d_off, d_len = self.to_dev_pack(off, lens)
         check(self.lib.ira_curve_fits(_ptr(y_dev), _ptr(d_off), _ptr(d_len), n,
                                       int(lens.max()) if n else 0, float(t_mul), float(t_div), _ptr(t_axis_dev),
                                       _lib.dbl_array(flat), nr,
@@ -432,13 +466,18 @@ class Engine:
         t = self.torch
         n = int(seg_off.size)
         f = n_fft // 2 + 1
+        if self.stft_generic_needed(n_fft):
+            return self._stft_generic(x_dev, seg_off, nframes, int(n_fft), int(hop), use_hann, floor_db, frame_sel,
+                                      frame_major)
         if frame_sel is not None:
             cols = np.array([int(s.size) for s in frame_sel], dtype=np.int32)
             sel_off = np.zeros(n, dtype=np.int64)
             if n > 1:
                 sel_off[1:] = np.cumsum(cols[:-1])
-            sel = self.to_dev(np.concatenate(frame_sel).astype(np.int32)) if cols.sum() else self.empty(1, t.int32)
-            sel_off_dev = self.to_dev(sel_off)
+            if cols.sum():
+                sel, sel_off_dev = self.to_dev_pack(np.concatenate(frame_sel).astype(np.int32), sel_off)
+            else:
+                sel, sel_off_dev = self.empty(1, t.int32), self.to_dev(sel_off)
         else:
             cols = np.ascontiguousarray(nframes, dtype=np.int32)
             sel = None
@@ -448,7 +487,7 @@ class Engine:
         if n > 1:
             out_off[1:] = np.cumsum(sizes[:-1])
         out = self.empty(int(sizes.sum()), t.float32)
-        d_off, d_cols, d_ooff = self.to_dev(seg_off), self.to_dev(cols), self.to_dev(out_off)
+        d_off, d_cols, d_ooff = self.to_dev_pack(seg_off, cols, out_off)
         self.event_tag = f"[f{precision},n{n_fft}{',sel' if frame_sel is not None else ''}]"
         fn = self.lib.ira_stft_mag_db_tf if frame_major else self.lib.ira_stft_mag_db
         check(fn(_ptr(x_dev), _ptr(d_off), _ptr(d_cols), n, int(cols.max()) if n else 0, int(n_fft), int(hop),
@@ -470,8 +509,8 @@ class Engine:
         if n > 1:
             out_off[1:] = np.cumsum(sizes[:-1])
         out = self.empty(int(sizes.sum()), t.float32)
-        d_off, d_cols, d_ooff = self.to_dev(seg_off), self.to_dev(cols), self.to_dev(out_off)
-        d_f, d_c = self.to_dev(first.astype(np.int32)), self.to_dev(count.astype(np.int32))
+        d_off, d_cols, d_ooff, d_f, d_c = self.to_dev_pack(seg_off, cols, out_off, first.astype(np.int32),
+                                                           count.astype(np.int32))
         self.event_tag = f"[f64,n{n_fft}]"
         check(self.lib.ira_stft_logbin(_ptr(x_dev), _ptr(d_off), _ptr(d_cols), n, int(cols.max()) if n else 0,
                                        int(n_fft), int(hop), _ptr(self.window(n_fft, use_hann, 64)),
@@ -481,13 +520,57 @@ class Engine:
         return out, out_off
 
     @staticmethod
+    def stft_generic_needed(n_fft: int) -> bool:
+        """Frame sizes the register / LDS STFT kernels do not take (they need a power of two in [64, 16384]): the reference
+        accepts any positive n_fft (numpy.fft.rfft of arbitrary length, spectrogram.py:150), e.g. `--nfft 6000`."""
+        n = int(n_fft)
+        return n < 64 or n > 16384 or (n & (n - 1)) != 0
+
+    def _stft_generic(self, x_dev, seg_off, nframes, n_fft: int, hop: int, use_hann: bool, floor_db: float, frame_sel,
+                      frame_major: bool):
+        """STFT of an arbitrary frame size through the arbitrary-length transforms: every frame is one element of
+        ira_rfft_any / ira_rfft_smooth (float64, Hann window of length n_fft = numpy.hanning(n_fft), frames of equal length
+        ride two per complex transform), then ira_spectrum_mag_phase's dB conversion (the same max(|X|, 10^(floor/20))
+        -> 20 log10 -> float32 as a11).  The natural result is frame-major (T, F); the (F, T) layout of the reference is
+        produced by a per-segment transposed copy (plumbing, only when a caller asks for it)."""
+        t = self.torch
+        n = int(seg_off.size)
+        f = n_fft // 2 + 1
+        if frame_sel is not None:
+            frames = [np.asarray(s_, dtype=np.int64) for s_ in frame_sel]
+        else:
+            frames = [np.arange(int(c), dtype=np.int64) for c in nframes]
+        cols = np.array([fr.size for fr in frames], dtype=np.int32)
+        sizes = cols.astype(np.int64) * f
+        out_off = np.zeros(n, dtype=np.int64)
+        if n > 1:
+            out_off[1:] = np.cumsum(sizes[:-1])
+        total_frames = int(cols.sum())
+        if total_frames == 0:
+            return self.empty(1, t.float32), out_off, cols
+        xoff = np.concatenate([int(seg_off[i]) + fr * int(hop) for i, fr in enumerate(frames)])
+        lengths = np.full(total_frames, n_fft, dtype=np.int32)
+        spec, spec_off = self.rfft_any(x_dev, xoff, lengths, bool(use_hann))
+        mag, _ = self.spectrum_mag_phase(spec, spec_off, lengths, float(floor_db), want_phase=False)
+        if frame_major:
+            return mag, out_off, cols
+        out = self.empty(int(sizes.sum()), t.float32)
+        for i in range(n):
+            c = int(cols[i])
+            if c:
+                o = int(out_off[i])
+                out[o : o + c * f].view(f, c).copy_(mag[o : o + c * f].view(c, f).t())
+        return out, out_off, cols
+
+    @staticmethod
     def stft_logbin_ok(n_fft: int) -> bool:
         return int(n_fft) == 8192
 
     @staticmethod
     def stft_frame_major_ok(n_fft: int, precision: int) -> bool:
-        """Configurations ira_stft_mag_db_tf implements."""
-        return (int(n_fft), int(precision)) in ((4096, 32), (8192, 64))
+        """Configurations that deliver the frame-major (T, F) layout directly: ira_stft_mag_db_tf's, and every frame size
+        that goes through the arbitrary-length path (_stft_generic)."""
+        return (int(n_fft), int(precision)) in ((4096, 32), (8192, 64)) or Engine.stft_generic_needed(n_fft)
 
     # ------------------------------------------------------------------ a9/a17: arbitrary-length f64 DFTs
     workspace_budget_bytes = 48 << 30   # cap for the Bluestein work + filter arrays of one chunk
@@ -672,21 +755,20 @@ class Engine:
                 else:
                     j1, j2 = idx.astype(np.int64), np.full(idx.size, -1, dtype=np.int64)
                 work = self.empty(int(j1.size) * 2 * int(L), t.float64)
-                d_xo, d_so = self.to_dev(xoff[j1]), self.to_dev(spec_off[j1])
                 paired = j2 >= 0
                 safe = np.maximum(j2, 0)
+                a_x2 = a_so2 = a_zo = zpair = None
                 if paired.any():
-                    d_x2 = self.to_dev(np.where(paired, xoff[safe], -1).astype(np.int64))
-                    d_so2 = self.to_dev(np.where(paired, spec_off[safe], 0).astype(np.int64))
+                    a_x2 = np.where(paired, xoff[safe], -1).astype(np.int64)
+                    a_so2 = np.where(paired, spec_off[safe], 0).astype(np.int64)
                     zoff = np.cumsum(np.where(paired, int(L), 0)) - np.where(paired, int(L), 0)
                     zpair = self.empty(int(paired.sum()) * 2 * int(L), t.float64)
-                    d_zo = self.to_dev(zoff.astype(np.int64))
-                else:
-                    d_x2 = d_so2 = zpair = d_zo = None
-                d_dl = d_wl = d_dl2 = d_wl2 = None
+                    a_zo = zoff.astype(np.int64)
+                a_dl = a_wl = a_dl2 = a_wl2 = None
                 if padded:
-                    d_dl, d_wl = self.to_dev(data_len[j1]), self.to_dev(win_len[j1])
-                    d_dl2, d_wl2 = self.to_dev(data_len[safe]), self.to_dev(win_len[safe])
+                    a_dl, a_wl, a_dl2, a_wl2 = data_len[j1], win_len[j1], data_len[safe], win_len[safe]
+                d_xo, d_so, d_x2, d_so2, d_zo, d_dl, d_wl, d_dl2, d_wl2 = self.to_dev_pack(
+                    xoff[j1], spec_off[j1], a_x2, a_so2, a_zo, a_dl, a_wl, a_dl2, a_wl2)
                 check(self.lib.ira_rfft_smooth(_ptr(x_dev), _ptr(d_xo), int(L), int(j1.size), 1 if use_hann else 0,
                                                _ptr(t1), _ptr(t2), _ptr(tf), _ptr(work), _ptr(spec), _ptr(d_so),
                                                _ptr(d_x2), _ptr(d_so2), _ptr(zpair), _ptr(d_zo), _ptr(d_dl), _ptr(d_wl),
@@ -714,30 +796,27 @@ class Engine:
             j1, j2, jh, jl = e1[sel], e2[sel], half[sel], jlen[sel]
             bf, bidx = self._filters(jl, lm)
             work = self.empty(int(sel.size) * (2 << lm), t.float64)
-            d_xo, d_l = self.to_dev(xoff[j1]), self.to_dev(jl)
-            d_bi, d_so = self.to_dev(bidx), self.to_dev(spec_off[j1])
             paired = j2 >= 0
             two = paired | jh                                   # jobs that carry a second "signal"
             safe = np.maximum(j2, 0)
+            a_x2 = a_so2 = a_zo = zpair = None
             if two.any():
-                x2 = np.where(jh, xoff[j1] + 1, np.where(paired, xoff[safe], -1))
-                d_x2 = self.to_dev(x2.astype(np.int64))
-                d_so2 = self.to_dev(np.where(paired, spec_off[safe], 0).astype(np.int64))
+                a_x2 = np.where(jh, xoff[j1] + 1, np.where(paired, xoff[safe], -1)).astype(np.int64)
+                a_so2 = np.where(paired, spec_off[safe], 0).astype(np.int64)
                 zlen = np.where(two, jl.astype(np.int64), 0)
-                zoff = np.cumsum(zlen) - zlen
+                a_zo = (np.cumsum(zlen) - zlen).astype(np.int64)
                 zpair = self.empty(int(zlen.sum()) * 2, t.float64)
-                d_zo = self.to_dev(zoff.astype(np.int64))
-            else:
-                d_x2 = d_so2 = zpair = d_zo = None
-            d_dl = d_wl = d_dl2 = d_wl2 = d_il = None
+            a_dl = a_wl = a_dl2 = a_wl2 = a_il = None
             if padded:
-                d_dl, d_wl = self.to_dev(data_len[j1]), self.to_dev(win_len[j1])
-                d_dl2, d_wl2 = self.to_dev(data_len[safe]), self.to_dev(win_len[safe])
+                a_dl, a_wl, a_dl2, a_wl2 = data_len[j1], win_len[j1], data_len[safe], win_len[safe]
             elif jh.any():
-                wl = np.where(jh, lengths[j1], jl).astype(np.int32)       # the Hann window belongs to the REAL signal
-                d_dl, d_wl = self.to_dev(jl), self.to_dev(wl)
+                a_dl = jl
+                a_wl = np.where(jh, lengths[j1], jl).astype(np.int32)       # the Hann window belongs to the REAL signal
+                a_il = jh.astype(np.int32)
+            d_xo, d_l, d_bi, d_so, d_x2, d_so2, d_zo, d_dl, d_wl, d_dl2, d_wl2, d_il = self.to_dev_pack(
+                xoff[j1], jl, bidx, spec_off[j1], a_x2, a_so2, a_zo, a_dl, a_wl, a_dl2, a_wl2, a_il)
+            if not padded and a_dl is not None:
                 d_dl2, d_wl2 = d_dl, d_wl
-                d_il = self.to_dev(jh.astype(np.int32))
             check(self.lib.ira_rfft_any(_ptr(x_dev), _ptr(d_xo), _ptr(d_l), int(sel.size), 1 if use_hann else 0, lm,
                                         _ptr(t1), _ptr(t2), _ptr(tf), _ptr(bf), _ptr(d_bi), _ptr(work), _ptr(spec),
                                         _ptr(d_so), _ptr(d_x2), _ptr(d_so2), _ptr(zpair), _ptr(d_zo), int(jl.max()),
@@ -782,12 +861,9 @@ class Engine:
             t1, t2, tf = self.smooth_tables(int(L))
             for sel in self._chunks_of(grp, 16 * int(L)):
                 work = self.empty(int(sel.size) * 2 * int(L), t.float64)
-                d_so = self.to_dev(spec_off[j1][sel])
-                d_bp = self.to_dev(np.ascontiguousarray(el_par[sel]))
-                d_fv = self.to_dev(np.ascontiguousarray(freq_val[j1][sel]))
-                d_y1 = self.to_dev(np.ascontiguousarray(y_off[j1][sel]))
-                d_y2 = self.to_dev(np.ascontiguousarray(el_y2[sel]))
-                d_so2 = self.to_dev(np.ascontiguousarray(el_so2[sel]))
+                d_so, d_bp, d_fv, d_y1, d_y2, d_so2 = self.to_dev_pack(
+                    spec_off[j1][sel], np.ascontiguousarray(el_par[sel]), np.ascontiguousarray(freq_val[j1][sel]),
+                    np.ascontiguousarray(y_off[j1][sel]), np.ascontiguousarray(el_y2[sel]), np.ascontiguousarray(el_so2[sel]))
                 check(self.lib.ira_band_irfft_smooth(_ptr(spec_dev), _ptr(d_so), int(L), int(sel.size), _ptr(d_bp),
                                                      _ptr(d_fv), _ptr(t1), _ptr(t2), _ptr(tf), _ptr(work), _ptr(y_dev),
                                                      _ptr(d_y1), _ptr(d_y2), _ptr(d_so2), self.stream),
@@ -821,7 +897,7 @@ class Engine:
         total = int((lengths.astype(np.int64) // 2 + 1).sum())
         mag = self.empty(total, t.float32)
         ph = self.empty(total, t.float64) if want_phase else None
-        d_so, d_l = self.to_dev(spec_off), self.to_dev(lengths)
+        d_so, d_l = self.to_dev_pack(spec_off, lengths)
         check(self.lib.ira_spectrum_mag_phase(_ptr(spec_dev), _ptr(d_so), _ptr(d_l), n, int(lengths.max()),
                                               float(floor_db), _ptr(mag), _ptr(d_so), _ptr(ph), _ptr(d_so),
                                               self.stream), "ira_spectrum_mag_phase")
@@ -834,7 +910,7 @@ class Engine:
         lengths = np.ascontiguousarray(lengths, dtype=np.int32)
         total = int((lengths.astype(np.int64) // 2 + 1).sum())
         out = self.empty(total, t.float64 if as_float64 else t.float32)
-        d_o, d_l = self.to_dev(off), self.to_dev(lengths)
+        d_o, d_l = self.to_dev_pack(off, lengths)
         check(self.lib.ira_phase_unwrap(_ptr(phase_dev), _ptr(d_o), _ptr(d_l), int(off.size), 1 if unwrap else 0,
                                         1 if degrees else 0, 0 if as_float64 else _ptr(out), _ptr(d_o),
                                         _ptr(out) if as_float64 else 0, self.stream), "ira_phase_unwrap")
@@ -906,7 +982,7 @@ class Engine:
         n = int(off.size)
         lengths = np.ascontiguousarray(lengths, dtype=np.int32)
         out = self.empty(n * 8, t.float64)
-        d_o, d_l, d_fv = self.to_dev(off), self.to_dev(lengths), self.to_dev(np.ascontiguousarray(freq_val, np.float64))
+        d_o, d_l, d_fv = self.to_dev_pack(off, lengths, np.ascontiguousarray(freq_val, np.float64))
         check(self.lib.ira_spectrum_stats(_ptr(mag_dev), _ptr(d_o), _ptr(d_l), n, _ptr(d_fv), float(f_min),
                                           float(f_max), float(probe_hz), _ptr(out), self.stream), "ira_spectrum_stats")
         return out[: n * 8].view(n, 8)
@@ -923,7 +999,7 @@ class Engine:
         if n > 1:
             out_off[1:] = np.cumsum(sizes[:-1])
         out = self.empty(int(sizes.sum()), t.float32)
-        d_mo, d_ns, d_oo = self.to_dev(mag_off), self.to_dev(nslices), self.to_dev(out_off)
+        d_mo, d_ns, d_oo = self.to_dev_pack(mag_off, nslices, out_off)
         check(self.lib.ira_waterfall_rel(_ptr(mag_dev), _ptr(d_mo), _ptr(d_ns), n, int(k_lo), int(nsel),
                                          1 if slice_max else 0, float(dyn_db), _ptr(out), _ptr(d_oo), self.stream),
               "ira_waterfall_rel")
@@ -964,13 +1040,19 @@ class Engine:
         gs = self.empty(n * order * order, t.float64) if order > 128 else None
         coeffs = self.empty(n * (order + 1), t.float64)
         info = self.empty(n * 4, t.float64)
-        d_xo, d_l = self.to_dev(np.ascontiguousarray(xoff, np.int64)), self.to_dev(lengths)
-        d_div = self.to_dev(np.ascontiguousarray(divisor, np.float64)) if divisor is not None else None
+        d_xo, d_l, d_div = self.to_dev_pack(np.ascontiguousarray(xoff, np.int64), lengths,
+                                            np.ascontiguousarray(divisor, np.float64) if divisor is not None else None)
+        flags = 1 if self.ar_dense_gram else 0                 # IRA_AR_DENSE_GRAM
         check(self.lib.ira_ar_gram(0 if x_is_f64 else _ptr(x_dev), _ptr(x_dev) if x_is_f64 else 0, _ptr(d_xo),
-                                   _ptr(d_l), _ptr(d_div), n, max_len, int(order), _ptr(part), self.stream),
+                                   _ptr(d_l), _ptr(d_div), n, max_len, int(order), _ptr(part), flags, self.stream),
               "ira_ar_gram")
         check(self.lib.ira_ar_solve(_ptr(part), _ptr(d_l), n, max_len, int(order), float(ridge), _ptr(gs),
-                                    _ptr(coeffs), _ptr(info), self.stream), "ira_ar_solve")
+                                    _ptr(coeffs), _ptr(info), flags, self.stream), "ira_ar_solve")
+        if ridge == 0.0 and order <= 512 and self.ar_minnorm_cut > 0.0 and not self.ar_dense_gram:
+            # conditional on the device: only elements whose Cholesky failed (rank-deficient Gram matrix) do any work
+            scratch2 = self.empty(n * 2 * order * order, t.float64)
+            check(self.lib.ira_ar_minnorm(_ptr(part), _ptr(d_l), n, max_len, int(order), _ptr(scratch2), _ptr(coeffs),
+                                          _ptr(info), float(self.ar_minnorm_cut), self.stream), "ira_ar_minnorm")
         if ridge == 0.0 and self.ar_refine_steps > 0:
             # conditional on the device: only elements whose pivots show cond(G) > threshold do any work
             nchunks = -(-(max_len - int(order)) // 4096)
@@ -978,10 +1060,15 @@ class Engine:
             check(self.lib.ira_ar_refine(0 if x_is_f64 else _ptr(x_dev), _ptr(x_dev) if x_is_f64 else 0, _ptr(d_xo),
                                          _ptr(d_l), _ptr(d_div), n, max_len, int(order), _ptr(part), _ptr(gs),
                                          _ptr(coeffs), _ptr(info), _ptr(grad), float(self.ar_refine_cond),
-                                         int(self.ar_refine_steps), self.stream), "ira_ar_refine")
+                                         int(self.ar_refine_steps), flags, self.stream), "ira_ar_refine")
         return coeffs[: n * (order + 1)].view(n, order + 1), info[: n * 4].view(n, 4)
 
     # Normal equations lose cond(A)^2 eps; above this cond(G) estimate the fit gets refinement steps (ira_ar_refine).
+    # Rank-deficient Gram matrices (Cholesky pivot <= 0) get the minimum-norm solution lstsq returns (ira_ar_minnorm):
+    # eigen-directions with lambda <= cut * lambda_max are dropped.  0 disables the fallback.
+    ar_minnorm_cut = 1e-12
+    # A/B: form the Gram matrix as a dense contraction on the FP64 matrix cores (IRA_AR_DENSE_GRAM) instead of the lag sums
+    ar_dense_gram = False
     ar_refine_cond = 1e9          # on the estimate trace(G) ||G^-1|| (<= order * cond(G))
     ar_refine_steps = 2
 

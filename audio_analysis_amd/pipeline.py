@@ -43,6 +43,34 @@ M_GD_MEDIAN, M_GD_P10, M_GD_P90 = 122, 123, 124        # section 8f blocks (off 
 M_DIFF_AC_MEDIAN, M_DIFF_ED_MEDIAN = 125, 126
 METRICS_WIDTH = 128
 
+# ---- per-IR status (M_STATUS): 0 = analysed; otherwise the bit of the FIRST report block, in the reference's block order
+# (report.py:252-386, then the filter / zplane commands), that would have raised ValueError for this channel -- the
+# reference aborts the file there (bundle.py:56-67 propagates it).  In a device batch the other channels proceed: the
+# failing channel keeps NaN metrics and this code, one bad IR does not poison a batch.
+ST_OK = 0
+ST_DECAY_TOO_SHORT = 1          # decay.py:146-147      "Not enough samples after trimming/ignoring to compute EDC."
+ST_BANDS_TOO_SHORT = 2          # rt60bands.py:346-347  "Not enough samples for rt60bands analysis."
+ST_FR_TOO_SHORT = 4             # frequency_response.py:201-202
+ST_SPECTROGRAM_TOO_SHORT = 8    # spectrogram.py:197-198 (need at least n_fft samples)
+ST_WATERFALL_TOO_SHORT = 16     # waterfall.py:375-376
+ST_MODAL_TOO_SHORT = 32         # modalcloud.py:315-316
+ST_FILTER_TOO_SHORT = 64        # filterplot.py:141-142
+ST_ZPLANE_TOO_SHORT = 128       # zplane.py: fewer than two samples after the time selection
+ST_EMPTY_FREQUENCY_RANGE = 256  # frequency_response.py:244-245 (set from the device statistics record)
+ST_ZPLANE_NOT_FINITE = 512      # zplane.py:117: numpy.linalg.lstsq raises LinAlgError on NaN / infinite samples
+STATUS_MESSAGES = {
+    ST_DECAY_TOO_SHORT: "Not enough samples after trimming/ignoring to compute EDC.",
+    ST_BANDS_TOO_SHORT: "Not enough samples for rt60bands analysis.",
+    ST_FR_TOO_SHORT: "Not enough samples after trimming/selection to analyse spectrum.",
+    ST_SPECTROGRAM_TOO_SHORT: "Not enough samples after trimming/selection for spectrogram (need at least n_fft).",
+    ST_WATERFALL_TOO_SHORT: "Not enough samples after trimming/selection for waterfall (need at least n_fft).",
+    ST_MODAL_TOO_SHORT: "Not enough samples after trimming/selection for modal cloud (need at least n_fft).",
+    ST_FILTER_TOO_SHORT: "Not enough samples after trimming/selection to analyse filter response.",
+    ST_ZPLANE_TOO_SHORT: "Not enough samples after trimming/selection for the AR fit.",
+    ST_EMPTY_FREQUENCY_RANGE: "Selected frequency range is empty.",
+    ST_ZPLANE_NOT_FINITE: "SVD did not converge in Linear Least Squares",
+}
+
 
 @dataclass(frozen=True)
 class FullReportSettings:
@@ -113,16 +141,82 @@ class FullReport:
     # Calling submit(next batch) BEFORE finish(previous) keeps the GPU busy while the host post-processes: the one
     # host round trip a step needs (the peak pick that fixes every block's geometry) runs on a high-priority side
     # stream, so it is not queued behind the previous step's kernels.
+    def channel_status(self, batch: ChannelBatch) -> np.ndarray:
+        """Per-channel status codes (ST_*) from lengths, peaks and settings alone -- every "too short" ValueError of the
+        reference's blocks is a pure function of those.  Needs batch.peak."""
+        from .analyse._common import segment_bounds
+        s, sr = self.s, self.s.sample_rate_hz
+        n = batch.count
+        st = np.zeros(n, dtype=np.int64)
+        peaks = batch.peak if batch.peak is not None else np.zeros(n, dtype=np.int64)
+
+        def seg_len(i, cfg, duration=True):
+            trim = bool(cfg.trim_to_peak)
+            dur = getattr(cfg, "analysis_duration_seconds", None) if duration else None
+            return segment_bounds(int(batch.length[i]), int(peaks[i]) if trim else 0, sr, trim,
+                                  float(cfg.ignore_leading_seconds), dur)[1]
+
+        checks = []
+        if s.run_decay:
+            checks.append((ST_DECAY_TOO_SHORT, lambda i: seg_len(i, s.decay, duration=False) < 4))
+        if s.run_rt60_bands:
+            checks.append((ST_BANDS_TOO_SHORT, lambda i: int(batch.length[i]) < 8))
+        if s.run_frequency_response:
+            checks.append((ST_FR_TOO_SHORT, lambda i: seg_len(i, s.frequency_response) < 32))
+        if s.run_spectrogram:
+            checks.append((ST_SPECTROGRAM_TOO_SHORT, lambda i: seg_len(i, s.spectrogram) < int(s.spectrogram.n_fft)))
+        if s.run_waterfall:
+            checks.append((ST_WATERFALL_TOO_SHORT, lambda i: seg_len(i, s.waterfall) < int(s.waterfall.n_fft)))
+        if s.run_modal_cloud:
+            checks.append((ST_MODAL_TOO_SHORT, lambda i: seg_len(i, s.modal_cloud) < int(s.modal_cloud.n_fft)))
+        if s.run_filter:
+            checks.append((ST_FILTER_TOO_SHORT, lambda i: seg_len(i, s.filter) < 32))
+        if s.run_zplane:
+            def z_short(i):
+                z = s.zplane
+                skip = int(round(float(z.ignore_leading_seconds) * sr))
+                start = min(max((int(peaks[i]) if z.trim_to_peak else 0) + skip, 0), int(batch.length[i]))
+                left = int(batch.length[i]) - start
+                if z.analysis_duration_seconds is not None:
+                    left = min(max(1, int(round(float(z.analysis_duration_seconds) * sr))), left)
+                return left < 2
+            checks.append((ST_ZPLANE_TOO_SHORT, z_short))
+        # the common case costs one vectorised comparison: nothing can fail when the shortest post-peak tail is long
+        need = max([8, 32] + [int(c.n_fft) for c, on in ((s.spectrogram, s.run_spectrogram), (s.waterfall, s.run_waterfall),
+                                                        (s.modal_cloud, s.run_modal_cloud)) if on])
+        margin = int(sr * 0.5)
+        if n and int(np.min(batch.length - peaks)) >= need + margin and not any(
+                getattr(c, "analysis_duration_seconds", None) is not None or float(c.ignore_leading_seconds) > 0.4
+                for c in (s.decay, s.frequency_response, s.filter, s.spectrogram, s.waterfall, s.modal_cloud, s.zplane)):
+            return st
+        for i in range(n):
+            for code, bad in checks:
+                if bad(i):
+                    st[i] = code                          # the FIRST failing block, like the reference's abort
+                    break
+        return st
+
     def submit(self, batch: ChannelBatch) -> dict:
+        """Enqueue one step.  Channels the reference would refuse (too few samples for an enabled block) are left out of
+        the device work and come back with their status code and NaN metrics; the rest of the batch proceeds."""
+        eng = self.eng
+        if batch.peak is None:
+            eng.peaks_begin(batch)                         # side stream, behind the upload of this batch and nothing else
+            eng.peaks(batch)                               # the one host round trip every block's geometry needs
+        status = self.channel_status(batch)
+        if not status.any():
+            return self._submit_valid(batch)
+        good = np.nonzero(status == 0)[0]
+        h = self._submit_valid(eng.subset(batch, good)) if good.size else None
+        return dict(scatter=True, inner=h, good=good, status=status, n=batch.count, length=batch.length.copy())
+
+    def _submit_valid(self, batch: ChannelBatch) -> dict:
         eng, s, sr = self.eng, self.s, self.s.sample_rate_hz
         t = eng.torch
         n = batch.count
         m = np.full((n, METRICS_WIDTH), np.nan, dtype=np.float64)
         m[:, M_STATUS] = 0.0
         m[:, M_NSAMPLES] = batch.length
-        if batch.peak is None:
-            eng.peaks_begin(batch)                         # side stream, behind the upload of this batch and nothing else
-            eng.peaks(batch)                               # the one host round trip every block's geometry needs
         res: Dict[str, dict] = {}
         fut: Dict[str, object] = {}
         state = {"spectrum": None, "filt": None}
@@ -188,7 +282,7 @@ class FullReport:
 
         def zplane_group():
             if s.run_zplane:
-                res["zplane"] = dict(finish=_zp.zplane_device(eng, batch, sr, s.zplane, defer=True))
+                res["zplane"] = dict(finish=_zp.zplane_device(eng, batch, sr, s.zplane, defer=True, with_status=True))
 
         main = t.cuda.current_stream(eng.device)
         lanes = eng.block_streams()
@@ -224,6 +318,16 @@ class FullReport:
         return dict(n=n, m=m, res=res, fut=fut, done=done, spectrum=spectrum, filt=filt)
 
     def finish(self, h: dict) -> np.ndarray:
+        if h.get("scatter"):
+            full = np.full((h["n"], METRICS_WIDTH), np.nan, dtype=np.float64)
+            full[:, M_STATUS] = h["status"]
+            full[:, M_NSAMPLES] = h["length"]
+            if h["inner"] is not None:
+                full[h["good"]] = self._finish_valid(h["inner"])
+            return full
+        return self._finish_valid(h)
+
+    def _finish_valid(self, h: dict) -> np.ndarray:
         s = self.s
         n, m, res, fut, spectrum, filt = h["n"], h["m"], h["res"], h["fut"], h["spectrum"], h["filt"]
         for ev in h["done"]:                               # the only wait of the step (one event per lane)
@@ -238,7 +342,9 @@ class FullReport:
             if nb:
                 m[:, M_BANDS : M_BANDS + 3 * nb] = values[:, :nb, :].reshape(n, 3 * nb)
         if s.run_zplane:
-            poles, _ = res["zplane"]["finish"]()
+            poles, _, ar_status = res["zplane"]["finish"]()
+            not_finite = ar_status == _zp.AR_STATUS_NOT_FINITE
+            m[not_finite & (m[:, M_STATUS] == 0.0), M_STATUS] = float(ST_ZPLANE_NOT_FINITE)
             sizes = np.array([p.size for p in poles])
             m[:, M_AR_POLES] = sizes
             if n and sizes.min() == sizes.max() and sizes[0] > 0:
@@ -266,7 +372,7 @@ class FullReport:
             m[:, M_FR_PEAK] = st[:, 2]
             with np.errstate(invalid="ignore", divide="ignore"):
                 m[:, M_FR_CENTROID] = np.where(st[:, 4] > 0.0, st[:, 3] / st[:, 4], st[:, 5])
-            m[st[:, 0] < 1.0, M_STATUS] = 1.0
+            m[st[:, 0] < 1.0, M_STATUS] = float(ST_EMPTY_FREQUENCY_RANGE)
         if filt is not None:
             st = fut["filter_stats"].get() if filt is not spectrum else st
             m[:, M_FILT_PEAK] = st[:, 2]

@@ -265,18 +265,33 @@ int32_t ira_logbin_aggregate(const float* mag_dev, const int64_t* mag_off_dev, c
  * analyse/zplane.py:83-120 (which uses an SVD-based lstsq; results agree to ~cond(A)^2 * 1e-16).
  * partial_dev: nb * ira_ar_partial_doubles(order, max_len) doubles of scratch; gscratch_dev: nb*order*order
  * doubles, only needed when order > 128; info_dev (optional): IRA_AR_INFO_DOUBLES doubles per element
- * [0] status: 0 solved, 1 a Cholesky pivot was not positive, 2 solved and refined (ira_ar_refine), [1] largest,
+ * [0] status: 0 solved, 1 a Cholesky pivot was not positive, 2 solved and refined (ira_ar_refine), 3 not finite,
+ * 4 rank-deficient: minimum-norm solution (ira_ar_minnorm, which then redefines [1..3]), [1] largest,
  * [2] smallest pivot, [3] condition estimate trace(G) * ||G^-1|| (two inverse iterations on the factor; between
  * cond(G) and order * cond(G)).  1 <= order <= 1024 < len. */
 #define IRA_AR_INFO_DOUBLES 4
+#define IRA_AR_DENSE_GRAM 1   /* flags: form G = A^T A as a dense contraction on the FP64 matrix cores (v_mfma_f64_16x16x4_f64)
+                               * instead of the O(order * len) lag-sum form: the cross-check of the default path.  gram, solve
+                               * and refine of one fit take the same flags (layout of partial_dev). */
 int64_t ira_ar_partial_doubles(int32_t order, int32_t max_len);
 /* The two halves of ira_ar_fit, callable separately: the MFMA Gram contraction, and reduce + Cholesky solve. */
 int32_t ira_ar_gram(const float* x_dev, const double* x64_dev, const int64_t* xoff_dev,
                     const int32_t* len_dev, const double* divisor_dev, int32_t nb, int32_t max_len,
-                    int32_t order, double* partial_dev, void* stream);
+                    int32_t order, double* partial_dev, int32_t flags, void* stream);
 int32_t ira_ar_solve(const double* partial_dev, const int32_t* len_dev, int32_t nb, int32_t max_len,
                      int32_t order, double ridge, double* gscratch_dev, double* coeffs_dev,
-                     double* info_dev, void* stream);
+                     double* info_dev, int32_t flags, void* stream);
+/* Rank-deficient fits.  For the elements ira_ar_solve flagged with status 1 (a Cholesky pivot was not positive: constant
+ * segments, a few taps followed by digital silence, segments shorter than ~2 order) -- every other element is left alone --
+ * G is eigen-decomposed (cyclic Jacobi) and the MINIMUM-NORM solution a = -V diag(1/lambda_k | 0) V^T r is written, dropping
+ * directions with lambda_k <= rel_cut * lambda_max: what numpy.linalg.lstsq(A, y, rcond=None) returns for a rank-deficient A
+ * (reference analyse/zplane.py:117).  info becomes [4, lambda_max, smallest kept lambda, rank]; a Gram matrix holding NaN or
+ * infinity (the reference's lstsq raises LinAlgError there) gives status 3 and NaN coefficients.  scratch2_dev: nb * 2 *
+ * order^2 doubles; order <= 512; rel_cut in (0, 1), 1e-12 sits just above the rounding noise of a float64 Gram matrix.
+ * Runs after ira_ar_solve (ridge = 0, default lag-sum record: not with IRA_AR_DENSE_GRAM) on the same partial / coeffs /
+ * info buffers, before ira_ar_refine. */
+int32_t ira_ar_minnorm(const double* partial_dev, const int32_t* len_dev, int32_t nb, int32_t max_len, int32_t order,
+                       double* scratch2_dev, double* coeffs_dev, double* info_dev, double rel_cut, void* stream);
 /* Iterative refinement for ill-conditioned fits (ridge = 0 only).  The reference's SVD-based lstsq is accurate to about
  * cond(A) eps, the normal equations only to cond(A)^2 eps = cond(G) eps; elements whose condition estimate
  * info[3] > cond_threshold get `steps` (1..4) rounds of  a += G^-1 A^T (y - A a)  with the residual and
@@ -287,11 +302,11 @@ int32_t ira_ar_solve(const double* partial_dev, const int32_t* len_dev, int32_t 
 int32_t ira_ar_refine(const float* x_dev, const double* x64_dev, const int64_t* xoff_dev, const int32_t* len_dev,
                       const double* divisor_dev, int32_t nb, int32_t max_len, int32_t order, const double* partial_dev,
                       double* gscratch_dev, double* coeffs_dev, double* info_dev, double* grad_dev,
-                      double cond_threshold, int32_t steps, void* stream);
+                      double cond_threshold, int32_t steps, int32_t flags, void* stream);
 int32_t ira_ar_fit(const float* x_dev, const double* x64_dev, const int64_t* xoff_dev,
                    const int32_t* len_dev, const double* divisor_dev, int32_t nb, int32_t max_len, int32_t order, double ridge,
                    double* partial_dev, double* gscratch_dev, double* coeffs_dev, double* info_dev,
-                   void* stream);
+                   int32_t flags, void* stream);
 
 /* All complex roots of npoly real polynomials given in DESCENDING powers, ncoef coefficients each
  * (Aberth-Ehrlich, float64).  Trailing coefficients with |c| < trail_eps are dropped first (reference
@@ -375,6 +390,12 @@ int32_t ira_wav_read_pcm16(const char* path, int64_t data_offset, int64_t frames
                            int16_t* dst_host);
 int32_t ira_pcm16_to_channels(const int16_t* pcm_dev, int64_t frames, int32_t channels, int32_t mono_downmix,
                               float* out_dev, void* stream);
+
+/* ---- a8 alone: mask_dev[k] = the float32 mask value the band inverses multiply bin k with, k < nbins, for ONE band record
+ * (band_params8: HOST array of 8 doubles, as in ira_band_irfft) on the axis float32(k * freq_val).  The reference's
+ * _make_lowpass_mask / _make_highpass_mask / _make_bandpass_mask (analyse/rt60bands.py:116-167) evaluated by the very
+ * device function the transforms inline -- for tests and for callers that want the mask itself. */
+int32_t ira_band_mask_values(const double* band_params8, double freq_val, int64_t nbins, float* mask_dev, void* stream);
 
 /* ira_host_pull: DEVICE kernel that reads PINNED (mapped) host memory over the PCIe link and writes HBM -- the batch upload
  *   without the copy engine, so the analysis streams' small table uploads never queue behind a 100 MB transfer, and for

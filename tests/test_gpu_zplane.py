@@ -95,7 +95,7 @@ def test_zplane_batch_vs_oracle():
 
 
 def test_ar_lag_path_matches_dense_mfma_gram():
-    """The O(pN) lag-sum normal equations (default) against the dense MFMA Gram (IRA_AR_DENSE=1): same coefficients."""
+    """The O(pN) lag-sum normal equations (default) against the dense MFMA Gram (flags = IRA_AR_DENSE_GRAM): same coefficients."""
     import os
     from audio_analysis_amd.engine import get_engine
     from audio_analysis_amd.synth import synth_ir
@@ -106,10 +106,10 @@ def test_ar_lag_path_matches_dense_mfma_gram():
         lens = b.length.astype(np.int32)
         c_lag, info_lag = eng.ar_fit(b.x, b.off, lens, None, order)
         try:
-            os.environ["IRA_AR_DENSE"] = "1"
+            eng.ar_dense_gram = True                       # IRA_AR_DENSE_GRAM flag of the AR entry points
             c_dense, info_dense = eng.ar_fit(b.x, b.off, lens, None, order)
         finally:
-            os.environ.pop("IRA_AR_DENSE", None)
+            eng.ar_dense_gram = False
         a, d = c_lag.cpu().numpy().reshape(len(chans), order + 1), c_dense.cpu().numpy().reshape(len(chans), order + 1)
         assert np.all(a[:, 0] == 1.0)
         # both solve the same normal equations; the difference is cond(G) * 1e-16
@@ -180,3 +180,50 @@ def test_ar_refinement_recovers_lstsq_accuracy_on_ill_conditioned_irs():
         rad, rad_ref = np.sort(np.abs(r.poles)), np.sort(np.abs(o["poles"]))
         assert np.max(np.abs(rad - rad_ref) / rad_ref) < 1e-7
         assert int(np.sum(rad >= 1.0)) == o["unstable"]
+
+
+def test_rank_deficient_fits_return_the_minimum_norm_solution():
+    """a singular Gram matrix used to come back pivot-patched.  For segments whose design matrix is rank
+    deficient -- a constant, a few taps followed by digital silence, a short exact AR(2) sequence, silence -- the
+    coefficients now equal numpy.linalg.lstsq's MINIMUM-NORM solution (the oracle's fit_ar is the reference's call), the
+    solver status says so, and a well-conditioned channel in the same batch is untouched."""
+    from audio_analysis_amd.engine import get_engine
+    from audio_analysis_amd.synth import synth_ir
+    eng = get_engine()
+    n = 6000
+    dc = np.full(n, 1.0, np.float32)
+    taps = np.zeros(n, np.float32); taps[:4] = [1.0, 0.5, -0.25, 0.125]
+    ar2 = np.zeros(n, np.float64); ar2[0] = 1.0; ar2[1] = 1.2
+    for i in range(2, n):
+        ar2[i] = 1.2 * ar2[i - 1] - 0.72 * ar2[i - 2]
+    ar2 = ar2.astype(np.float32)                                        # two poles, radius 0.85: rank 2 (+ rounding dust)
+    zeros = np.zeros(n, np.float32)
+    good = synth_ir(31, 0, n, rt60_seconds=0.05, pre_delay=0)
+    chans = [dc, taps, good, zeros]
+    b = eng.upload(chans)
+    for order in (8, 64):
+        co, info = eng.ar_fit(b.x, b.off, b.length.astype(np.int32), None, order)
+        co, info = co.cpu().numpy(), info.cpu().numpy()
+        assert list(info[:, 0]) == [4.0, 4.0, 0.0, 4.0], (order, info[:, 0])
+        assert info[0, 3] == 1.0 and info[3, 3] == 0.0 and 1 <= info[1, 3] <= 4        # ranks: constant 1, silence 0
+        for i, x in enumerate(chans):
+            ref = O.fit_ar(x.astype(np.float64), order)
+            scale = max(1.0, float(np.abs(ref).max()))
+            assert np.abs(co[i] - ref).max() <= 1e-8 * scale, (order, i, np.abs(co[i] - ref).max())
+    # the AR(2) sequence at order 8: lstsq keeps directions down to 1e-10 of sigma_max, the eigen cut sits at 1e-6 of it;
+    # the two POLES of the generating recursion must come out either way
+    b2 = eng.upload([ar2])
+    co, info = eng.ar_fit(b2.x, b2.off, b2.length.astype(np.int32), None, 8)
+    roots, cnt = eng.poly_roots(co, 1, 9, 1e-14)
+    r = roots.cpu().numpy()[0, : int(cnt.cpu().numpy()[0])]
+    rad = np.sort(np.hypot(r[:, 0], r[:, 1]))[::-1]
+    assert abs(rad[0] - np.sqrt(0.72)) < 1e-6 and abs(rad[1] - np.sqrt(0.72)) < 1e-6, rad
+    # NaN input: the reference's lstsq raises LinAlgError; the batch API reports status 3, the drop-in function raises
+    bad = good.copy(); bad[100] = np.nan
+    b3 = eng.upload([bad, good])
+    co, info = eng.ar_fit(b3.x, b3.off, b3.length.astype(np.int32), None, 16)
+    info = info.cpu().numpy()
+    assert info[0, 0] == 3.0 and info[1, 0] in (0.0, 2.0) and np.all(np.isnan(co.cpu().numpy()[0, 1:]))
+    from audio_analysis_amd.analyse import zplane
+    with pytest.raises(np.linalg.LinAlgError):
+        zplane._fit_ar_least_squares(bad.astype(np.float64), 16)

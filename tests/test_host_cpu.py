@@ -50,7 +50,7 @@ def test_argument_validation_without_gpu():
     assert lib.ira_stft_mag_db(1, 1, 1, 1, 1, 1000, 512, 1, 1, 32, -120.0, 1, 1, 0, 0, 0) == -2   # n_fft not a power of 2
     assert lib.ira_stft_mag_db(1, 1, 1, 1, 1, 4096, 512, 1, 1, 16, -120.0, 1, 1, 0, 0, 0) == -3  # precision
     assert lib.ira_poly_roots(1, 1, 5000, 1e-14, 1, 1, 0) == -2
-    assert lib.ira_ar_gram(1, 0, 1, 1, 0, 1, 100, 2000, 1, 0) == -2
+    assert lib.ira_ar_gram(1, 0, 1, 1, 0, 1, 100, 2000, 1, 0, 0) == -2
 
 
 def test_product_path_fails_loudly_without_gpu():
@@ -61,6 +61,27 @@ def test_product_path_fails_loudly_without_gpu():
     from audio_analysis_amd.analyse import decay
     with pytest.raises(IraError):
         decay.analyse_decay_for_channel(np.zeros(100, np.float32), SR, "m", decay.DecayAnalysisSettings())
+
+
+def test_library_reads_no_environment_and_keeps_no_state():
+    """the product library is a pure function of its arguments -- no getenv, no function-local
+    statics in the sources; tuning knobs only exist under IRA_TUNING_BUILD (ira_common.h)."""
+    import re
+    for src in sorted((REPO / "audio_analysis_amd" / "csrc").glob("*.hip")) + sorted((REPO / "audio_analysis_amd" / "csrc").glob("*.h")):
+        text = src.read_text()
+        if src.name == "ira_common.h":
+            body = text.split("#ifdef IRA_TUNING_BUILD")[1].split("#else")[0]
+            assert "getenv" in body and "getenv" not in text.replace(body, "")
+            continue
+        assert "getenv" not in text, src.name
+        for line in text.splitlines():
+            code = line.split("//")[0]
+            assert not re.search(r"^\s+static\s+(?!constexpr|inline|_assert)", code), (src.name, line)
+    lib_path = REPO / "audio_analysis_amd" / "csrc" / "libira.so"
+    if lib_path.exists():
+        import subprocess
+        syms = subprocess.run(["nm", "-D", "--undefined-only", str(lib_path)], capture_output=True, text=True).stdout
+        assert "getenv" not in syms
 
 
 def test_product_never_imports_the_oracle():

@@ -250,3 +250,25 @@ def test_deconvolve_oracle_reproduces_the_reference_bit_for_bit():
         O.deconvolve(r[:5], sw)
     with pytest.raises(ValueError):
         O.deconvolve(r, sw, output_length_mode="nope")
+
+
+def test_band_signals_and_masks_vs_reference():
+    """a8 / a9 pinned directly (tests/golden/make_band_goldens.py ran the reference's mask builders and _apply_fft_mask):
+    the oracle's masks and band-filtered signals are bit-identical for a Bluestein length and a smooth length."""
+    from pathlib import Path
+    gb = np.load(Path(__file__).resolve().parent / "golden" / "band_signals.npz")
+    gi = np.load(Path(__file__).resolve().parent / "golden" / "goldens.npz")
+    e = gb["third1k_edges"]
+    bands = {"lp250": dict(kind="lowpass", low_edge_hz=None, high_edge_hz=250.0),
+             "bp500_2000": dict(kind="bandpass", low_edge_hz=500.0, high_edge_hz=2000.0),
+             "hp4000": dict(kind="highpass", low_edge_hz=4000.0, high_edge_hz=None),
+             "third1k": dict(kind="bandpass", low_edge_hz=float(e[0]), high_edge_hz=float(e[1]))}
+    for tag in ("xd", "xb"):
+        x = gi[f"in/{tag}"]
+        f = np.fft.rfftfreq(x.size, d=1.0 / 48000.0).astype(np.float32)
+        for name, band in bands.items():
+            m = O.band_mask(f, band, 1.0 / 6.0, 24000.0)
+            assert m.dtype == np.float32
+            np.testing.assert_array_equal(m, gb[f"mask/{tag}/{name}"])
+            y = np.fft.irfft(np.fft.rfft(x.astype(np.float64)) * m, n=x.size).astype(np.float32)
+            np.testing.assert_array_equal(y, gb[f"y/{tag}/{name}"])
