@@ -29,6 +29,7 @@ PROTOTYPES = {
     "ira_edc_db": (i32, [vp, vp, vp, i32, C.c_int64, f64, f64, vp, vp, vp, vp, vp]),
     "ira_curve_fits": (i32, [vp, vp, vp, i32, i32, f32, f32, vp, C.POINTER(f64), i32, i32, C.POINTER(f64), i32, i32,
                              f64, f64, vp, vp, vp]),
+    "ira_edc_box_smooth": (i32, [vp, vp, vp, i32, C.c_int64, i32, f64, vp, vp]),
     "ira_edc_fits": (i32, [vp, vp, vp, i32, C.c_int64, f64, f64, f32, f32, C.POINTER(f64), i32, i32, C.POINTER(f64), i32,
                            vp, vp, vp, vp, vp, vp]),
     "ira_stft_mag_db": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, f64, vp, vp, vp, vp, vp]),

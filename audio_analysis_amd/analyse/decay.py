@@ -108,17 +108,13 @@ def _edc_on_device(eng, batch, sample_rate_hz: int, settings: DecayAnalysisSetti
     starts, lens = _decay_bounds(eng, batch, sample_rate_hz, settings)
     smooth = int(settings.edc_smoothing_window_samples or 0)
     if smooth > 1:
-        # Optional, default-off: box smoothing of the unfloored f64 dB curve on the host (decay.py:161-164),
-        # then floor + float32 cast, and back to the device for the fits.
+        # Optional, default-off: box smoothing of the unfloored f64 dB curve (decay.py:161-164), then floor + float32
+        # cast -- on the device (ira_edc_box_smooth); the fits then read the smoothed curve (ira_curve_fits).
+        if np.any(lens < smooth):
+            raise ValueError("edc_smoothing_window_samples exceeds the analysed length")
         _, edc_off, raw64 = eng.edc_db(batch.x, batch.off + starts, lens, settings.edc_epsilon,
                                        settings.edc_floor_db, want_f64=True)
-        host = raw64.cpu().numpy()
-        out = np.empty(int(lens.sum()), dtype=np.float32)
-        kernel = np.ones(smooth, dtype=np.float64) / float(smooth)
-        for o, ln in zip(edc_off, lens):
-            sm = np.convolve(host[o : o + ln], kernel, mode="same")
-            out[o : o + ln] = np.maximum(sm, float(settings.edc_floor_db)).astype(np.float32)
-        edc = eng.to_dev(out)
+        edc = eng.edc_box_smooth(raw64, edc_off, lens, smooth, settings.edc_floor_db)
     else:
         edc, edc_off = eng.edc_db(batch.x, batch.off + starts, lens, settings.edc_epsilon, settings.edc_floor_db)
     return edc, edc_off, starts, lens

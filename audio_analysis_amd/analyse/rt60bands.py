@@ -205,8 +205,7 @@ def rt60_bands_device(eng, batch, sample_rate_hz: int, settings: Rt60BandsAnalys
     """
     t = eng.torch
     dec = settings.decay_settings
-    if dec.edc_smoothing_window_samples and dec.edc_smoothing_window_samples > 1:
-        raise NotImplementedError("edc_smoothing_window_samples > 1 is not supported in the band filter bank")
+    smooth = int(dec.edc_smoothing_window_samples or 0)
     nch = batch.count
     n_all = batch.length
     if np.any(n_all < 8):
@@ -272,10 +271,19 @@ def rt60_bands_device(eng, batch, sample_rate_hz: int, settings: Rt60BandsAnalys
         seg_off_a, seg_len_a = np.array(seg_off, np.int64), np.array(seg_len, np.int64)
         if np.any(seg_len_a < 4):
             raise ValueError("Not enough samples after trimming/ignoring to compute EDC.")
-        # fused EDC -> crossings -> fits (ira_edc_fits): a band's EDC curve only feeds its fits (reference
-        # rt60bands.py:272-321), so it is never written
-        fit_dev, _, _, _ = eng.edc_fits(y, seg_off_a, seg_len_a, dec.edc_epsilon, dec.edc_floor_db, 1.0,
-                                        float(sample_rate_hz), ranges, 8)
+        if smooth > 1:
+            # default-off dB smoothing (decay.py:161-164 through rt60bands.py:356-360): the smoothed curve is what the fits
+            # see, so it is materialised: EDC (unfloored f64) -> box smoothing + floor -> crossings / fits on the curve
+            if np.any(seg_len_a < smooth):
+                raise ValueError("edc_smoothing_window_samples exceeds the analysed length")
+            _, e_off, raw64 = eng.edc_db(y, seg_off_a, seg_len_a, dec.edc_epsilon, dec.edc_floor_db, want_f64=True)
+            edc = eng.edc_box_smooth(raw64, e_off, seg_len_a, smooth, dec.edc_floor_db)
+            fit_dev, _ = eng.curve_fits(edc, e_off, seg_len_a, 1.0, float(sample_rate_hz), ranges, 8)
+        else:
+            # fused EDC -> crossings -> fits (ira_edc_fits): a band's EDC curve only feeds its fits (reference
+            # rt60bands.py:272-321), so it is never written
+            fit_dev, _, _, _ = eng.edc_fits(y, seg_off_a, seg_len_a, dec.edc_epsilon, dec.edc_floor_db, 1.0,
+                                            float(sample_rate_hz), ranges, 8)
         ci, bi = np.array(seg_c), np.array(seg_b)
         have[ci, bi] = True
 

@@ -247,6 +247,32 @@ __global__ __launch_bounds__(EDC_THREADS) void edc_emit_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// Optional dB smoothing of the EDC (decay.py:159-166, default off): numpy.convolve(edc_db, ones(w)/w, mode="same") on the
+// UNFLOORED float64 curve, then the floor and the float32 cast.  "same" keeps the centre of the full convolution: output i
+// sums the inputs i - (w-1-h) .. i + h with h = (w-1)/2 (integer division), zero beyond the ends (the edges sag).
+// Each product a[j] * (1/w) is rounded like numpy's, the sum runs in ascending j.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void edc_box_smooth_kernel(const double* __restrict__ in64,
+                                                             const int64_t* __restrict__ off,
+                                                             const int64_t* __restrict__ len, int window, double floor_db,
+                                                             float* __restrict__ out) {
+  const int seg = blockIdx.y;
+  const long long n = len[seg];
+  const double* a = in64 + off[seg];
+  float* o = out + off[seg];
+  const double inv_w = 1.0 / (double)window;
+  const long long h = (window - 1) / 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    long long j0 = i + h - (window - 1), j1 = i + h;
+    if (j0 < 0) j0 = 0;
+    if (j1 > n - 1) j1 = n - 1;
+    double acc = 0.0;
+    for (long long j = j0; j <= j1; ++j) acc += a[j] * inv_w;
+    o[i] = (float)np_max(acc, floor_db);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // a4/a5/a16: crossings + line fits on float32 dB curves.
 // ------------------------------------------------------------------------------------------------
 constexpr int FIT_MAX_RANGES = 4;
@@ -951,6 +977,20 @@ extern "C" int32_t ira_edc_fits(const float* x_dev, const int64_t* off_dev, cons
   if (edc_db_dev != nullptr)
     edc_emit_kernel<<<dim3(ntiles, nseg), EDC_THREADS, 0, st>>>(x_dev, off_dev, len_dev, eps, floor_db, edc_db_dev,
                                                                 nullptr, edc_off_dev, scratch_dev);
+  IRA_RETURN_LAUNCH();
+}
+
+extern "C" int32_t ira_edc_box_smooth(const double* edc_db64_dev, const int64_t* off_dev, const int64_t* len_dev,
+                                      int32_t nseg, int64_t max_len, int32_t window, double floor_db, float* out_dev,
+                                      void* stream) {
+  IRA_CHECK_PTR(edc_db64_dev); IRA_CHECK_PTR(off_dev); IRA_CHECK_PTR(len_dev); IRA_CHECK_PTR(out_dev);
+  if (nseg <= 0) return nseg == 0 ? IRA_OK : IRA_E_SIZE;
+  if (window < 1 || max_len <= 0 || nseg > 65535) return IRA_E_SIZE;
+  if ((int64_t)window > max_len) return IRA_E_UNSUPPORTED;      // numpy's "same" then returns `window` values, not len
+  long long blocks = (max_len + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  edc_box_smooth_kernel<<<dim3((unsigned)blocks, nseg), 256, 0, (hipStream_t)stream>>>(edc_db64_dev, off_dev, len_dev, window,
+                                                                                       floor_db, out_dev);
   IRA_RETURN_LAUNCH();
 }
 

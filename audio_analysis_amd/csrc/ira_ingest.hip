@@ -86,16 +86,14 @@ __global__ __launch_bounds__(PCM_THREADS) void pcm16_kernel(const int16_t* __res
 }
 
 // ------------------------------------------------------------------------------------------------
-// ira_host_pull: the batch upload as a KERNEL that reads pinned host memory through the PCIe link and writes HBM.
-// A hipMemcpyAsync of a whole batch (123 MB for 64 x 10 s) holds the copy engine for ~2.2 ms, and every small
-// asynchronous upload of the analysis streams (offset / length / job tables) queues behind it: the analysis stalled for
-// exactly one transfer per step (measured: 8.6 ms per step with a copy-engine upload against 6.4 ms compute-only).  A
-// small grid of pull workgroups leaves the copy engine to the small tables, overlaps with the analysis kernels on the
-// other CUs, and -- for PCM16 taps -- converts while it copies, so the int16 staging buffer in HBM disappears.
-// Each lane keeps PULL_U 16-byte reads of host memory in flight (a PCIe round trip is ~1.5-2 us: ~100 KB must be in
-// flight to fill a Gen5 x16 link; 8 workgroups x 256 lanes x 4 x 16 B = 131 KB -- measured on MI355X, full report,
-// 64 x 10 s: 8 workgroups 9283 IRs/s, 16 8488, 32 7611, 48 7690: more reads in flight do not move the link faster but do
-// crowd the fabric queues the analysis kernels' HBM reads share, e.g. the peak pick went from 0.09 to 1.2 ms).
+// ira_host_pull: the batch upload as a KERNEL that reads pinned host memory through the PCIe link and writes HBM -- an
+// alternative to hipMemcpyAsync that converts PCM16 while it copies (no int16 staging buffer in HBM) and leaves the copy
+// engines alone.  Each lane keeps PULL_U 16-byte reads of host memory in flight; a PCIe round trip is ~1.5-2 us, so
+// ~100 KB in flight fill a Gen5 x16 link: 8 workgroups x 256 lanes x 4 x 16 B = 131 KB, 46-47 GB/s measured.  MORE is
+// worse: with 32-48 workgroups the outstanding host reads crowd the fabric queues every other kernel's HBM reads go
+// through (full report, 64 x 10 s: peak pick 0.09 -> 1.2 ms, step 6.9 -> 8.4 ms).  Against the copy engine it is a draw
+// (tools/upload_ab.py, alternating order in one process: 10.37 k vs 9.4-10.8 k IRs/s at 256 x 10 s per step), so the
+// feed uses it only when asked (audio_analysis_amd.feed.DeviceFeed(pull=True)).
 // ------------------------------------------------------------------------------------------------
 constexpr int PULL_THREADS = 256;
 constexpr int PULL_U = 4;

@@ -401,6 +401,16 @@ class Engine:
             return out, edc_off, out64
         return out, edc_off
 
+    def edc_box_smooth(self, edc64_dev, off: np.ndarray, lens: np.ndarray, window: int, floor_db: float):
+        """Box smoothing of unfloored float64 dB curves + floor + float32 cast (ira_edc_box_smooth)."""
+        t = self.torch
+        lens = np.ascontiguousarray(lens, dtype=np.int64)
+        out = self.empty(int(lens.sum()), t.float32)
+        d_off, d_len = self.to_dev_pack(np.ascontiguousarray(off, np.int64), lens)
+        check(self.lib.ira_edc_box_smooth(_ptr(edc64_dev), _ptr(d_off), _ptr(d_len), int(lens.size), int(lens.max()),
+                                          int(window), float(floor_db), _ptr(out), self.stream), "ira_edc_box_smooth")
+        return out
+
     # ------------------------------------------------------------------ a3-a6 fused
     def edc_fits(self, x_dev, seg_off: np.ndarray, seg_len: np.ndarray, eps: float, floor_db: float,
                  t_mul: float, t_div: float, ranges: Sequence[Tuple[float, float]], min_points: int,

@@ -8,10 +8,14 @@ Two wire formats:
   float32  4 bytes per sample, copied straight into the batch buffer;
   int16    2 bytes per sample (what a PCM16 tap holds, recorder.hpp:49-53), converted to float32 (x/32768 clipped:
            io.py:46-64) on the way.
-The transfer itself is a KERNEL (ira_host_pull): a few dozen workgroups read the pinned batch through the PCIe link and
-write HBM, converting PCM16 in the same pass.  A copy-engine transfer (hipMemcpyAsync) of a 123 MB batch holds the engine
-for 2.2 ms, and the small asynchronous table uploads of the analysis streams queue behind it -- measured, the analysis then
-stalls one whole transfer per step (8.6 instead of 6.4 ms).  DeviceFeed(pull=False) keeps the copy-engine path as the A/B.
+The transfer is an ordinary asynchronous copy (hipMemcpyAsync on the copy stream; PCM16 then takes one conversion launch,
+ira_pcm16_to_channels).  DeviceFeed(pull=True) moves the batch with a KERNEL instead (ira_host_pull: a few workgroups
+read the pinned batch through the PCIe link and write HBM, converting PCM16 in the same pass, no int16 staging buffer in
+HBM).  Measured in alternating order inside one process (tools/upload_ab.py, full report, MI355X): 256 x 10 s per step
+copy engine 9.4-10.8 k, pull kernel (8 workgroups) 10.36-10.39 k IRs/s; 64 x 10 s 9.5-9.7 k vs 9.0-9.5 k -- the same
+within run-to-run noise, so the copy engine stays the default.  What does NOT work is a large pull grid: 32-48 workgroups
+keep so many PCIe reads in flight that the fabric queues the analysis kernels' HBM reads share back up (the peak pick
+went from 0.09 to 1.2 ms, the step from 6.9 to 8.4 ms).
 
 A ChannelBatch handed out by push() carries the event recorded behind its upload (+ conversion): the peak pick and
 every report lane wait for THAT event only (pipeline.FullReport.submit), never for the copy stream as a whole.
@@ -63,10 +67,10 @@ class HostBatch:
 
 
 class DeviceFeed:
-    def __init__(self, eng: Engine, max_samples: int, depth: int = 4, pull: bool = True, pull_workgroups: int = 8):
+    def __init__(self, eng: Engine, max_samples: int, depth: int = 4, pull: bool = False, pull_workgroups: int = 8):
         t = eng.torch
         self.eng = eng
-        self.pull = bool(pull)                     # False: copy-engine upload (hipMemcpyAsync) -- the A/B of the pull kernel
+        self.pull = bool(pull)                     # True: the batch crosses PCIe under ira_host_pull instead of hipMemcpyAsync
         self.pull_workgroups = int(pull_workgroups)
         self.depth = int(depth)
         self.copy_stream = t.cuda.Stream(device=eng.device)
@@ -86,8 +90,8 @@ class DeviceFeed:
         with t.cuda.stream(self.copy_stream):
             done = False
             if self.pull:
-                # pull kernel: reads the pinned batch through the PCIe link itself (and converts PCM16 on the way), so the
-                # copy engine stays free for the analysis streams' small table uploads (ira_host_pull in include/ira.h)
+                # pull kernel: reads the pinned batch through the PCIe link itself and converts PCM16 on the way
+                # (ira_host_pull in include/ira.h)
                 rc = eng.lib.ira_host_pull(int(hb.pinned.data_ptr()), int(hb.total), 1 if hb.pcm16 else 0,
                                            int(x.data_ptr()), int(self.pull_workgroups), eng.stream)
                 if rc == -3:                                  # IRA_E_UNSUPPORTED: not mapped host memory

@@ -13,7 +13,7 @@ so no step re-analyses samples that are still in the 256 MB Infinity Cache, and 
 stream under the kernels of batch k (audio_analysis_amd.feed).  Weak scaling: B per GPU is fixed.
 
   --config report (default)  the BASELINE metric: full report (decay + rt60bands[three] + fr + filter + spectrogram +
-                             waterfall + modalcloud + zplane AR(64)), B = 64 mono IRs of 10 s
+                             waterfall + modalcloud + zplane AR(64)), B = 256 mono IRs of 10 s per step
   --config 2   256 x 2 s: STFT spectrogram + Schroeder decay
   --config 3   third-octave rt60bands + waterfall on 10 s IRs, B = 256 per step (16 steps = the config's 4096 IRs)
   --config 4   zplane AR(64) + modal cloud on 10 s IRs, B = 256 per step (8 steps = 2048 IRs = one GPU's shard of 16384)
@@ -24,6 +24,7 @@ Rank 0 prints ONE JSON line:
   "value"           H2D-inclusive throughput, float32 upload (what section 8d defines)
   "value_int16"     the same with 2-byte PCM16 upload + device conversion (what a tap bundle delivers)
   "value_resident"  inputs already in HBM (still rotating over the distinct batches): the compute-only rate
+  "value_pull_kernel" the same steps with the batch moved by ira_host_pull instead of hipMemcpyAsync (A/B)
   "roofline"        for the dominant call (largest share of device time) measured live with HIP events recorded on the
                     launch stream -- in a short serialised pass of the same steps (one stream) right after the timed
                     region, because a kernel's own duration is not observable while other streams share the GPU
@@ -42,6 +43,8 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+# transfers and format conversion of the ingest: reported in device_ms_per_step_by_call, never the "dominant kernel"
+INGEST_CALLS = ("ira_host_pull", "ira_pcm16_to_channels")
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 F64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak (FMA counted as two flops)
 
@@ -158,7 +161,9 @@ def config_table():
                    run_spectrogram=False, run_waterfall=False, run_modal_cloud=False, run_zplane=False)
     third = replace(full.rt60_bands, band_mode="third")
     return {
-        "report": dict(settings=full, batch=64, seconds=10.0, steps=20, cpu_s=1.3,
+        # B = 256 per step: the host enqueues ~150 launches and table uploads per step whatever the batch size; measured on
+        # MI355X (H2D included): B = 64 8.4-9.3 k, 128 10.1 k, 256 10.5 k IRs/s
+        "report": dict(settings=full, batch=256, seconds=10.0, steps=20, cpu_s=1.3,
                        metric="IRs/sec full report (STFT+RT60bands+zplane), 48 kHz 10 s IR",
                        what="metrics-only full report", excluded=["png rendering", "group delay", "diffusion", "ir plots"]),
         "2": dict(settings=replace(none, run_decay=True, run_spectrogram=True), batch=256, seconds=2.0, steps=20, cpu_s=0.03,
@@ -374,7 +379,7 @@ def main():
     ap.add_argument("--literal-steps", type=int, default=5,
                     help="config report only: extra steps with the reference's default-on group-delay and diffusion "
                          "blocks added (reported as literal_full_report; 0 = skip)")
-    ap.add_argument("--upload", default="pull", choices=["pull", "copy"],
+    ap.add_argument("--upload", default="copy", choices=["pull", "copy"],
                     help="pull: the batch crosses PCIe under a pull kernel (ira_host_pull); copy: hipMemcpyAsync on the copy engine")
     ap.add_argument("--pull-workgroups", type=int, default=8)
     ap.add_argument("--variants", default="all", choices=["all", "value"],
@@ -453,12 +458,12 @@ def main():
     gathered = last.get("g")
     note(f"timed region: {steps} steps in {elapsed:.3f} s = {B * world * steps / elapsed:.0f} IRs/s")
 
-    el_copy = None
-    if a.variants == "all" and a.upload == "pull":
-        feed.pull = False                              # A/B: the same steps with a copy-engine upload
+    el_pull = None
+    if a.variants == "all" and a.upload == "copy":
+        feed.pull = True                               # A/B: the same steps with the pull-kernel upload (ira_host_pull)
         run_fed(2, host_f32)
-        el_copy = timed(lambda c: run_fed(c, host_f32), steps)
-        feed.pull = True
+        el_pull = timed(lambda c: run_fed(c, host_f32), steps)
+        feed.pull = False
     # ---- variants: int16 upload; inputs resident in HBM (rotating over the K device-resident batches) ----------------------
     el_i16 = el_res = None
     resident = None
@@ -532,7 +537,8 @@ def main():
         traffic_tab = {}
     tot, roof = make_roof(ev, roof_steps, settings, L, n, B, traffic_tab)
     dev_ms = sum(tot.values())
-    dominant = max(tot, key=tot.get)
+    analysis = {k: v for k, v in tot.items() if k not in INGEST_CALLS}
+    dominant = max(analysis, key=analysis.get)
     stft_name = next((k for k in tot if k.startswith("ira_stft_mag_db") and "[f32" in k), None)
     rs = roof(stft_name) if stft_name else None
     if rs is not None and stft_err is not None:
@@ -565,12 +571,12 @@ def main():
         },
         "value_int16": None if el_i16 is None else total_irs / el_i16,
         "value_resident": None if el_res is None else total_irs / el_res,
-        "value_copy_engine": None if el_copy is None else total_irs / el_copy,
-        "upload": "pull kernel (ira_host_pull reads pinned host memory over PCIe)" if feed.pull else "hipMemcpyAsync",
+        "value_pull_kernel": None if el_pull is None else total_irs / el_pull,
+        "upload": "pull kernel (ira_host_pull reads pinned host memory over PCIe)" if feed.pull else "hipMemcpyAsync on a copy stream",
         "variants": {"value": "float32 upload inside the timed region (SURVEY.md 8d)",
                      "value_int16": "PCM16 upload (2 B/sample) + device conversion inside the timed region",
                      "value_resident": "no upload: the same distinct batches already in HBM (compute-only rate)",
-                     "value_copy_engine": "float32 upload by hipMemcpyAsync instead of the pull kernel (A/B)"},
+                     "value_pull_kernel": "float32 upload by the pull kernel (ira_host_pull) instead of hipMemcpyAsync (A/B)"},
         "h2d_GBps": B * n * 4.0 * steps / elapsed / 1e9,
         "roofline": roof(dominant),
         "roofline_stft": rs,
@@ -645,7 +651,8 @@ def bench_bundle(a, cfg, eng, rank, world, B, n, steps, blocks):
     except Exception:
         traffic_tab = {}
     tot, roof = make_roof(ev, roof_steps, settings, L, n, 2 * B, traffic_tab)
-    dominant = max(tot, key=tot.get)
+    analysis = {k: v for k, v in tot.items() if k not in INGEST_CALLS}
+    dominant = max(analysis, key=analysis.get)
     files = B * steps * world
     out = {
         "metric": cfg["metric"], "value": files / elapsed, "unit": "stereo taps/s", "n_gpus": world, "steps": steps,

@@ -89,6 +89,13 @@ int32_t ira_curve_fits(const float* y_dev, const int64_t* off_dev, const int64_t
                        double min_peak_above_floor, double* fit_out_dev, double* cross_out_dev,
                        void* stream);
 
+/* Optional dB smoothing of the EDC (reference analyse/decay.py:159-166, default off): out[s][i] = float32(max(floor_db,
+ * numpy.convolve(edc_db64[s], ones(window)/window, mode="same")[i])) on the unfloored float64 curve ira_edc_db writes
+ * (edc_db64_dev); in and out share the offsets off_dev.  IRA_E_UNSUPPORTED when a segment is shorter than the window
+ * (numpy's "same" then changes the length of the curve). */
+int32_t ira_edc_box_smooth(const double* edc_db64_dev, const int64_t* off_dev, const int64_t* len_dev, int32_t nseg,
+                           int64_t max_len, int32_t window, double floor_db, float* out_dev, void* stream);
+
 /* ---- a3-a6 fused: Schroeder EDC -> crossings -> decay-line fits, straight from the samples --------------------------
  * The same results as ira_edc_db followed by ira_curve_fits (analytic time axis t[i] = float32(i)*t_mul/t_div, no
  * rel_to_peak), without reading an EDC array: per segment the chunk sums locate each target level, only the
@@ -398,12 +405,12 @@ int32_t ira_pcm16_to_channels(const int16_t* pcm_dev, int64_t frames, int32_t ch
 int32_t ira_band_mask_values(const double* band_params8, double freq_val, int64_t nbins, float* mask_dev, void* stream);
 
 /* ira_host_pull: DEVICE kernel that reads PINNED (mapped) host memory over the PCIe link and writes HBM -- the batch upload
- *   without the copy engine, so the analysis streams' small table uploads never queue behind a 100 MB transfer, and for
- *   PCM16 the conversion of io.py:46-64 (x/32768 clipped) happens in the same pass.  host_src: host pointer of a pinned
- *   allocation (hipHostMalloc / torch pin_memory), 16-byte aligned; count samples; format 0 = float32 copied as is,
- *   1 = mono int16 -> float32; out_dev 16-byte aligned; workgroups = grid size (0 = 8: just enough reads in flight to
- *   fill a Gen5 x16 link; more only crowd the fabric queues the analysis kernels' HBM reads go through).  IRA_E_UNSUPPORTED if host_src is not mapped host memory
- *   (the caller then uses an ordinary asynchronous copy). */
+ *   without the copy engine, and for PCM16 with the conversion of io.py:46-64 (x/32768 clipped) in the same pass (no int16
+ *   staging buffer in HBM).  host_src: host pointer of a pinned allocation (hipHostMalloc / torch pin_memory), 16-byte
+ *   aligned; count samples; format 0 = float32 copied as is, 1 = mono int16 -> float32; out_dev 16-byte aligned;
+ *   workgroups = grid size (0 = 8: just enough reads in flight to fill a Gen5 x16 link; more only crowd the fabric queues
+ *   the analysis kernels' HBM reads go through).  Throughput equals hipMemcpyAsync's within noise: an
+ *   option, not the default.  IRA_E_UNSUPPORTED if host_src is not mapped host memory. */
 int32_t ira_host_pull(const void* host_src, int64_t count, int32_t format, float* out_dev, int32_t workgroups,
                       void* stream);
 

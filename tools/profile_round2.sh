@@ -10,7 +10,7 @@ R=$GRAFT_REPO_ROOT
 mkdir -p "$R/$out"
 cd /tmp && export TMPDIR=/tmp
 export IRA_STREAMS=1
-ARGS="--config $cfg --steps 2 --warmup 1 --host-batches 2 --variants value --no-cpu-baseline --literal-steps 0 --roofline-steps 1 --upload copy"
+B=${3:-}; ARGS="--config $cfg ${B:+--batch $B} --steps 2 --warmup 1 --host-batches 2 --variants value --no-cpu-baseline --literal-steps 0 --roofline-steps 1 --upload copy"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$out/stats" -- python3 "$R/bench.py" $ARGS > "$R/$out/stats.log" 2>&1 || echo "stats pass failed" >> "$R/$out/fail.log"
 for c in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
   tag=$(echo $c | cut -d' ' -f1)
