@@ -570,14 +570,18 @@ int pick_columns(int len, int other, bool inplace) {
   return best;
 }
 
-// LDS column stride of the in-place plan.  The staging stores and the output loads walk a tile row by row, i.e. a quarter
-// wave touches 16 / C consecutive rows of each of the C columns: with a stride that is a multiple of 16 elements (256 B =
-// all 64 banks) the columns land on the same banks (2-way conflict at C = 2).  The pad shifts column c by c * 16 / C
-// sixteen-byte bank groups.
+// LDS column stride of the in-place plan: the column length itself.  Two layouts aimed at the bank conflicts of these
+// kernels were built, measured with counters and REMOVED (profiles/r02_smooth_fft_counters.txt):
+//   * a pad on the column stride (round 1, commit 33d5c94): SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE stayed at 53 % (pass-1
+//     kernel) and 37-39 % (pass-2 kernel), times unchanged -- the conflicts are inside a column, not between columns;
+//   * a skew inside the column (slot i + (i >> 3), round 2): conflicts of the 640-point transform (radices 8, 8, 10) fell
+//     to 36 % and its LDS-active cycles by 27 %, the 750-point transform (10, 5, 5, 3: no power-of-two strides to break)
+//     rose to 49 %, and the band inverses went 1.31 -> 1.37 ms: the kernels are not bound by LDS cycles (LDS instructions
+//     issue in 1.5 % of the wave cycles, 53 % of them wait on memory and barriers), and the 12 % of extra LDS per
+//     workgroup cost one resident workgroup per CU in pass 2.
 int column_stride(int len, int c) {
-  if (c <= 1 || 16 % c != 0) return len;
-  const int want = 16 / c;
-  return len + ((want - len % 16) % 16 + 16) % 16;
+  (void)c;
+  return len;
 }
 
 bool smooth_split(long long n, int* n1_out, int* n2_out) {

@@ -56,7 +56,17 @@ __device__ __forceinline__ double lin_of4(double re, double im, double floor_pow
   if (!(p < 1.0e300)) return exp10((double)(float)(20.0 * log10(hypot(re, im))) * 0.05);
   const double db = 3.0102999566398120 * ira::log2_table(p, tab);
   const double t = ((double)(float)db - db) * 0.11512925464970228;
-  return sqrt(p) * fma(t, fma(t, 0.5, 1.0), 1.0);
+  // sqrt(p) for a normal p (floor_pow < p < 1e300: no scaling needed): hardware reciprocal square root (~26 bits) and two
+  // coupled Newton steps (Goldschmidt form), ~2e-16 relative -- 9 instructions instead of the ~25 of the library sqrt,
+  // whose denormal / special-case handling this range never needs.  (This conversion is 16 of every lane's values and was
+  // more than half of the kernel's VALU work: profiles/r02_stft4_counters.txt.)
+  const double y0 = __builtin_amdgcn_rsq(p);
+  double g = p * y0, h = 0.5 * y0;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  return g * fma(t, fma(t, 0.5, 1.0), 1.0);
 }
 
 __global__ __launch_bounds__(TL4) void stft4_kernel(
@@ -287,6 +297,212 @@ __global__ __launch_bounds__(TL4) void stft4_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// STFT v5: the same transform with ONE FRAME ON FOUR WAVES (256 lanes, 16 complex values per lane).
+// Counters of v4 (profiles/r02_stft4_counters.txt): 3624 VALU instructions per wave at ~4.2 cycles each (float64 issues
+// over 4 cycles), VALU active 30 % of a wave's life, 34 % parked at waitcnt / barriers; with 2 waves per SIMD (228
+// VGPRs, 35 KB of LDS per 2-wave workgroup) the SIMDs' float64 pipes are busy 60 % of the time.  The frame's LDS budget
+// (one half-size exchange buffer) does not depend on how many lanes share it, the register budget does: 16 values per
+// lane instead of 32 fit ~128 VGPRs, so the same four frames per CU now bring 16 waves instead of 8 and a wave that waits
+// at a barrier has three others on its SIMD to cover for it.
+//   step 1  lane m = q: 16-point DFT over n1 from global memory, twiddle W_M^(k1 m)
+//   E1      lanes 0..127 write [16 k1][128 m'] (stride 129), all lanes read n2 = 0..7 at (k1 = q & 15, n3 = q >> 4);
+//           then lanes 128..255 write and all read n2 = 8..15
+//   step 2  16-point DFT over n2, twiddle W_M^(16 k2 n3)
+//   E2      lanes with n3 < 8 (q < 128) write k1 + 16 k2 + 256 n3, lane r = q = k1 + 16 k2 reads n3 = 0..7; then n3 >= 8
+//   step 3  16-point DFT over n3 -> lane r holds Z[r + 256 k3]
+//   E3      natural order, real parts then imaginary parts through one 4096-double buffer; lane pairs k = q + 256 i, i < 8
+// ------------------------------------------------------------------------------------------------------------
+constexpr int TL5 = 256;
+
+__global__ __launch_bounds__(TL5) __attribute__((amdgpu_waves_per_eu(4, 4))) void stft5_kernel(
+    const float* __restrict__ x, const int64_t* __restrict__ off, const int32_t* __restrict__ nframes, int hop,
+    const double* __restrict__ window, const cdd* __restrict__ tw, double floor_lin, float floor_db,
+    float* __restrict__ out, const int64_t* __restrict__ out_off, const int32_t* __restrict__ frame_sel,
+    const int64_t* __restrict__ sel_off, int lb_nbins, int lb_kbase, const int32_t* __restrict__ lb_first,
+    const int32_t* __restrict__ lb_count) {
+  __shared__ __attribute__((aligned(16))) cdd ex[EXC4];
+  __shared__ ira::LogTabEntry ltab[ira::LOGTAB_N];
+  __shared__ int lb_range[2];
+  __shared__ int frame_bad;
+  const unsigned gx = gridDim.x, nwg = gridDim.x * gridDim.y;
+  const unsigned orig = blockIdx.y * gx + blockIdx.x;
+  const unsigned xq = nwg / 8, xr = nwg % 8, xcd = orig % 8;
+  const unsigned wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + orig / 8;
+  const int seg = (int)(wg / gx);
+  const int col = (int)(wg % gx);
+  const int T_out = nframes[seg];
+  if (col >= T_out) return;
+  const int q = threadIdx.x;
+  double* exd = reinterpret_cast<double*>(ex);
+  ira::build_log_table(ltab, q);
+  if (q < 2) lb_range[q] = q == 0 ? F4 : 0;
+
+  const int64_t frame = frame_sel ? (int64_t)frame_sel[sel_off[seg] + col] : (int64_t)col;
+  const float* fx = x + off[seg] + frame * hop;
+  const int k1l = q & 15, n3l = q >> 4;            // step-2 role: (k1, n3)
+  const bool lower = q < TL4;                      // lanes whose step-1 / step-2 results go through the buffer first
+
+  // ---- step 1 -------------------------------------------------------------------------------------------------
+  cdd v[16];
+  {
+    float xa[16], xb[16];
+    double wa[16], wb[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+      const int n = n1 * 256 + q;
+      xa[n1] = fx[2 * n]; xb[n1] = fx[2 * n + 1];
+      wa[n1] = window[2 * n]; wb[n1] = window[2 * n + 1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) v[n1] = {(double)xa[n1] * wa[n1], (double)xb[n1] * wb[n1]};
+  }
+  dft_dif<double, 16>(v);
+  ira::twiddle16<double, true>(v, tw[2 * q]);                 // W_M^(k1 q) = W_N^(2 q k1), k1 at v[brev(k1)]
+
+  // ---- E1: half-size exchange, lower lanes first ----------------------------------------------------------------
+  cdd b[16];
+  if (lower) {
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) ex[k1 * ROW4 + q] = v[brev_bits(k1, 4)];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int n2 = 0; n2 < 8; ++n2) b[n2] = ex[k1l * ROW4 + n2 * 16 + n3l];
+  __syncthreads();
+  if (!lower) {
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) ex[k1 * ROW4 + (q - TL4)] = v[brev_bits(k1, 4)];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int n2 = 0; n2 < 8; ++n2) b[8 + n2] = ex[k1l * ROW4 + n2 * 16 + n3l];
+  __syncthreads();
+
+  // ---- step 2 and E2 ---------------------------------------------------------------------------------------------
+  dft_dif<double, 16>(b);
+  ira::twiddle16<double, true>(b, tw[32 * n3l]);              // W_M^(16 k2 n3) = W_N^(32 n3 k2)
+  if (lower) {                                                 // n3 < 8
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) ex[k1l + 16 * k2 + E2N4 * n3l] = b[brev_bits(k2, 4)];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int n3 = 0; n3 < 8; ++n3) v[n3] = ex[q + E2N4 * n3];
+  __syncthreads();
+  if (!lower) {
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) ex[k1l + 16 * k2 + E2N4 * (n3l - 8)] = b[brev_bits(k2, 4)];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int n3 = 0; n3 < 8; ++n3) v[8 + n3] = ex[q + E2N4 * n3];
+  __syncthreads();
+
+  // ---- step 3: lane r = q holds Z[r + 256 k3] at v[brev(k3)] ----------------------------------------------------------
+  dft_dif<double, 16>(v);
+
+  // ---- E3: real parts, then imaginary parts, natural order ------------------------------------------------------------
+  double zkr[8], zpr[8], zki[8], zpi[8], midr, midi;
+#pragma unroll
+  for (int k3 = 0; k3 < 16; ++k3) exd[q + 256 * k3] = v[brev_bits(k3, 4)].re;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = q + TL5 * i;
+    zkr[i] = exd[k];
+    zpr[i] = exd[(M4 - k) & (M4 - 1)];
+  }
+  midr = exd[M4 / 2];
+  __syncthreads();
+#pragma unroll
+  for (int k3 = 0; k3 < 16; ++k3) exd[q + 256 * k3] = v[brev_bits(k3, 4)].im;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = q + TL5 * i;
+    zki[i] = exd[k];
+    zpi[i] = exd[(M4 - k) & (M4 - 1)];
+  }
+  midi = exd[M4 / 2];
+  if (q == 0) frame_bad = !((zkr[0] - zkr[0]) + (zki[0] - zki[0]) == 0.0) ? 1 : 0;   // NaN / infinity in the frame (see v4)
+  __syncthreads();                                            // E3 fully read; frame_bad, lb_range visible
+  const bool bad_frame = frame_bad != 0;
+  const float qnan32 = __uint_as_float(0x7fc00000u);
+
+  // ---- post ---------------------------------------------------------------------------------------------------
+  const double floor_pow = floor_lin * floor_lin;
+  const cdd wlane = tw[q];
+  if (lb_nbins <= 0) {
+    float* fo = out + out_off[seg] + (int64_t)col * F4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = q + TL5 * i;
+      const cdd e = {0.5 * (zkr[i] + zpr[i]), 0.5 * (zki[i] - zpi[i])};
+      const cdd d = {0.5 * (zkr[i] - zpr[i]), 0.5 * (zki[i] + zpi[i])};
+      const cdd o = {d.im, -d.re};
+      const cdd wk = ira::cmul(wlane, tw[TL5 * i]);          // W_N^k = W_N^q W_N^(256 i); second factor wave-uniform
+      const cdd pp = ira::cmul(wk, o);
+      fo[k] = bad_frame ? qnan32 : db_of4(e.re + pp.re, e.im + pp.im, floor_pow, floor_db, ltab);
+      fo[M4 - k] = bad_frame ? qnan32 : db_of4(e.re - pp.re, e.im - pp.im, floor_pow, floor_db, ltab);   // k = 0 -> bin M
+    }
+    if (q == 0) fo[M4 / 2] = bad_frame ? qnan32 : db_of4(midr, midi, floor_pow, floor_db, ltab);
+    return;
+  }
+  // fused modal-cloud aggregation, as in v4
+  {
+    int lo = F4, hi = 0;
+    for (int bb = q; bb < lb_nbins; bb += TL5) {
+      const int c = lb_count[bb];
+      if (c > 0) {
+        const int f0 = lb_kbase + lb_first[bb];
+        lo = f0 < lo ? f0 : lo;
+        hi = f0 + c > hi ? f0 + c : hi;
+      }
+    }
+    atomicMin(&lb_range[0], lo);
+    atomicMax(&lb_range[1], hi);
+  }
+  __syncthreads();
+  const int k_lo = lb_range[0], k_hi = lb_range[1];
+  const double floor_lin32 = exp10((double)floor_db * 0.05);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = q + TL5 * i;
+    const bool need_a = k >= k_lo && k < k_hi, need_b = (M4 - k) >= k_lo && (M4 - k) < k_hi;
+    if (!need_a && !need_b) continue;
+    const cdd e = {0.5 * (zkr[i] + zpr[i]), 0.5 * (zki[i] - zpi[i])};
+    const cdd d = {0.5 * (zkr[i] - zpr[i]), 0.5 * (zki[i] + zpi[i])};
+    const cdd o = {d.im, -d.re};
+    const cdd wk = ira::cmul(wlane, tw[TL5 * i]);
+    const cdd pp = ira::cmul(wk, o);
+    if (need_a) exd[k] = lin_of4(e.re + pp.re, e.im + pp.im, floor_pow, floor_db, floor_lin32, ltab);
+    if (need_b) exd[M4 - k] = lin_of4(e.re - pp.re, e.im - pp.im, floor_pow, floor_db, floor_lin32, ltab);
+  }
+  if (q == 0 && M4 / 2 >= k_lo && M4 / 2 < k_hi) exd[M4 / 2] = lin_of4(midr, midi, floor_pow, floor_db, floor_lin32, ltab);
+  __syncthreads();
+  float* co = out + out_off[seg];
+  for (int bb = q; bb < lb_nbins; bb += TL5) {
+    const int c = lb_count[bb];
+    float val = qnan32;
+    if (c > 0) {
+      const double* r = exd + lb_kbase + lb_first[bb];
+      double acc = r[0];
+      for (int k0 = 1; k0 < c; k0 += 8) {
+        double v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v8[u] = (k0 + u < c) ? r[k0 + u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (k0 + u < c) acc += v8[u];
+      }
+      val = (float)(20.0 * log10(fmax(acc / (double)c, 1e-30)));
+    }
+    co[(int64_t)bb * T_out + col] = (bad_frame && c > 0) ? qnan32 : val;
+  }
+}
+
 }  // namespace
 
 // float64 / n_fft 8192, frame-major output only; anything else returns IRA_E_UNSUPPORTED.
@@ -297,9 +513,14 @@ int32_t ira_stft4_dispatch_tf(const float* x, const int64_t* off, const int32_t*
   if (precision != 64 || n_fft != 8192) return IRA_E_UNSUPPORTED;
   const double floor_lin = std::pow(10.0, floor_db / 20.0);
   dim3 grid(max_frames, nseg);
-  stft4_kernel<<<grid, TL4, 0, st>>>(x, off, nframes, hop, static_cast<const double*>(window),
-                                     static_cast<const cdd*>(tw), floor_lin, (float)floor_db, out, out_off, frame_sel,
-                                     sel_off, 0, 0, nullptr, nullptr);
+  if (ira_tune_flag("IRA_STFT_V4"))
+    stft4_kernel<<<grid, TL4, 0, st>>>(x, off, nframes, hop, static_cast<const double*>(window),
+                                       static_cast<const cdd*>(tw), floor_lin, (float)floor_db, out, out_off, frame_sel,
+                                       sel_off, 0, 0, nullptr, nullptr);
+  else
+    stft5_kernel<<<grid, TL5, 0, st>>>(x, off, nframes, hop, static_cast<const double*>(window),
+                                       static_cast<const cdd*>(tw), floor_lin, (float)floor_db, out, out_off, frame_sel,
+                                       sel_off, 0, 0, nullptr, nullptr);
   IRA_RETURN_LAUNCH();
 }
 
@@ -312,8 +533,13 @@ int32_t ira_stft4_dispatch_logbin(const float* x, const int64_t* off, const int3
   if (precision != 64 || n_fft != 8192) return IRA_E_UNSUPPORTED;
   const double floor_lin = std::pow(10.0, floor_db / 20.0);
   dim3 grid(max_frames, nseg);
-  stft4_kernel<<<grid, TL4, 0, st>>>(x, off, nframes, hop, static_cast<const double*>(window),
-                                     static_cast<const cdd*>(tw), floor_lin, (float)floor_db, curves, curves_off,
-                                     nullptr, nullptr, nbins, k_base, first, count);
+  if (ira_tune_flag("IRA_STFT_V4"))
+    stft4_kernel<<<grid, TL4, 0, st>>>(x, off, nframes, hop, static_cast<const double*>(window),
+                                       static_cast<const cdd*>(tw), floor_lin, (float)floor_db, curves, curves_off,
+                                       nullptr, nullptr, nbins, k_base, first, count);
+  else
+    stft5_kernel<<<grid, TL5, 0, st>>>(x, off, nframes, hop, static_cast<const double*>(window),
+                                       static_cast<const cdd*>(tw), floor_lin, (float)floor_db, curves, curves_off,
+                                       nullptr, nullptr, nbins, k_base, first, count);
   IRA_RETURN_LAUNCH();
 }
