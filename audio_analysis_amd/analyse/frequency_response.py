@@ -4,8 +4,9 @@ Frequency response (whole-segment spectrum) on the GPU.
 Host-side mirror of the reference's analyse/frequency_response.py (dataclasses :43-102,
 analyse_frequency_response_for_channel :173-271, summary :424-432).  The windowed arbitrary-length rFFT is
 ira_rfft_any (float64 Bluestein); dB conversion and peak/centroid statistics are ira_spectrum_* kernels.
-The optional log-frequency smoothing (default off, :117-169) is host-side post-processing of the device
-result, after which the statistics are recomputed from the smoothed curve exactly as the reference does.
+The optional log-frequency smoothing (default off, :117-169) runs on the device too (ira_log_smooth_db, in place, before
+the statistics kernel, which therefore sees the smoothed curve exactly as the reference recomputes them); a host
+restatement remains for grids beyond the kernel's LDS budget.
 """
 from __future__ import annotations
 
@@ -88,6 +89,23 @@ def smooth_log_frequency(frequency_hz, magnitude_db, f_min_hz, f_max_hz, smoothi
     return result
 
 
+def selected_bin_range(nbins: int, step: float, lo_hz: float, hi_hz: float):
+    """(first bin, count) of the rFFT bins whose FLOAT32 frequency float32(k * step) lies in [lo_hz, hi_hz] -- the
+    reference's boolean mask on rfftfreq(n).astype(float32) is one contiguous run; found by arithmetic plus a check of
+    the neighbouring bins' float32 values instead of building the whole axis."""
+    def f32(k):
+        return float(np.float32(float(k) * step))
+    k0 = int(np.clip(np.floor(lo_hz / step), 0, nbins))
+    k0 = max(0, k0 - 2)
+    while k0 < nbins and f32(k0) < lo_hz:
+        k0 += 1
+    k1 = int(np.clip(np.ceil(hi_hz / step), 0, nbins - 1))
+    k1 = min(nbins - 1, k1 + 2)
+    while k1 >= 0 and f32(k1) > hi_hz:
+        k1 -= 1
+    return k0, max(0, k1 - k0 + 1)
+
+
 def spectrum_segments(eng, batch, sample_rate_hz: int, settings, what: str):
     """Time selection for fr / filter -> (starts, lens)."""
     peaks = eng.peaks(batch) if settings.trim_to_peak else np.zeros(batch.count, dtype=np.int64)
@@ -116,8 +134,23 @@ def spectrum_device(eng, batch, sample_rate_hz: int, settings, what: str, want_p
     f_lo = float(np.clip(settings.f_min_hz, 0.0, nyq))
     f_hi = float(np.clip(settings.f_max_hz, f_lo, nyq))
     steps = np.array([rfft_bin_step(int(n), sample_rate_hz) for n in lens], dtype=np.float64)
+    smoothed = False
+    bins_w = int(getattr(settings, "smoothing_log_bins", 0) or 0)
+    if bins_w > 1:
+        # optional, default-off: log-frequency smoothing of the dB curve on the device, in place (ira_log_smooth_db); the
+        # statistics below then see the smoothed curve, exactly as the reference recomputes them (frequency_response.py:236-260)
+        s_lo = float(np.clip(settings.f_min_hz, 1.0, nyq))
+        s_hi = float(np.clip(settings.f_max_hz, s_lo, nyq))
+        rng = [selected_bin_range(int(n) // 2 + 1, float(st), max(1.0, s_lo), max(max(1.0, s_lo), s_hi))
+               for n, st in zip(lens, steps)]
+        k_lo = np.array([r[0] for r in rng], dtype=np.int32)
+        nsel = np.array([r[1] for r in rng], dtype=np.int32)
+        if np.all(nsel > 0):
+            smoothed = eng.log_smooth(mag, off, np.ones(len(rng), np.int32), k_lo, nsel, steps, bins_w,
+                                      int(getattr(settings, "log_bins_per_octave", 96)), through_float32=False)
     stats = eng.spectrum_stats(mag, off, lens, steps, f_lo, f_hi, 1000.0)
-    return dict(spec=spec, off=off, starts=starts, lens=lens, mag=mag, phase=phase, stats=stats, f_lo=f_lo, f_hi=f_hi)
+    return dict(spec=spec, off=off, starts=starts, lens=lens, mag=mag, phase=phase, stats=stats, f_lo=f_lo, f_hi=f_hi,
+                smoothed=smoothed)
 
 
 def analyse_frequency_response_batch(
@@ -138,7 +171,8 @@ def analyse_frequency_response_batch(
 def frequency_response_results(dev, sample_rate_hz: int, channel_names, settings) -> List[ChannelFrequencyResponse]:
     starts, lens, off, mag, f_lo, f_hi = dev["starts"], dev["lens"], dev["off"], dev["mag"], dev["f_lo"], dev["f_hi"]
     nyq = 0.5 * float(sample_rate_hz)
-    smoothing = bool(settings.smoothing_log_bins and int(settings.smoothing_log_bins) > 1)
+    # host-side smoothing only when the device did not do it (grids beyond the kernel's LDS budget)
+    smoothing = bool(settings.smoothing_log_bins and int(settings.smoothing_log_bins) > 1) and not dev.get("smoothed")
     stats = None if smoothing else dev["stats"].cpu().numpy()
     mag_host = mag.cpu().numpy()
     out = []
@@ -177,7 +211,7 @@ def frequency_response_summary_lines(dev, sample_rate_hz: int, channel_names, se
     """One summarise_frequency_response_results_text line per channel from the (n, 8) statistics records alone; the
     spectra stay in HBM.  (With the optional log-frequency smoothing the statistics depend on the smoothed curve: the
     full path is used.)"""
-    if settings.smoothing_log_bins and int(settings.smoothing_log_bins) > 1:
+    if settings.smoothing_log_bins and int(settings.smoothing_log_bins) > 1 and not dev.get("smoothed"):
         return [summarise_frequency_response_results_text([r])
                 for r in frequency_response_results(dev, sample_rate_hz, channel_names, settings)]
     stats = dev["stats"].cpu().numpy()

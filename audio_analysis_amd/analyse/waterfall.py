@@ -158,17 +158,26 @@ def waterfall_device(eng, batch, sample_rate_hz: int, settings: WaterfallAnalysi
                                          bool(settings.use_hann_window), float(settings.floor_db), 64, frame_sel=picks)
     smooth = bool(settings.smoothing_log_bins and int(settings.smoothing_log_bins) > 1)
     if smooth:
-        # optional, default-off: per-slice log-frequency smoothing on the host, then back to the device
-        host = mag.cpu().numpy().copy()
+        # optional, default-off: per-slice log-frequency smoothing (waterfall.py:140-185, float32 round trip around the
+        # convolution) on the device, in place: one curve per (channel, slice) = a column of the (F, S) matrix
         f_all = n_fft // 2 + 1
-        for i in range(batch.count):
-            s = int(cols[i])
-            block = host[mag_off[i] : mag_off[i] + f_all * s].reshape(f_all, s)
-            for j in range(s):
-                block[rows, j] = smooth_log_frequency(f_sel, block[rows, j].astype(np.float32), f_lo, f_hi,
-                                                      int(settings.smoothing_log_bins),
-                                                      int(settings.log_bins_per_octave), through_float32=True)
-        mag = eng.to_dev(host)
+        step = 1.0 / (n_fft * (1.0 / float(sample_rate_hz)))
+        c_off = np.concatenate([mag_off[i] + np.arange(int(cols[i]), dtype=np.int64) for i in range(batch.count)])
+        c_stride = np.concatenate([np.full(int(cols[i]), int(cols[i]), dtype=np.int32) for i in range(batch.count)])
+        ncurves = int(c_off.size)
+        done = eng.log_smooth(mag, c_off, c_stride, np.full(ncurves, k_lo, np.int32), np.full(ncurves, nsel, np.int32),
+                              np.full(ncurves, step, np.float64), int(settings.smoothing_log_bins),
+                              int(settings.log_bins_per_octave), through_float32=True)
+        if not done:                                              # grid beyond the kernel's LDS budget: host restatement
+            host = mag.cpu().numpy().copy()
+            for i in range(batch.count):
+                s = int(cols[i])
+                block = host[mag_off[i] : mag_off[i] + f_all * s].reshape(f_all, s)
+                for j in range(s):
+                    block[rows, j] = smooth_log_frequency(f_sel, block[rows, j].astype(np.float32), f_lo, f_hi,
+                                                          int(settings.smoothing_log_bins),
+                                                          int(settings.log_bins_per_octave), through_float32=True)
+            mag = eng.to_dev(host)
     dyn = float(max(10.0, settings.dynamic_range_db))
     rel, rel_off = eng.waterfall_rel(mag, mag_off, cols, k_lo, nsel,
                                      str(settings.db_reference).lower() == "slice_max", dyn)

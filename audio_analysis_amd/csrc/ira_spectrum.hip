@@ -378,6 +378,87 @@ __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const float* __restri
   }
 }
 
+// ---- optional log-frequency smoothing of a dB curve (reference waterfall.py:140-185, frequency_response.py:117-169; default
+// off).  Per curve: linear interpolation of the selected bins onto a uniform log2(f) grid (numpy.interp), a moving average of
+// `window` grid points (numpy.convolve(.., ones(w)/w, "same": zero beyond the ends), linear interpolation back, float32.
+// through_f32: the waterfall module round-trips the gridded curve through float32 around the convolution.
+// One workgroup per curve; the grid (count <= LS_MAX points) lives in LDS.  The bins of a curve are `stride` elements apart
+// (1 for a spectrum, the slice count for a column of an (F, S) matrix); frequencies are float32(k * fstep) as everywhere.
+constexpr int LS_MAX = 2048;
+constexpr int LS_THREADS = 256;
+
+__device__ __forceinline__ double ls_freq(long long k, double fstep) { return (double)(float)((double)k * fstep); }
+
+__global__ __launch_bounds__(LS_THREADS) void log_smooth_kernel(float* __restrict__ mag, const int64_t* __restrict__ off,
+                                                                const int32_t* __restrict__ stride_a,
+                                                                const int32_t* __restrict__ k_lo_a,
+                                                                const int32_t* __restrict__ nsel_a,
+                                                                const double* __restrict__ fstep_a,
+                                                                const double* __restrict__ lg_lo, const double* __restrict__ lg_hi,
+                                                                const int32_t* __restrict__ count_a, int window,
+                                                                int through_f32) {
+  __shared__ double xg[LS_MAX], on[LS_MAX], sm[LS_MAX];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int count = count_a[c], nsel = nsel_a[c], k_lo = k_lo_a[c];
+  const long long stride = stride_a[c];
+  const double fstep = fstep_a[c], a = lg_lo[c], b = lg_hi[c];
+  if (count < 2 || count > LS_MAX || nsel < 1) return;
+  float* m = mag + off[c];
+  const double step = (b - a) / (double)(count - 1);
+  // ---- onto the grid: numpy.interp(2 ** linspace(a, b, count), fs, ms) ----------------------------------------------
+  for (int g = tid; g < count; g += LS_THREADS) {
+    const double y = (g == count - 1) ? b : (double)g * step + a;
+    const double x = exp2(y);
+    xg[g] = x;
+    double v;
+    const double f0 = ls_freq(k_lo, fstep), fl = ls_freq((long long)k_lo + nsel - 1, fstep);
+    if (nsel == 1 || x <= f0) v = (double)m[(long long)k_lo * stride];
+    else if (x >= fl) v = (double)m[(long long)(k_lo + nsel - 1) * stride];
+    else {
+      int lo = 0, hi = nsel - 1;                             // largest j with fs[j] <= x
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (ls_freq((long long)k_lo + mid, fstep) <= x) lo = mid; else hi = mid;
+      }
+      const double x0 = ls_freq((long long)k_lo + lo, fstep), x1 = ls_freq((long long)k_lo + lo + 1, fstep);
+      const double y0 = (double)m[(long long)(k_lo + lo) * stride], y1 = (double)m[(long long)(k_lo + lo + 1) * stride];
+      const double slope = (y1 - y0) / (x1 - x0);
+      v = slope * (x - x0) + y0;
+    }
+    on[g] = through_f32 ? (double)(float)v : v;
+  }
+  __syncthreads();
+  // ---- moving average, "same" -------------------------------------------------------------------------------------------
+  const double inv_w = 1.0 / (double)window;
+  const int h = (window - 1) / 2;
+  for (int g = tid; g < count; g += LS_THREADS) {
+    int j0 = g + h - (window - 1), j1 = g + h;
+    if (j0 < 0) j0 = 0;
+    if (j1 > count - 1) j1 = count - 1;
+    double acc = 0.0;
+    for (int j = j0; j <= j1; ++j) acc += on[j] * inv_w;
+    sm[g] = through_f32 ? (double)(float)acc : acc;
+  }
+  __syncthreads();
+  // ---- back onto the bins: numpy.interp(fs, grid, smoothed) -> float32 ------------------------------------------------
+  for (int i = tid; i < nsel; i += LS_THREADS) {
+    const double x = ls_freq((long long)k_lo + i, fstep);
+    double v;
+    if (x <= xg[0]) v = sm[0];
+    else if (x >= xg[count - 1]) v = sm[count - 1];
+    else {
+      int lo = 0, hi = count - 1;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (xg[mid] <= x) lo = mid; else hi = mid;
+      }
+      const double slope = (sm[lo + 1] - sm[lo]) / (xg[lo + 1] - xg[lo]);
+      v = slope * (x - xg[lo]) + sm[lo];
+    }
+    m[(long long)(k_lo + i) * stride] = (float)v;
+  }
+}
+
 }  // namespace
 
 extern "C" int32_t ira_spectrum_mag_phase(const double* spec_dev, const int64_t* spec_off_dev, const int32_t* L_dev,
@@ -447,5 +528,21 @@ extern "C" int32_t ira_order_stats(const double* values_dev, const int64_t* off_
   if (nseg <= 0) return nseg == 0 ? IRA_OK : IRA_E_SIZE;
   order_stats_kernel<<<nseg, OS_THREADS, 0, (hipStream_t)stream>>>(values_dev, off_dev, count_dev, ranks_dev, nranks,
                                                                     out_dev);
+  IRA_RETURN_LAUNCH();
+}
+
+extern "C" int32_t ira_log_smooth_db(float* mag_dev, const int64_t* off_dev, const int32_t* stride_dev,
+                                     const int32_t* k_lo_dev, const int32_t* nsel_dev, const double* fstep_dev,
+                                     const double* log2_lo_dev, const double* log2_hi_dev, const int32_t* count_dev,
+                                     int32_t ncurves, int32_t max_count, int32_t window, int32_t through_float32,
+                                     void* stream) {
+  IRA_CHECK_PTR(mag_dev); IRA_CHECK_PTR(off_dev); IRA_CHECK_PTR(stride_dev); IRA_CHECK_PTR(k_lo_dev); IRA_CHECK_PTR(nsel_dev);
+  IRA_CHECK_PTR(fstep_dev); IRA_CHECK_PTR(log2_lo_dev); IRA_CHECK_PTR(log2_hi_dev); IRA_CHECK_PTR(count_dev);
+  if (ncurves <= 0) return ncurves == 0 ? IRA_OK : IRA_E_SIZE;
+  if (window < 1) return IRA_E_SIZE;
+  if (max_count > LS_MAX) return IRA_E_UNSUPPORTED;              // grid does not fit the workgroup's LDS
+  log_smooth_kernel<<<ncurves, LS_THREADS, 0, (hipStream_t)stream>>>(mag_dev, off_dev, stride_dev, k_lo_dev, nsel_dev,
+                                                                     fstep_dev, log2_lo_dev, log2_hi_dev, count_dev, window,
+                                                                     through_float32 ? 1 : 0);
   IRA_RETURN_LAUNCH();
 }

@@ -926,6 +926,31 @@ class Engine:
                                         _ptr(out) if as_float64 else 0, self.stream), "ira_phase_unwrap")
         return out
 
+    def log_smooth(self, mag_dev, off: np.ndarray, stride: np.ndarray, k_lo: np.ndarray, nsel: np.ndarray,
+                   fstep: np.ndarray, window: int, bins_per_octave: int, through_float32: bool) -> bool:
+        """Log-frequency smoothing of dB curves in place (ira_log_smooth_db).  Grid geometry exactly as the reference
+        computes it on the host: log2 of the first / last selected float32 frequency, count = max(8, ceil(span * bpo)) + 1
+        with bpo >= 16.  Returns False (nothing done) when a grid is too large for the kernel."""
+        n = int(np.asarray(off).size)
+        k_lo = np.ascontiguousarray(k_lo, dtype=np.int32)
+        nsel = np.ascontiguousarray(nsel, dtype=np.int32)
+        fstep = np.ascontiguousarray(fstep, dtype=np.float64)
+        f_first = (k_lo.astype(np.float64) * fstep).astype(np.float32).astype(np.float64)
+        f_last = ((k_lo.astype(np.float64) + nsel - 1) * fstep).astype(np.float32).astype(np.float64)
+        with np.errstate(divide="ignore"):
+            a, b = np.log2(f_first), np.log2(f_last)
+        bpo = int(max(16, bins_per_octave))
+        count = (np.maximum(8, np.ceil((b - a) * bpo)).astype(np.int64) + 1).astype(np.int32)
+        if n == 0:
+            return True
+        if int(count.max()) > 2048 or not np.all(np.isfinite(a)):
+            return False
+        d = self.to_dev_pack(np.ascontiguousarray(off, np.int64), np.ascontiguousarray(stride, np.int32), k_lo, nsel, fstep,
+                             a, b, count)
+        check(self.lib.ira_log_smooth_db(_ptr(mag_dev), *[_ptr(x) for x in d], n, int(count.max()), int(window),
+                                         1 if through_float32 else 0, self.stream), "ira_log_smooth_db")
+        return True
+
     def order_stats(self, values_dev, off: np.ndarray, count: np.ndarray, ranks: np.ndarray):
         """sorted(segment)[rank] for every (segment, rank): float64 device tensor (nseg, nranks); ranks is (nseg, nranks)."""
         t = self.torch

@@ -264,6 +264,19 @@ int32_t ira_logbin_aggregate(const float* mag_dev, const int64_t* mag_off_dev, c
                              const int32_t* count_dev, int32_t nbins, float* out_dev,
                              const int64_t* out_off_dev, int32_t frame_major_rows, void* stream);
 
+/* Optional log-frequency smoothing of dB curves IN PLACE (reference analyse/waterfall.py:140-185 and
+ * analyse/frequency_response.py:117-169; default off): curve c = the bins k_lo[c] .. k_lo[c]+nsel[c]-1 (frequencies
+ * float32(k * fstep[c])) of the float32 array at mag_dev + off[c], consecutive bins stride[c] elements apart.  They are
+ * interpolated (numpy.interp) onto count[c] points uniform in log2(f) between log2_lo[c] and log2_hi[c] (the host computes
+ * numpy.log2 of the first / last selected frequency and the count), averaged with a `window`-point box
+ * (numpy.convolve(.., "same")), interpolated back and cast to float32.  through_float32 != 0: the waterfall variant, which
+ * casts the gridded curve to float32 before and after the convolution.  max_count = largest count (<= 2048, else
+ * IRA_E_UNSUPPORTED). */
+int32_t ira_log_smooth_db(float* mag_dev, const int64_t* off_dev, const int32_t* stride_dev, const int32_t* k_lo_dev,
+                          const int32_t* nsel_dev, const double* fstep_dev, const double* log2_lo_dev,
+                          const double* log2_hi_dev, const int32_t* count_dev, int32_t ncurves, int32_t max_count,
+                          int32_t window, int32_t through_float32, void* stream);
+
 /* ---- a19-a21: z-plane AR pole fit ----------------------------------------------------------------------------
  * Covariance-method AR least squares of order `order` on segments x[xoff[e] .. +len[e]) / divisor[e]
  * (divisor_dev may be NULL = 1; if x64_dev != NULL the samples are read from it as float64 instead): normal equations G = A^T A, r = A^T y with A[n,k] = s[n-k], y = -s[n],

@@ -355,3 +355,22 @@ def test_band_masks_and_band_signals_vs_reference_goldens():
             err = np.abs(got[i].astype(np.float64) - want.astype(np.float64))
             assert np.all(err <= 2e-7 * peak + 2e-7 * np.abs(want)), (tag, name, float(err.max()), peak)
             assert np.mean(got[i] == want) > 0.9, (tag, name, float(np.mean(got[i] == want)))   # mostly the same float32
+
+
+def test_band_bank_with_edc_smoothing_vs_oracle():
+    """The default-off dB smoothing of the EDC (decay.py:161-164) inside the band filter bank (rt60bands.py:356-360 hands the
+    decay settings through): smoothed on the device (ira_edc_box_smooth), fitted on the smoothed curve."""
+    from audio_analysis_amd.analyse import decay, rt60bands as rb
+    from audio_analysis_amd.synth import synth_ir
+    x = synth_ir(91, 0, 60000, rt60_seconds=0.3)
+    dec = decay.DecayAnalysisSettings(edc_smoothing_window_samples=65)
+    r = rb.analyse_rt60_bands_for_channel(x, 48000, "m", rb.Rt60BandsAnalysisSettings(band_mode="octave", include_t20=True,
+                                                                                     decay_settings=dec))
+    o = O.analyse_rt60_bands(x, 48000, band_mode="octave", include_t20=True, decay=dict(edc_smoothing_window_samples=65))
+    assert list(r.band_metrics_by_name) == [b["name"] for b in o["bands"]]
+    for name, mm in r.band_metrics_by_name.items():
+        for got, key in ((mm.rt60_t30_seconds, "t30"), (mm.rt60_t20_seconds, "t20")):
+            want = o["metrics"][name][key]
+            assert (got is None) == (want is None), (name, key)
+            if want is not None:
+                assert abs(got - want) <= 1e-4 * abs(want), (name, key, got, want)
