@@ -62,6 +62,30 @@ __device__ __forceinline__ cplx<T> cmul_mi(cplx<T> a) { return {a.im, -a.re}; }
 template <typename T>
 __device__ __forceinline__ cplx<T> cmul_pi(cplx<T> a) { return {-a.im, a.re}; }
 
+// ---- wave-uniform values -------------------------------------------------------------------------------------------------
+// A per-job value read through a pointer the compiler cannot prove read-only (the job tables live beside the work arrays the
+// kernel stores to) is fetched with a VECTOR load every time the source mentions it, each followed by s_waitcnt vmcnt(0) --
+// which also waits for every tile load or store still in flight and turns one round of loads into one round trip per
+// element.  Kernels therefore read their job's values ONCE, before the tile loops, through uniform(): the value moves to
+// scalar registers and the loops contain no loads but the tile's own.
+template <typename T>
+__device__ __forceinline__ T uniform(T v) {
+  static_assert(sizeof(T) == 4 || sizeof(T) == 8, "32- or 64-bit values");
+  if constexpr (sizeof(T) == 4) {
+    int i;
+    __builtin_memcpy(&i, &v, 4);
+    i = __builtin_amdgcn_readfirstlane(i);
+    __builtin_memcpy(&v, &i, 4);
+  } else {
+    int w[2];
+    __builtin_memcpy(w, &v, 8);
+    w[0] = __builtin_amdgcn_readfirstlane(w[0]);
+    w[1] = __builtin_amdgcn_readfirstlane(w[1]);
+    __builtin_memcpy(&v, w, 8);
+  }
+  return v;
+}
+
 // ---- wave-level reductions (64 lanes) ---------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

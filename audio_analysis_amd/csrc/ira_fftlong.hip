@@ -111,50 +111,103 @@ enum InMode { IN_SIGNAL = 0, IN_FILTER = 1, IN_SPECTRUM = 2 };
 enum RowMode { ROW_FWD = 0, ROW_CONV = 1 };
 enum OutMode { OUT_SPECTRUM = 0, OUT_BANDS = 1 };
 
+// The job's own values, read ONCE per workgroup into scalar registers (ira::uniform, all loads first: one round trip).
+// Written as J.xoff[e] / J.bands[2 e] inside the tile loops each of them is a vector load followed by s_waitcnt vmcnt(0),
+// i.e. a memory round trip per element (see ira_common.h, uniform()).
+struct Ctx {
+  long long L;
+  long long o1, o2;                 // IN_SIGNAL: sample offsets (o2 < 0: one signal); IN_SPECTRUM: spectrum offsets
+  long long st;                     // IN_SIGNAL: sample stride (2 = even / odd samples of one real signal)
+  long long nd1, nd2, lw1, lw2;     // IN_SIGNAL: samples actually read / Hann window lengths of the two signals
+  bool two;                         // IN_SPECTRUM: the two bands come from two different spectra
+  BandMask b1, b2;
+  double fv;
+};
+
+__device__ __forceinline__ BandMask uniform_band(const BandMask& p) {
+  BandMask b{};
+  b.kind = ira::uniform(p.kind);
+  b.hp_x0 = ira::uniform(p.hp_x0); b.hp_x1 = ira::uniform(p.hp_x1);
+  b.lp_x0 = ira::uniform(p.lp_x0); b.lp_x1 = ira::uniform(p.lp_x1);
+  return b;
+}
+
+template <int MODE>
+__device__ __forceinline__ Ctx job_ctx(const Jobs& J, int e) {
+  Ctx c{};
+  const int L = J.L[e];
+  if (MODE == IN_SIGNAL) {
+    const long long o1 = J.xoff[e];
+    const long long o2 = J.x2off ? (long long)J.x2off[e] : -1ll;
+    const int il = J.interleave ? J.interleave[e] : 0;
+    const int nd1 = J.data_len ? J.data_len[e] : -1, nd2 = J.data_len2 ? J.data_len2[e] : -1;
+    const int lw1 = J.win_len ? J.win_len[e] : -1, lw2 = J.win_len2 ? J.win_len2[e] : -1;
+    c.L = ira::uniform(L);
+    c.o1 = ira::uniform(o1);
+    c.o2 = ira::uniform(o2);
+    c.st = ira::uniform(il) ? 2 : 1;
+    c.nd1 = J.data_len ? (long long)ira::uniform(nd1) : c.L;
+    c.nd2 = J.data_len2 ? (long long)ira::uniform(nd2) : c.nd1;
+    c.lw1 = J.win_len ? (long long)ira::uniform(lw1) : c.L;
+    c.lw2 = J.win_len2 ? (long long)ira::uniform(lw2) : c.lw1;
+  } else if (MODE == IN_SPECTRUM) {
+    const long long o1 = J.spec_off[e];
+    const long long o2 = J.spec_off2 ? (long long)J.spec_off2[e] : -1ll;
+    const BandMask b1 = J.bands[2 * e], b2 = J.bands[2 * e + 1];
+    const double fv = J.freq_val[e];
+    c.L = ira::uniform(L);
+    c.o1 = ira::uniform(o1);
+    c.o2 = J.spec_off2 ? ira::uniform(o2) : c.o1;
+    c.two = c.o2 != c.o1;
+    c.b1 = uniform_band(b1);
+    c.b2 = uniform_band(b2);
+    c.fv = ira::uniform(fv);
+  } else {
+    c.L = ira::uniform(L);
+  }
+  return c;
+}
+
 // Input generation in two phases, so that ALL of a thread's global loads are in flight before the first one is used (a
 // load that is waited for inside the element loop costs one full memory round trip per element: 8 per workgroup tile):
-// fetch_input does nothing but the loads, value_input the arithmetic.  w = chirp(n, L) and h = hann_at(n, L) come from the
-// caller (recurrences along a thread's elements, see cols_fwd_kernel); IN_FILTER evaluates its mirrored chirp directly
-// (filters are plan data, built once and cached).
-struct RawL { double a, b, c, d; };
+// fetch_input does nothing but the loads -- unconditional ones: a lane beyond the data reads sample 0 of the batch buffer
+// and value_input drops it; nothing is converted or branched on here -- value_input the arithmetic.  w = chirp(n, L) and
+// h = hann_at(n, L) come from the caller (recurrences along a thread's elements, see cols_fwd_kernel); IN_FILTER
+// evaluates its mirrored chirp directly (filters are plan data, built once and cached).
+struct RawL { double a, b, c, d; float fa, fb; };
 constexpr int FL_UI = 4;    // K1: fetches in flight per thread and batch (a fetch is up to four doubles)
 constexpr int FL_U = 8;     // K2 / K3: 16-byte loads in flight per thread and batch
 
 template <int MODE>
-__device__ __forceinline__ RawL fetch_input(const Jobs& J, int e, long long n, long long L, long long nd1, long long nd2) {
-  RawL r{0.0, 0.0, 0.0, 0.0};
+__device__ __forceinline__ RawL fetch_input(const Jobs& J, const Ctx& c, long long n) {
+  RawL r{0.0, 0.0, 0.0, 0.0, 0.0f, 0.0f};
   if (MODE == IN_SIGNAL) {
-    if (n < L) {
-      const long long st = (J.interleave && J.interleave[e]) ? 2 : 1;
-      if (n < nd1) r.a = (double)J.x[J.xoff[e] + st * n];
-      const long long o2 = J.x2off ? J.x2off[e] : -1;
-      if (o2 >= 0 && n < nd2) r.b = (double)J.x[o2 + st * n];
-    }
+    r.fa = *((n < c.L && n < c.nd1) ? J.x + c.o1 + c.st * n : J.x);
+    r.fb = *((c.o2 >= 0 && n < c.L && n < c.nd2) ? J.x + c.o2 + c.st * n : J.x);
   } else if (MODE == IN_SPECTRUM) {
-    if (n < L) {
-      const long long k = n > L / 2 ? L - n : n;
-      const cd xk = J.spec[J.spec_off[e] + k];
-      r.a = xk.re; r.b = xk.im;
-      if (J.spec_off2 != nullptr && J.spec_off2[e] != J.spec_off[e]) {
-        const cd x2 = J.spec[J.spec_off2[e] + k];
-        r.c = x2.re; r.d = x2.im;
-      }
+    const long long k = n > c.L / 2 ? c.L - n : n;
+    const long long kk = n < c.L ? k : 0;
+    const cd xk = J.spec[c.o1 + kk];
+    r.a = xk.re; r.b = xk.im;
+    if (c.two) {
+      const cd x2 = J.spec[c.o2 + kk];
+      r.c = x2.re; r.d = x2.im;
     }
   }
   return r;
 }
 
 template <int MODE>
-__device__ __forceinline__ cd value_input(const Jobs& J, int e, long long n, long long L, long long M, cd w, double h,
+__device__ __forceinline__ cd value_input(const Jobs& J, const Ctx& c, long long n, long long M, cd w, double h,
                                           double h2, const RawL& r) {
+  const long long L = c.L;
   if (MODE == IN_SIGNAL) {
     if (n >= L) return {0.0, 0.0};
-    double v = r.a, v2 = r.b;
+    double v = n < c.nd1 ? (double)r.fa : 0.0, v2 = (c.o2 >= 0 && n < c.nd2) ? (double)r.fb : 0.0;
     if (J.use_hann) {
       v *= h; v2 *= h2;
     }
-    const long long o2 = J.x2off ? J.x2off[e] : -1;
-    if (o2 < 0) return {v * w.re, v * w.im};
+    if (c.o2 < 0) return {v * w.re, v * w.im};
     return {v * w.re - v2 * w.im, v * w.im + v2 * w.re};
   } else if (MODE == IN_FILTER) {
     long long m = n;
@@ -170,11 +223,11 @@ __device__ __forceinline__ cd value_input(const Jobs& J, int e, long long n, lon
     const bool upper = n > L / 2;
     const long long k = upper ? L - n : n;
     const cd xk = {r.a, upper ? -r.b : r.b};
-    const float f = (float)((double)k * J.freq_val[e]);
-    const double m1 = (double)mask_at(J.bands[2 * e], f);
-    const double m2 = (double)mask_at(J.bands[2 * e + 1], f);
+    const float f = (float)((double)k * c.fv);
+    const double m1 = (double)mask_at(c.b1, f);
+    const double m2 = (double)mask_at(c.b2, f);
     cd wk;
-    if (J.spec_off2 == nullptr || J.spec_off2[e] == J.spec_off[e]) {
+    if (!c.two) {
       wk = ira::cmul(xk, cd{m1, m2});
     } else {                                        // X1 m1 + i X2 m2: band 1 of one channel, band 2 of another
       const cd x2 = {r.c, upper ? -r.d : r.d};
@@ -205,10 +258,12 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   unsigned bx, by;
   remap_xcd(bx, by);
   const int e = by;
-  const long long L = J.L[e];
+  const Ctx ctx = job_ctx<MODE>(J, e);
+  const long long L = ctx.L;
   const unsigned N1 = 1u << g.log2n1, N2 = 1u << g.log2n2;
   const long long M = 1ll << g.log2m;
   const unsigned n2_0 = bx * C;
+  const unsigned lc = 31u - (unsigned)__builtin_clz((unsigned)C), cm = (unsigned)C - 1u;   // C is a power of two (make_plan)
   const unsigned stride = N1 + 1;
   const int tid = threadIdx.x;
   // A thread's elements are n_k = n_0 + k*dn (same column, rows FL_THREADS/C apart).  The chirp exp(-i pi n^2/L) along
@@ -216,17 +271,15 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   // three exactly reduced sincospi per thread instead of one per element; the Hann window is a plain rotation.
   // (<= N1*C/FL_THREADS = 8 steps, so the recurrences add a few 1e-16.)
   {
-    const unsigned c = tid % C, n1_0 = tid / C;
-    const long long dn = (long long)(FL_THREADS / C) * N2;
+    const unsigned c = tid & cm, n1_0 = tid >> lc;
+    const long long dn = (long long)(FL_THREADS >> lc) * N2;
     const long long n0 = (long long)n1_0 * N2 + n2_0 + c;
     cd w = {1.0, 0.0}, d = {1.0, 0.0}, e2 = {1.0, 0.0};
     // Hann windows of the (up to) two signals: window length and sample count may differ from the transform length
-    long long lw1 = L, lw2 = L, nd1 = L, nd2 = L;
+    long long lw1 = L, lw2 = L;
     if (MODE == IN_SIGNAL) {
-      if (J.win_len) lw1 = J.win_len[e];
-      if (J.data_len) nd1 = J.data_len[e];
-      lw2 = J.win_len2 ? (long long)J.win_len2[e] : lw1;
-      nd2 = J.data_len2 ? (long long)J.data_len2[e] : nd1;
+      lw1 = ctx.lw1;
+      lw2 = ctx.lw2;
     }
     double hc = 1.0, hs = 0.0, rc = 1.0, rs = 0.0, hc2 = 1.0, hs2 = 0.0, rc2 = 1.0, rs2 = 0.0;
     if (MODE != IN_FILTER) {
@@ -235,7 +288,7 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       e2 = unit_q(2 * dn * dn, L);
       if (MODE == IN_SIGNAL && J.use_hann) {
         // window index of transform index n: n (plain), or 2n / 2n+1 for the even / odd samples of an interleaved job
-        const long long st = (J.interleave && J.interleave[e]) ? 2 : 1;
+        const long long st = ctx.st;
         const long long i1 = st * n0, i2 = st * n0 + (st - 1);
         if (lw1 > 1) {
           sincospi((double)(2 * i1 + 1 - lw1) / (double)(lw1 - 1), &hs, &hc);
@@ -254,17 +307,17 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 #pragma unroll
       for (int u = 0; u < FL_UI; ++u) {
         const unsigned j = jb + u < cnt ? jb + u : cnt - 1;                 // clamp: unconditional loads
-        raw[u] = fetch_input<MODE>(J, e, n0 + (long long)j * dn, L, nd1, nd2);
+        raw[u] = fetch_input<MODE>(J, ctx, n0 + (long long)j * dn);
       }
 #pragma unroll
       for (int u = 0; u < FL_UI; ++u) {
         const unsigned j = jb + u;
         if (j < cnt) {
-          const unsigned n1 = (tid + FL_THREADS * j) / C;
+          const unsigned n1 = (tid + FL_THREADS * j) >> lc;
           const long long n = n0 + (long long)j * dn;
           const double h = (lw1 > 1) ? 0.5 + 0.5 * hc : 1.0;
           const double h2 = (lw2 > 1) ? 0.5 + 0.5 * hc2 : 1.0;
-          lds[c * stride + n1] = (g.ablate & 1) ? cd{(double)n, 1.0} : value_input<MODE>(J, e, n, L, M, w, h, h2, raw[u]);
+          lds[c * stride + n1] = (g.ablate & 1) ? cd{(double)n, 1.0} : value_input<MODE>(J, ctx, n, M, w, h, h2, raw[u]);
           w = ira::cmul(w, d);
           d = ira::cmul(d, e2);
           const double nc = hc * rc - hs * rs;
@@ -287,7 +340,7 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     for (int u = 0; u < FL_UI; ++u) {
       unsigned i = base + tid + FL_THREADS * u;
       i = i < total_o ? i : total_o - 1;
-      const unsigned p = (n2_0 + i % C) * ira::lds_brev(i / C, g.log2n1);
+      const unsigned p = (n2_0 + (i & cm)) * ira::lds_brev(i >> lc, g.log2n1);
       th[u] = g.t1[p >> g.log2n2];
       tl[u] = g.tf[p & (N2 - 1u)];
     }
@@ -295,7 +348,7 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     for (int u = 0; u < FL_UI; ++u) {
       const unsigned i = base + tid + FL_THREADS * u;
       if (i >= total_o) continue;
-      const unsigned c = i % C, r = i / C;
+      const unsigned c = i & cm, r = i >> lc;
       const cd v = ira::cmul(lds[c * stride + r], ira::cmul(th[u], tl[u]));
       if ((g.ablate & 4) && v.re != 12345.678) continue;
       w[(long long)r * N2 + n2_0 + c] = v;
@@ -317,25 +370,29 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   const long long M = 1ll << g.log2m;
   const unsigned r0 = bx * R;
   const int tid = threadIdx.x;
+  const int filt = MODE == ROW_CONV ? ira::uniform(J.bidx[e]) : 0;            // before the tile loop (see Ctx)
   cd* w = work + (long long)e * M + (long long)r0 * N2;
   const unsigned total = N2 * (unsigned)R;
   for (unsigned base = 0; base < total; base += FL_THREADS * FL_U) {
+    // All loads of the batch in flight together.  Index clamped, and the LDS store NOT guarded (a lane past the end stores
+    // the last element's own value onto itself): behind an `if (i < total)` the compiler sinks each load into its store's
+    // branch and the eight loads become eight serial round trips (seen in the ISA: load, s_waitcnt vmcnt(0), ds_write, x8).
     cd raw[FL_U];
 #pragma unroll
     for (int u = 0; u < FL_U; ++u) {
-      unsigned i = base + tid + FL_THREADS * u;
-      raw[u] = w[i < total ? i : total - 1];                  // all loads of the batch in flight together
+      const unsigned i = base + tid + FL_THREADS * u;
+      raw[u] = w[i < total ? i : total - 1];
     }
 #pragma unroll
     for (int u = 0; u < FL_U; ++u) {
       const unsigned i = base + tid + FL_THREADS * u;
-      if (i < total) lds[i] = raw[u];
+      lds[i < total ? i : total - 1] = raw[u];
     }
   }
   __syncthreads();
   if (!(g.ablate & 8)) ira::lds_fft_dif<double, FL_LR>(lds, g.log2n2, g.t2, 1u, tid, FL_THREADS, R, N2);
   if (MODE == ROW_CONV) {
-    const cd* b = J.bfilt + (long long)J.bidx[e] * M + (long long)r0 * N2;
+    const cd* b = J.bfilt + (long long)filt * M + (long long)r0 * N2;
     if (!(g.ablate & 16))
       for (unsigned base = 0; base < total; base += FL_THREADS * FL_U) {
         cd fb[FL_U];
@@ -388,14 +445,30 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   unsigned bx, by;
   remap_xcd(bx, by);
   const int e = by;
-  const long long L = J.L[e];
+  // the job's length and output offsets, once (scalar registers; see Ctx)
+  long long L, out1, out2 = -1;
+  bool paired = false;
+  {
+    const int l = J.L[e];
+    if (MODE == OUT_SPECTRUM) {
+      const long long x2 = J.x2off ? (long long)J.x2off[e] : -1ll, zo = J.x2off ? (long long)J.zpair_off[e] : 0ll;
+      const long long so = J.spec_out_off[e];
+      paired = ira::uniform(x2) >= 0;
+      out1 = paired ? ira::uniform(zo) : ira::uniform(so);
+    } else {
+      const long long y1 = J.y1_off[e], y2 = J.y2_off[e];
+      out1 = ira::uniform(y1);
+      out2 = ira::uniform(y2);
+    }
+    L = ira::uniform(l);
+  }
   const unsigned N1 = 1u << g.log2n1, N2 = 1u << g.log2n2;
   const long long M = 1ll << g.log2m;
   const unsigned n2_0 = bx * C;
+  const unsigned lc = 31u - (unsigned)__builtin_clz((unsigned)C), cm = (unsigned)C - 1u;   // C is a power of two (make_plan)
   const unsigned stride = N1 + 1;
   const int tid = threadIdx.x;
   // outputs needed: n <= L/2 (spectrum) or n < L (bands); rows beyond that are computed but not stored
-  const bool paired = (MODE == OUT_SPECTRUM) && J.x2off != nullptr && J.x2off[e] >= 0;
   const long long n_need = (MODE == OUT_SPECTRUM && !paired) ? L / 2 + 1 : L;
   const cd* w = work + (long long)e * M;
   const unsigned total = N1 * (unsigned)C;
@@ -405,37 +478,46 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     for (int u = 0; u < FL_U; ++u) {
       unsigned i = base + tid + FL_THREADS * u;
       i = i < total ? i : total - 1;
-      raw[u] = (g.ablate & 256) ? cd{(double)i, 1.0} : w[(long long)(i / C) * N2 + n2_0 + i % C];
+      raw[u] = (g.ablate & 256) ? cd{(double)i, 1.0} : w[(long long)(i >> lc) * N2 + n2_0 + (i & cm)];
     }
 #pragma unroll
     for (int u = 0; u < FL_U; ++u) {
       const unsigned i = base + tid + FL_THREADS * u;
-      if (i < total) lds[(i % C) * stride + i / C] = raw[u];
+      if (i < total) lds[(i & cm) * stride + (i >> lc)] = raw[u];
     }
   }
   __syncthreads();
   if (!(g.ablate & 32)) ira::lds_fft_dit<double, FL_LR>(lds, g.log2n1, g.t1, 1u, true, tid, FL_THREADS, C, stride);
   const double inv_m = 1.0 / (double)M;
+  // The output chirp exp(-i pi n^2 / L) along a thread's elements n_j = n_0 + j dn by the same recurrence as in K1
+  // (w_{j+1} = w_j d_j, d_{j+1} = d_j e2: three exactly reduced sincospi per thread instead of a 64-bit modulo and a
+  // sincospi per element, which were most of this kernel's instructions; <= 8 steps, a few 1e-16).
+  const long long dn = (long long)(FL_THREADS >> lc) * N2;
+  const long long n0 = (long long)((unsigned)tid >> lc) * N2 + n2_0 + ((unsigned)tid & cm);
+  cd cw = unit_q(n0 * n0, L), cdl = unit_q(2 * n0 * dn + dn * dn, L);
+  const cd ce2 = unit_q(2 * dn * dn, L);
   for (unsigned i = tid; i < N1 * (unsigned)C; i += FL_THREADS) {
-    const unsigned c = i % C, n1 = i / C;
+    const unsigned c = i & cm, n1 = i >> lc;
     const long long n = (long long)n1 * N2 + n2_0 + c;
+    const cd wn = cw;
+    cw = ira::cmul(cw, cdl);
+    cdl = ira::cmul(cdl, ce2);
     if (n >= n_need) continue;
     cd v = lds[c * stride + n1];
-    if (!(g.ablate & 64)) v = ira::cmul(v, chirp(n, L));
+    if (!(g.ablate & 64)) v = ira::cmul(v, wn);
     if (MODE == OUT_SPECTRUM) {
       v.re *= inv_m; v.im *= inv_m;
       if (paired) {
-        J.zpair[J.zpair_off[e] + n] = v;         // split into the two half spectra by pair_split_kernel
+        J.zpair[out1 + n] = v;                   // split into the two half spectra by pair_split_kernel
       } else {
         if (n == 0 || (2 * n == L)) v.im = 0.0;  // DC / Nyquist of a real signal
-        J.spec_out[J.spec_out_off[e] + n] = v;
+        J.spec_out[out1 + n] = v;
       }
     } else {
       const double sc = inv_m / (double)L;
       // y1 + i y2 = conj(v) / L
-      J.y[J.y1_off[e] + n] = (float)(v.re * sc);
-      const long long o2 = J.y2_off[e];
-      if (o2 >= 0) J.y[o2 + n] = (float)(-v.im * sc);
+      J.y[out1 + n] = (float)(v.re * sc);
+      if (out2 >= 0) J.y[out2 + n] = (float)(-v.im * sc);
     }
   }
 }
@@ -450,9 +532,10 @@ __global__ __launch_bounds__(256) void pair_split_kernel(Jobs J) {
   const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (k > L / 2) return;
   const cd* z = J.zpair + J.zpair_off[e];
+  const long long o1 = J.spec_out_off[e], o2 = J.spec_out_off2[e];      // before the stores (see Ctx)
   const cd zk = z[k], zl = z[k == 0 ? 0 : L - k];
-  J.spec_out[J.spec_out_off[e] + k] = {0.5 * (zk.re + zl.re), 0.5 * (zk.im - zl.im)};
-  J.spec_out[J.spec_out_off2[e] + k] = {0.5 * (zk.im + zl.im), 0.5 * (zl.re - zk.re)};
+  J.spec_out[o1 + k] = {0.5 * (zk.re + zl.re), 0.5 * (zk.im - zl.im)};
+  J.spec_out[o2 + k] = {0.5 * (zk.im + zl.im), 0.5 * (zl.re - zk.re)};
 }
 
 // Interleaved jobs: z[m] = x[2m] + i x[2m+1], Z = DFT_L(z); the real signal's spectrum of length 2L is

@@ -25,8 +25,21 @@ constexpr int SM_THREADS = 256;
 constexpr int SM_MAX_N = 1024;     // largest sub-transform (LDS: 2 buffers x C x N x 16 B)
 constexpr int SM_MAX_RADICES = 12;
 
+// Division of a small non-negative integer by a plan constant d: floor(x / d) = umulhi(x, magic), magic = floor(2^32 / d) + 1,
+// exact for x < 2^32 / d (here x < 2^20, d <= 1024).  The tile index arithmetic of these kernels (i / C, i % C, k1 / C2,
+// p / N2, the mixed-radix digits of dif_slot) was ~40 % of their VALU instructions as generic 32-bit divisions (~25
+// instructions each), and the kernels are VALU-bound (~70 % busy).
+struct FastDiv { unsigned d, magic; };
+__host__ __device__ inline FastDiv fast_div_of(unsigned d) {
+  return {d, d <= 1u ? 0u : (unsigned)(0x100000000ull / d) + 1u};
+}
+__device__ __forceinline__ unsigned fdiv(unsigned x, FastDiv f) { return f.d <= 1u ? x : __umulhi(x, f.magic); }
+
 struct SmoothPlan {
   int n, n1, n2;
+  FastDiv dc1, dc2, dn1, dn2;       // the same numbers as divisors
+  FastDiv dr1[12], dr2[12];         // radices as divisors, and the span N / (r_0 ... r_i) of digit i after lds_fft_dif_inplace
+  int span1[12], span2[12];
   int c1, c2;                       // columns per workgroup in pass 1 / pass 2
   int ld1, ld2;                     // LDS column strides (n1 / n2 plus a bank-conflict pad, see column_stride)
   int r1[SM_MAX_RADICES], nr1;      // radices of the N1-point transform
@@ -142,14 +155,13 @@ __device__ __forceinline__ void bfly<16>(cd (&a)[16]) {
 // fine[t & 31] = W_N^(t & 31): two LDS reads and one complex multiply (a dependent GLOBAL load per butterfly was the
 // critical path of every pass, an in-kernel sincospi costs ~100 instructions).
 constexpr int SM_TW = 66;       // 33 coarse + 33 fine entries
-__device__ __forceinline__ void build_twiddle_lds(cd* tab, const cd* __restrict__ tw, int N, int tid) {
-  if (tid < 33) {
-    const int t = 32 * tid;
-    tab[tid] = t < N ? tw[t] : cd{1.0, 0.0};
-  } else if (tid < 66) {
-    const int t = tid - 33;
-    tab[tid] = t < N ? tw[t] : cd{1.0, 0.0};
-  }
+// In two halves: the table LOAD is issued before the tile's loads, the LDS write comes after them (one round trip for both).
+__device__ __forceinline__ cd twiddle_lds_fetch(const cd* __restrict__ tw, int N, int tid) {
+  const int t = tid < 33 ? 32 * tid : tid - 33;
+  return (tid < 66 && t < N) ? tw[t] : cd{1.0, 0.0};
+}
+__device__ __forceinline__ void twiddle_lds_put(cd* tab, cd v, int tid) {
+  if (tid < 66) tab[tid] = v;
 }
 
 template <int R>
@@ -272,15 +284,13 @@ __device__ void lds_fft_dif_inplace(cd* a, int N, int ld, const int* radices, in
   }
 }
 
-// slot of X[k] after lds_fft_dif_inplace
-__device__ __forceinline__ int dif_slot(int k, int N, const int* radices, int nrad) {
-  int slot = 0, span = N;
+// slot of X[k] after lds_fft_dif_inplace: digit i of k (mixed radix r_0, r_1, ...) times span_i = N / (r_0 ... r_i)
+__device__ __forceinline__ int dif_slot(int k, const FastDiv* radices, const int* span, int nrad) {
+  int slot = 0;
 #pragma unroll 1
   for (int i = 0; i < nrad; ++i) {
-    const int r = radices[i];
-    const int q = k / r;
-    span /= r;
-    slot += (k - q * r) * span;
+    const int q = (int)fdiv((unsigned)k, radices[i]);
+    slot += (k - q * (int)radices[i].d) * span[i];
     k = q;
   }
   return slot;
@@ -288,7 +298,7 @@ __device__ __forceinline__ int dif_slot(int k, int N, const int* radices, int nr
 
 // W_n^p for p < n = N1*N2 as a coarse (N1 entries) times a fine (N2 entries) table value.
 __device__ __forceinline__ cd twiddle_n(const SmoothPlan& P, unsigned p) {      // p < n <= 2^20
-  const unsigned hi = p / (unsigned)P.n2, lo = p - hi * (unsigned)P.n2;
+  const unsigned hi = fdiv(p, P.dn2), lo = p - hi * (unsigned)P.n2;
   return ira::cmul(P.t1[hi], P.tf[lo]);
 }
 
@@ -322,28 +332,77 @@ __device__ __forceinline__ double hann_s(long long i, long long L) {
   return 0.5 + 0.5 * cospi((double)(2 * i + 1 - L) / (double)(L - 1));
 }
 
-// Input generation in two phases so that a thread's memory reads are all in flight before the first one is used:
-// smooth_fetch does nothing but the loads, smooth_value the arithmetic (window, masks, Hermitian extension).
-struct RawIn { double a, b, c, d; };
+// The job's own values (offsets, lengths, band records), read ONCE per workgroup into scalar registers (ira::uniform): the
+// tile loops below then contain no loads but the tile's own.  (As plain J.xoff[e] / J.bands[2 e] expressions inside the
+// loops every one of them was a vector load followed by s_waitcnt vmcnt(0), i.e. one memory round trip per ELEMENT: the
+// pass-1 input phase of the band inverses took 47 k cycles of a 69 k-cycle tile)
+struct SCtx {
+  long long o1, o2;                 // SM_SIGNAL: sample offsets (o2 < 0: one signal); SM_SPECTRUM: spectrum offsets
+  long long nd1, nd2, lw1, lw2;     // SM_SIGNAL: samples actually read / Hann window lengths of the two signals
+  bool two;                         // SM_SPECTRUM: the two bands come from two different spectra
+  BandMaskS b1, b2;
+  double fv;
+};
 
+__device__ __forceinline__ BandMaskS uniform_band(const BandMaskS& p) {
+  BandMaskS b{};
+  b.kind = ira::uniform(p.kind);
+  b.hp_x0 = ira::uniform(p.hp_x0); b.hp_x1 = ira::uniform(p.hp_x1);
+  b.lp_x0 = ira::uniform(p.lp_x0); b.lp_x1 = ira::uniform(p.lp_x1);
+  return b;
+}
+
+// (all loads first, then the moves to scalar registers: ONE round trip)
 template <int MODE>
-__device__ __forceinline__ RawIn smooth_fetch(const SmoothPlan& P, const SJobs& J, int e, long long i) {
-  RawIn r{0.0, 0.0, 0.0, 0.0};
+__device__ __forceinline__ SCtx smooth_ctx(const SmoothPlan& P, const SJobs& J, int e) {
+  SCtx c{};
   const long long n = P.n;
   if (MODE == SM_SIGNAL) {
-    const long long nd1 = J.data_len ? (long long)J.data_len[e] : n;
-    if (i < nd1) r.a = (double)J.x[J.xoff[e] + i];
-    const long long o2 = J.x2off ? J.x2off[e] : -1;
-    if (o2 >= 0) {
-      const long long nd2 = J.data_len2 ? (long long)J.data_len2[e] : nd1;
-      if (i < nd2) r.b = (double)J.x[o2 + i];
-    }
+    const long long o1 = J.xoff[e];
+    const long long o2 = J.x2off ? (long long)J.x2off[e] : -1ll;
+    const int nd1 = J.data_len ? J.data_len[e] : (int)n, nd2 = J.data_len2 ? J.data_len2[e] : -1;
+    const int lw1 = J.win_len ? J.win_len[e] : (int)n, lw2 = J.win_len2 ? J.win_len2[e] : -1;
+    c.o1 = ira::uniform(o1);
+    c.o2 = ira::uniform(o2);
+    c.nd1 = ira::uniform(nd1);
+    c.nd2 = J.data_len2 ? (long long)ira::uniform(nd2) : c.nd1;
+    c.lw1 = ira::uniform(lw1);
+    c.lw2 = J.win_len2 ? (long long)ira::uniform(lw2) : c.lw1;
+  } else {
+    const long long o1 = J.sp_off[e];
+    const long long o2 = J.sp_off2 ? (long long)J.sp_off2[e] : -1ll;
+    const BandMaskS b1 = J.bands[2 * e], b2 = J.bands[2 * e + 1];
+    const double fv = J.freq_val[e];
+    c.o1 = ira::uniform(o1);
+    c.o2 = J.sp_off2 ? ira::uniform(o2) : c.o1;
+    c.two = c.o2 != c.o1;
+    c.b1 = uniform_band(b1);
+    c.b2 = uniform_band(b2);
+    c.fv = ira::uniform(fv);
+  }
+  return c;
+}
+
+// Input generation in two phases so that a thread's memory reads are all in flight before the first one is used:
+// smooth_fetch does nothing but the loads, smooth_value the arithmetic (window, masks, Hermitian extension).
+// (The loads are UNCONDITIONAL -- a lane beyond the data reads sample 0 of the batch buffer and drops it in smooth_value --
+// and nothing is computed from them here: a load inside a per-lane branch, or one converted on the spot, is waited for at
+// once, which made the forward pass-1 input phase ten serial round trips.)
+struct RawIn { double a, b, c, d; float fa, fb; };
+
+template <int MODE>
+__device__ __forceinline__ RawIn smooth_fetch(const SmoothPlan& P, const SJobs& J, const SCtx& c, long long i) {
+  RawIn r{0.0, 0.0, 0.0, 0.0, 0.0f, 0.0f};
+  const long long n = P.n;
+  if (MODE == SM_SIGNAL) {
+    r.fa = *(i < c.nd1 ? J.x + c.o1 + i : J.x);
+    r.fb = *((c.o2 >= 0 && i < c.nd2) ? J.x + c.o2 + i : J.x);       // no branch around it either (same reason)
   } else {
     const long long k = i > n / 2 ? n - i : i;
-    const cd x1 = J.spec[J.sp_off[e] + k];
+    const cd x1 = J.spec[c.o1 + k];
     r.a = x1.re; r.b = x1.im;
-    if (J.sp_off2 != nullptr && J.sp_off2[e] != J.sp_off[e]) {
-      const cd x2 = J.spec[J.sp_off2[e] + k];
+    if (c.two) {
+      const cd x2 = J.spec[c.o2 + k];
       r.c = x2.re; r.d = x2.im;
     }
   }
@@ -351,14 +410,13 @@ __device__ __forceinline__ RawIn smooth_fetch(const SmoothPlan& P, const SJobs& 
 }
 
 template <int MODE>
-__device__ __forceinline__ cd smooth_value(const SmoothPlan& P, const SJobs& J, int e, long long i, const RawIn& r) {
+__device__ __forceinline__ cd smooth_value(const SmoothPlan& P, const SJobs& J, const SCtx& c, long long i, const RawIn& r) {
   const long long n = P.n;
   if (MODE == SM_SIGNAL) {
-    double v = r.a, v2 = r.b;
+    double v = i < c.nd1 ? (double)r.fa : 0.0, v2 = (c.o2 >= 0 && i < c.nd2) ? (double)r.fb : 0.0;
     if (J.use_hann) {
-      const long long lw1 = J.win_len ? (long long)J.win_len[e] : n;
-      v *= hann_s(i, lw1);
-      if (J.x2off && J.x2off[e] >= 0) v2 *= hann_s(i, J.win_len2 ? (long long)J.win_len2[e] : lw1);
+      v *= hann_s(i, c.lw1);
+      if (c.o2 >= 0) v2 *= hann_s(i, c.lw2);
     }
     return {v, v2};
   } else {
@@ -366,11 +424,11 @@ __device__ __forceinline__ cd smooth_value(const SmoothPlan& P, const SJobs& J, 
     const bool upper = i > n / 2;
     const long long k = upper ? n - i : i;
     cd x1 = {r.a, upper ? -r.b : r.b};
-    const float f = (float)((double)k * J.freq_val[e]);
-    const double m1 = (double)mask_s(J.bands[2 * e], f);
-    const double m2 = (double)mask_s(J.bands[2 * e + 1], f);
+    const float f = (float)((double)k * c.fv);
+    const double m1 = (double)mask_s(c.b1, f);
+    const double m2 = (double)mask_s(c.b2, f);
     cd w;
-    if (J.sp_off2 == nullptr || J.sp_off2[e] == J.sp_off[e]) {
+    if (!c.two) {
       w = ira::cmul(x1, cd{m1, m2});
     } else {
       const cd x2 = {r.c, upper ? -r.d : r.d};
@@ -411,24 +469,28 @@ __global__ __launch_bounds__(SM_THREADS, (MODE == SM_SIGNAL ? 6 : 5)) void smoot
   const int n2_0 = (int)bx * C;
   unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
   SM_STAMP(s0);
-  build_twiddle_lds(twl, P.t1, N1, tid);                  // issued first: overlaps the input round trip below
+  const SCtx ctx = smooth_ctx<MODE>(P, J, e);
+  const cd twv = twiddle_lds_fetch(P.t1, N1, tid);        // issued first: shares the round trip of the tile loads below
   const int total1 = N1 * C;
   for (int base = 0; base < total1; base += SM_THREADS * SM_UC) {
     RawIn raw[SM_UC];
     auto index_of = [&](int u) -> long long {               // recomputed, not kept: registers are what limits occupancy
       int i = base + tid + SM_THREADS * u;
       i = i < total1 ? i : total1 - 1;                      // clamp: every fetch is unconditional (stays in registers)
-      return (long long)(i / C) * N2 + n2_0 + i % C;
+      const int row = (int)fdiv((unsigned)i, P.dc1);
+      return (long long)row * N2 + n2_0 + (i - row * C);
     };
 #pragma unroll
-    for (int u = 0; u < SM_UC; ++u) raw[u] = smooth_fetch<MODE>(P, J, e, index_of(u));
+    for (int u = 0; u < SM_UC; ++u) raw[u] = smooth_fetch<MODE>(P, J, ctx, index_of(u));
 #pragma unroll
     for (int u = 0; u < SM_UC; ++u) {
       const int i = base + tid + SM_THREADS * u;
-      const cd v = smooth_value<MODE>(P, J, e, index_of(u), raw[u]);
-      if (i < total1) a[(i % C) * LD + i / C] = v;
+      const cd v = smooth_value<MODE>(P, J, ctx, index_of(u), raw[u]);
+      const int row = (int)fdiv((unsigned)i, P.dc1);
+      if (i < total1) a[(i - row * C) * LD + row] = v;
     }
   }
+  twiddle_lds_put(twl, twv, tid);
   __syncthreads();
   SM_STAMP(s1);
   const cd* r = a;
@@ -436,12 +498,29 @@ __global__ __launch_bounds__(SM_THREADS, (MODE == SM_SIGNAL ? 6 : 5)) void smoot
   else r = lds_fft_stockham(a, b, N1, P.r1, P.nr1, twl, tid, C);
   SM_STAMP(s2);
   cd* w = work + (long long)e * P.n;
-  for (int i = tid; i < N1 * C; i += SM_THREADS) {
-    const int c = i / N1, k1 = i - c * N1;
-    const int n2 = n2_0 + c;
-    const int C2 = P.c2;
-    w[(long long)(k1 / C2) * ((long long)N2 * C2) + (long long)n2 * C2 + k1 % C2] =
-        ira::cmul(r[c * LD + (P.inplace ? dif_slot(k1, N1, P.r1, P.nr1) : k1)], twiddle_n(P, (unsigned)k1 * (unsigned)n2));
+  const int C2 = P.c2;
+  for (int base = 0; base < total1; base += SM_THREADS * SM_UC) {
+    cd th[SM_UC], tl[SM_UC];                               // the twiddle factors W_n^(k1 n2) of the batch: loads first
+#pragma unroll
+    for (int u = 0; u < SM_UC; ++u) {
+      int i = base + tid + SM_THREADS * u;
+      i = i < total1 ? i : total1 - 1;
+      const int c = (int)fdiv((unsigned)i, P.dn1), k1 = i - c * N1;
+      const unsigned p = (unsigned)k1 * (unsigned)(n2_0 + c);
+      const unsigned hi = fdiv(p, P.dn2);
+      th[u] = P.t1[hi];
+      tl[u] = P.tf[p - hi * (unsigned)N2];
+    }
+#pragma unroll
+    for (int u = 0; u < SM_UC; ++u) {
+      const int i = base + tid + SM_THREADS * u;
+      if (i >= total1) continue;
+      const int c = (int)fdiv((unsigned)i, P.dn1), k1 = i - c * N1;
+      const int n2 = n2_0 + c;
+      const int kt = (int)fdiv((unsigned)k1, P.dc2);                 // tile of k1 in pass 2
+      w[(long long)kt * ((long long)N2 * C2) + (long long)n2 * C2 + (k1 - kt * C2)] =
+          ira::cmul(r[c * LD + (P.inplace ? dif_slot(k1, P.dr1, P.span1, P.nr1) : k1)], ira::cmul(th[u], tl[u]));
+    }
   }
   if (P.stamp) {
     SM_STAMP(s3);
@@ -466,22 +545,40 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_rows_kernel(SmoothPlan P, S
   const cd* w = work + (long long)e * P.n;
   unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
   SM_STAMP(s0);
-  build_twiddle_lds(twl, P.t2, N2, tid);                  // issued first: overlaps the tile load below
+  // the job's output offsets, once (scalar registers; see SCtx)
+  bool paired = false;
+  long long out1 = 0, out2 = -1;
+  if (OUT == SM_OUT_SPEC) {
+    const long long x2 = J.x2off ? (long long)J.x2off[e] : -1ll, zo = J.x2off ? (long long)J.zpair_off[e] : 0ll;
+    const long long so = J.spec_off[e];
+    paired = ira::uniform(x2) >= 0;
+    out1 = paired ? ira::uniform(zo) : ira::uniform(so);
+  } else {
+    const long long y1 = J.y1_off[e], y2 = J.y2_off[e];
+    out1 = ira::uniform(y1);
+    out2 = ira::uniform(y2);
+  }
+  const cd twv = twiddle_lds_fetch(P.t2, N2, tid);        // issued first: shares the round trip of the tile load below
   const int total2 = N2 * C;
   for (int base = 0; base < total2; base += SM_THREADS * SM_U) {
+    // Clamped index for the load AND for the LDS store (a lane past the end rewrites the last element with its own value):
+    // behind an `if (i < total2)` the compiler sinks each load into its store's branch -- eight serial round trips.
     cd raw[SM_U];
 #pragma unroll
     for (int u = 0; u < SM_U; ++u) {
       int i = base + tid + SM_THREADS * u;
-      i = i < total2 ? i : total2 - 1;                      // clamp: unconditional loads, conditional stores
+      i = i < total2 ? i : total2 - 1;
       raw[u] = w[(long long)bx * total2 + i];               // this tile: n2 * C + c, contiguous
     }
 #pragma unroll
     for (int u = 0; u < SM_U; ++u) {
-      const int i = base + tid + SM_THREADS * u;
-      if (i < total2) a[(i % C) * LD + i / C] = raw[u];
+      int i = base + tid + SM_THREADS * u;
+      i = i < total2 ? i : total2 - 1;
+      const int row = (int)fdiv((unsigned)i, P.dc2);
+      a[(i - row * C) * LD + row] = raw[u];
     }
   }
+  twiddle_lds_put(twl, twv, tid);
   __syncthreads();
   SM_STAMP(s1);
   const cd* r = a;
@@ -489,23 +586,21 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_rows_kernel(SmoothPlan P, S
   else r = lds_fft_stockham(a, b, N2, P.r2, P.nr2, twl, tid, C);
   SM_STAMP(s2);
   const long long n = P.n;
-  const bool paired = (OUT == SM_OUT_SPEC) && J.x2off != nullptr && J.x2off[e] >= 0;
   for (int i = tid; i < N2 * C; i += SM_THREADS) {
-    const int c = i % C, k2 = i / C;
+    const int k2 = (int)fdiv((unsigned)i, P.dc2), c = i - k2 * C;
     const long long k = (long long)(k1_0 + c) + (long long)N1 * k2;        // natural output index
-    cd v = r[c * LD + (P.inplace ? dif_slot(k2, N2, P.r2, P.nr2) : k2)];
+    cd v = r[c * LD + (P.inplace ? dif_slot(k2, P.dr2, P.span2, P.nr2) : k2)];
     if (OUT == SM_OUT_SPEC) {
       if (paired) {
-        J.zpair[J.zpair_off[e] + k] = v;
+        J.zpair[out1 + k] = v;
       } else if (k <= n / 2) {
         if (k == 0 || 2 * k == n) v.im = 0.0;
-        J.spec_out[J.spec_off[e] + k] = v;
+        J.spec_out[out1 + k] = v;
       }
     } else {
       const double sc = 1.0 / (double)n;
-      J.y[J.y1_off[e] + k] = (float)(v.re * sc);
-      const long long o2 = J.y2_off[e];
-      if (o2 >= 0) J.y[o2 + k] = (float)(-v.im * sc);
+      J.y[out1 + k] = (float)(v.re * sc);
+      if (out2 >= 0) J.y[out2 + k] = (float)(-v.im * sc);
     }
   }
   if (P.stamp) {
@@ -523,9 +618,10 @@ __global__ __launch_bounds__(256) void smooth_pair_split_kernel(SmoothPlan P, SJ
   const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (k > L / 2) return;
   const cd* z = J.zpair + J.zpair_off[e];
+  const long long o1 = J.spec_off[e], o2 = J.spec_off2[e];      // before the stores (see SCtx)
   const cd zk = z[k], zl = z[k == 0 ? 0 : L - k];
-  J.spec_out[J.spec_off[e] + k] = {0.5 * (zk.re + zl.re), 0.5 * (zk.im - zl.im)};
-  J.spec_out[J.spec_off2[e] + k] = {0.5 * (zk.im + zl.im), 0.5 * (zl.re - zk.re)};
+  J.spec_out[o1 + k] = {0.5 * (zk.re + zl.re), 0.5 * (zk.im - zl.im)};
+  J.spec_out[o2 + k] = {0.5 * (zk.im + zl.im), 0.5 * (zl.re - zk.re)};
 }
 
 // ---- planning ------------------------------------------------------------------------------------------------------------
@@ -641,6 +737,10 @@ int32_t make_smooth_plan(int32_t n, const void* t1, const void* t2, const void* 
   { const int v = ira_tune_int("IRA_SMOOTH_C2", 0); if (v >= 1 && n1 % v == 0) P->c2 = v; }
   P->ld1 = P->inplace ? column_stride(n1, P->c1) : n1;
   P->ld2 = P->inplace ? column_stride(n2, P->c2) : n2;
+  P->dc1 = fast_div_of((unsigned)P->c1); P->dc2 = fast_div_of((unsigned)P->c2);
+  P->dn1 = fast_div_of((unsigned)n1); P->dn2 = fast_div_of((unsigned)n2);
+  for (int i = 0, span = n1; i < P->nr1; ++i) { span /= P->r1[i]; P->dr1[i] = fast_div_of((unsigned)P->r1[i]); P->span1[i] = span; }
+  for (int i = 0, span = n2; i < P->nr2; ++i) { span /= P->r2[i]; P->dr2[i] = fast_div_of((unsigned)P->r2[i]); P->span2[i] = span; }
   P->t1 = static_cast<const cd*>(t1); P->t2 = static_cast<const cd*>(t2); P->tf = static_cast<const cd*>(tf);
   P->stamp = ira_tune_flag("IRA_SMOOTH_STAMP");
   return IRA_OK;

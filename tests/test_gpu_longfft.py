@@ -238,9 +238,11 @@ def test_fr_and_filter_vs_golden(golden, tag, inp):
     assert filterplot.summarise_filter_response_results_text([r]) == cs["summary"]
 
 
-def test_fr_smoothing_and_radians(golden):
+def test_fr_smoothing_and_radians(golden, monkeypatch):
     from audio_analysis_amd.analyse import filterplot, frequency_response as fr
     g, c, _ = golden
+    # the smoothing must be the device kernel (ira_log_smooth_db), not the host restatement kept for curves too long for it
+    monkeypatch.setattr(fr, "smooth_log_frequency", lambda *a, **k: pytest.fail("host smoothing ran"))
     r = fr.analyse_frequency_response_for_channel(g["in/xa"], SR, "m",
                                                   fr.FrequencyResponseAnalysisSettings(smoothing_log_bins=9))
     np.testing.assert_allclose(r.magnitude_db, g["xa_smooth/fr/mag_db"], rtol=0, atol=2e-5)
