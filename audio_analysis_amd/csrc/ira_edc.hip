@@ -616,7 +616,22 @@ __global__ void curve_fit_kernel(const float* __restrict__ ybase, const int64_t*
 //            range accumulated in float64 (one sweep instead of the three passes of curve_fit_kernel).
 // Nothing reads an EDC array: a band EDC that only feeds its fits (rt60bands.py:272-321) is never written, and
 // the decay block's curve is written by the emit pass for the caller but not read back here.
+//
+// Three launches.  Phase A is serial per segment (a handful of tiles); phase B is not: a low band's fit range spans
+// the whole file (118 tiles of a 10 s IR), and as ONE workgroup per segment it was a 1 ms tail at 5 % VALU utilisation
+// (profiles/r02: 192 workgroups on 256 CUs).  So:
+//   edc_fit_kernel      (segments)            phase A; crossings out; range records + chunking into the segment's scratch
+//   edc_moments_kernel  (chunks x segments)   phase B for one chunk of K consecutive tiles: partial moments -> scratch
+//   edc_line_kernel     (segments x ranges)   partial moments summed in chunk order (deterministic), line fit, records out
+// The records live in the first half of the segment's scratch (the tile totals, dead once edc_carry has run).
 // ------------------------------------------------------------------------------------------------
+constexpr int FITREC_HDR = 8;                                   // j_first, j_last, K (tiles per chunk), nchunks
+constexpr int FITREC_RANGE = 8;                                 // ts, te, tmid, ymid, a0, a1, ok, -
+constexpr int FITREC_PART = FITREC_HDR + FITREC_RANGE * 4;      // partial moments: [chunk][range][6]
+constexpr int FIT_MAX_CHUNKS = 80;
+constexpr int FIT_MIN_CHUNK_TILES = 4;                          // 16 k samples per chunk at least
+static_assert(FITREC_PART + FIT_MAX_CHUNKS * 4 * 6 <= IRA_EDC_SCRATCH_DOUBLES / 2, "fit records fit the dead half of the scratch");
+
 struct EdcFitRange {
   double ts, te, tmid, ymid;
   long long a0, a1;
@@ -636,6 +651,14 @@ struct EdcFitShared {
   float y_at[FIT_MAX_TARGETS], y_prev[FIT_MAX_TARGETS];
   float tgt32[FIT_MAX_TARGETS];
   int first_tile[FIT_MAX_TARGETS];                // tile (counted from the END) where the search starts; -1 = never
+};
+
+struct EdcMomentsShared {
+  EdcShared scan;
+  ira::LogTabEntry ltab[ira::LOGTAB_N];
+  float db[EDC_TILE];
+  EdcFitRange rng[FIT_MAX_RANGES];
+  double part[EDC_WAVES][FIT_MAX_RANGES][6];
 };
 
 // Samples of tile j (counted from the end of the segment) into registers: issued one tile AHEAD of its use (phase B walks
@@ -680,7 +703,7 @@ __device__ __forceinline__ double crossing_time_from_values(long long idx, long 
 
 __global__ __launch_bounds__(EDC_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void edc_fit_kernel(
     const float* __restrict__ x, const int64_t* __restrict__ off, const int64_t* __restrict__ len, double eps,
-    double floor_db, FitParams P, const double* __restrict__ scratch, double* __restrict__ fit_out,
+    double floor_db, FitParams P, double* __restrict__ scratch, double* __restrict__ fit_out,
     double* __restrict__ cross_out) {
   extern __shared__ __align__(16) unsigned char ef_smem[];
   EdcFitShared& sh = *reinterpret_cast<EdcFitShared*>(ef_smem);
@@ -697,12 +720,13 @@ __global__ __launch_bounds__(EDC_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
       for (int r = 0; r < P.nranges; ++r)
         for (int k = 0; k < IRA_FIT_DOUBLES; ++k) fo[r * IRA_FIT_DOUBLES + k] = (k == 0) ? 0.0 : qnan;
       for (int j = 0; j < P.ncross && co; ++j) co[j] = qnan;
+      scratch[(int64_t)seg * IRA_EDC_SCRATCH_DOUBLES + 3] = -1.0;      // nchunks < 0: records already written
     }
     return;
   }
   ira::build_log_table(sh.ltab, tid);
   const float* src = x + off[seg];
-  const double* sc = scratch + (int64_t)seg * IRA_EDC_SCRATCH_DOUBLES;
+  double* sc = scratch + (int64_t)seg * IRA_EDC_SCRATCH_DOUBLES;
   const int ntiles = (int)((n + EDC_TILE - 1) / EDC_TILE);
   for (int j = tid; j < ntiles; j += EDC_THREADS) sh.carry[j] = sc[IRA_EDC_SCRATCH_DOUBLES / 2 + j];
   const double norm = sc[IRA_EDC_SCRATCH_DOUBLES - 1];
@@ -803,8 +827,7 @@ __global__ __launch_bounds__(EDC_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
   }
   if (P.nranges == 0) return;
 
-  // ---- phase B: one sweep over the tiles between the crossings, shifted moments per range ---------------------------
-  // Range parameters live in LDS and the running sums in per-wave LDS slots (registers are spent on the 16-sample scan).
+  // ---- the ranges: crossing times, index window, mid-range shifts; and the chunking of phase B --------------------------
   if (tid < FIT_MAX_RANGES) {
     EdcFitRange g;
     g.ok = 0; g.ts = g.te = qnan; g.tmid = g.ymid = 0.0; g.ts32 = g.te32 = 0.0f; g.a0 = 0; g.a1 = -1; g.pad = 0;
@@ -815,7 +838,6 @@ __global__ __launch_bounds__(EDC_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
       g.te = crossing_time_from_values(i_lo, n, sh.y_prev[2 * r + 1], sh.y_at[2 * r + 1], P.lo[r], ta);
       g.ok = !(isnan(g.ts) || isnan(g.te) || g.te <= g.ts) ? 1 : 0;
       if (g.ok) {
-        g.ts32 = (float)g.ts; g.te32 = (float)g.te;
         g.a0 = i_hi - 2 > 0 ? i_hi - 2 : 0;
         g.a1 = i_lo + 2 < n - 1 ? i_lo + 2 : n - 1;
         g.tmid = 0.5 * (g.ts + g.te);
@@ -823,85 +845,166 @@ __global__ __launch_bounds__(EDC_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
       }
     }
     sh.rng[tid] = g;
+    double* rec = sc + FITREC_HDR + FITREC_RANGE * tid;
+    rec[0] = g.ts; rec[1] = g.te; rec[2] = g.tmid; rec[3] = g.ymid;
+    rec[4] = (double)g.a0; rec[5] = (double)g.a1; rec[6] = (double)g.ok; rec[7] = 0.0;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    long long lo_all = n, hi_all = -1;
+    for (int r = 0; r < P.nranges; ++r) {
+      if (!sh.rng[r].ok) continue;
+      lo_all = sh.rng[r].a0 < lo_all ? sh.rng[r].a0 : lo_all;
+      hi_all = sh.rng[r].a1 > hi_all ? sh.rng[r].a1 : hi_all;
+    }
+    int j_first = 0, j_last = 0, K = FIT_MIN_CHUNK_TILES, nchunks = 0;
+    if (hi_all >= lo_all) {
+      j_first = (int)((n - 1 - lo_all) / EDC_TILE);              // earliest tile in time (largest number)
+      j_last = (int)((n - 1 - hi_all) / EDC_TILE);
+      const int T = j_first - j_last + 1;
+      const int kk = (T + FIT_MAX_CHUNKS - 1) / FIT_MAX_CHUNKS;
+      K = kk > FIT_MIN_CHUNK_TILES ? kk : FIT_MIN_CHUNK_TILES;
+      nchunks = (T + K - 1) / K;
+    }
+    sc[0] = (double)j_first; sc[1] = (double)j_last; sc[2] = (double)K; sc[3] = (double)nchunks;
+  }
+}
+
+// Phase B for chunk blockIdx.x of segment blockIdx.y: tiles j_first - c K ... down to j_last, at most K of them.
+__global__ __launch_bounds__(EDC_THREADS) void edc_moments_kernel(
+    const float* __restrict__ x, const int64_t* __restrict__ off, const int64_t* __restrict__ len, double eps,
+    double floor_db, FitParams P, double* __restrict__ scratch) {
+  __shared__ EdcMomentsShared sh;
+  const int seg = blockIdx.y, c = blockIdx.x;
+  double* sc = scratch + (int64_t)seg * IRA_EDC_SCRATCH_DOUBLES;
+  // the segment's header and range records: all loads first, then the moves to scalar registers (one round trip)
+  const double h0 = sc[0], h1 = sc[1], h2 = sc[2], h3 = sc[3];
+  const long long n = len[seg];
+  const long long so = off[seg];
+  const double nrm = sc[IRA_EDC_SCRATCH_DOUBLES - 1];
+  const int nchunks = (int)ira::uniform(h3);
+  if (c >= nchunks) return;
+  const int j_first = (int)ira::uniform(h0), j_last = (int)ira::uniform(h1), K = (int)ira::uniform(h2);
+  const int tid = threadIdx.x;
+  const TimeAxis ta{nullptr, P.t_mul, P.t_div};
+  ira::build_log_table(sh.ltab, tid);
+  if (tid < FIT_MAX_RANGES) {
+    const double* rec = sc + FITREC_HDR + FITREC_RANGE * tid;
+    EdcFitRange g;
+    g.ts = rec[0]; g.te = rec[1]; g.tmid = rec[2]; g.ymid = rec[3];
+    g.a0 = (long long)rec[4]; g.a1 = (long long)rec[5]; g.ok = tid < P.nranges ? (int)rec[6] : 0; g.pad = 0;
+    g.ts32 = (float)g.ts; g.te32 = (float)g.te;
+    sh.rng[tid] = g;
   }
   for (int i = tid; i < EDC_WAVES * FIT_MAX_RANGES * 6; i += EDC_THREADS) (&sh.part[0][0][0])[i] = 0.0;
+  const float* src = x + ira::uniform(so);
+  const long long nn = ira::uniform(n);
+  const double norm = ira::uniform(nrm);
+  const bool fast = norm > 1e-300 && norm < 1e300;
   __syncthreads();
-  long long lo_all = n, hi_all = -1;
-  for (int r = 0; r < P.nranges; ++r) {
-    if (!sh.rng[r].ok) continue;
-    lo_all = sh.rng[r].a0 < lo_all ? sh.rng[r].a0 : lo_all;
-    hi_all = sh.rng[r].a1 > hi_all ? sh.rng[r].a1 : hi_all;
-  }
-  if (hi_all >= lo_all) {
-    const int j_first = (int)((n - 1 - lo_all) / EDC_TILE);      // earliest tile in time (largest number)
-    const int j_last = (int)((n - 1 - hi_all) / EDC_TILE);
-    const int lane = tid & 63, wave = tid >> 6;
-    float xv[EDC_PER_THREAD];
-    edc_tile_fetch(src, n, j_first, xv);
-    for (int j = j_first; j >= j_last; --j) {
-      long long tstart; int tlen;
-      float xn[EDC_PER_THREAD];
-      if (j > j_last) edc_tile_fetch(src, n, j - 1, xn);     // next tile's samples: in flight during this tile's work
-      edc_tile_to_lds(xv, n, j, eps, floor_db, norm, lnorm, fast, parity, sh, tstart, tlen);
-      parity ^= 1;
-      for (int r = 0; r < P.nranges; ++r) {
-        const EdcFitRange g = sh.rng[r];                     // uniform
-        if (!g.ok || g.a1 < tstart || g.a0 >= tstart + tlen) continue;
-        double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0, m4 = 0.0, m5 = 0.0;
-        for (int i = tid; i < tlen; i += EDC_THREADS) {
-          const long long gi = tstart + i;
-          const float tf = ta.at(gi);
-          if (gi >= g.a0 && gi <= g.a1 && tf >= g.ts32 && tf <= g.te32) {
-            const double u = (double)tf - g.tmid, w = (double)sh.db[i] - g.ymid;
-            m0 += 1.0; m1 += u; m2 += w; m3 += u * u; m4 += u * w; m5 += w * w;
-          }
-        }
-        m0 = ira::wave_sum(m0); m1 = ira::wave_sum(m1); m2 = ira::wave_sum(m2);
-        m3 = ira::wave_sum(m3); m4 = ira::wave_sum(m4); m5 = ira::wave_sum(m5);
-        if (lane == 0) {
-          double* pp = sh.part[wave][r];
-          pp[0] += m0; pp[1] += m1; pp[2] += m2; pp[3] += m3; pp[4] += m4; pp[5] += m5;
-        }
-      }
-      __syncthreads();                                       // sh.db is rewritten by the next tile
-      if (j > j_last) {
+  const double lnorm = fast ? ira::log2_table(norm, sh.ltab) : 0.0;
+  const int j_hi = j_first - c * K;
+  const int j_lo = j_hi - K + 1 > j_last ? j_hi - K + 1 : j_last;
+  const int lane = tid & 63, wave = tid >> 6;
+  int parity = 0;
+  float xv[EDC_PER_THREAD];
+  edc_tile_fetch(src, nn, j_hi, xv);
+  double carry = sc[IRA_EDC_SCRATCH_DOUBLES / 2 + j_hi];
+  for (int j = j_hi; j >= j_lo; --j) {
+    float xn[EDC_PER_THREAD];
+    double carry_next = 0.0;
+    if (j > j_lo) {                                            // next tile's samples and carry: in flight during this tile's work
+      edc_tile_fetch(src, nn, j - 1, xn);
+      carry_next = sc[IRA_EDC_SCRATCH_DOUBLES / 2 + j - 1];
+    }
+    const long long hi = nn - (long long)j * EDC_TILE;
+    const long long tstart = hi - EDC_TILE > 0 ? hi - EDC_TILE : 0;
+    const int tlen = (int)(hi - tstart);
+    {
+      double sfx[EDC_PER_THREAD];
+      tile_suffix_scan(xv, sh.scan, parity, sfx);
+      const int i0 = EDC_PER_THREAD * tid;
 #pragma unroll
-        for (int r = 0; r < EDC_PER_THREAD; ++r) xv[r] = xn[r];
+      for (int r = 0; r < EDC_PER_THREAD; ++r)
+        if (i0 + r < tlen) sh.db[i0 + r] = (float)np_max(edc_db64(sfx[r] + carry, eps, norm, lnorm, fast, sh.ltab), floor_db);
+    }
+    __syncthreads();
+    parity ^= 1;
+    for (int r = 0; r < P.nranges; ++r) {
+      const EdcFitRange g = sh.rng[r];                       // uniform
+      if (!g.ok || g.a1 < tstart || g.a0 >= tstart + tlen) continue;
+      double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0, m4 = 0.0, m5 = 0.0;
+      for (int i = tid; i < tlen; i += EDC_THREADS) {
+        const long long gi = tstart + i;
+        const float tf = ta.at(gi);
+        if (gi >= g.a0 && gi <= g.a1 && tf >= g.ts32 && tf <= g.te32) {
+          const double u = (double)tf - g.tmid, w = (double)sh.db[i] - g.ymid;
+          m0 += 1.0; m1 += u; m2 += w; m3 += u * u; m4 += u * w; m5 += w * w;
+        }
+      }
+      m0 = ira::wave_sum(m0); m1 = ira::wave_sum(m1); m2 = ira::wave_sum(m2);
+      m3 = ira::wave_sum(m3); m4 = ira::wave_sum(m4); m5 = ira::wave_sum(m5);
+      if (lane == 0) {
+        double* pp = sh.part[wave][r];
+        pp[0] += m0; pp[1] += m1; pp[2] += m2; pp[3] += m3; pp[4] += m4; pp[5] += m5;
       }
     }
-  }
-  if (tid < P.nranges) {
-    const int r = tid;
-    const EdcFitRange g = sh.rng[r];
-    double* o = fo + r * IRA_FIT_DOUBLES;
-    if (!g.ok) {
-      o[0] = 0.0; o[1] = g.ts; o[2] = g.te; for (int k = 3; k < IRA_FIT_DOUBLES; ++k) o[k] = qnan;
-    } else {
-      double cnt = 0.0, su = 0.0, sw = 0.0, suu = 0.0, suw = 0.0, sww = 0.0;
-      for (int w = 0; w < EDC_WAVES; ++w) {
-        const double* pp = sh.part[w][r];
-        cnt += pp[0]; su += pp[1]; sw += pp[2]; suu += pp[3]; suw += pp[4]; sww += pp[5];
-      }
-      const long long npts = (long long)cnt;
-      if (npts < P.min_points) {
-        o[0] = 0.0; o[1] = g.ts; o[2] = g.te; for (int k = 3; k < 7; ++k) o[k] = qnan; o[7] = (double)npts;
-      } else {
-        // centred moments from the shifted sums (shift = mid-range: the subtractions lose nothing that matters in f64)
-        const double um = su / cnt, wm = sw / cnt;
-        const double stt = suu - su * um, sty = suw - su * wm, syy = sww - sw * wm;
-        const double slope = sty / stt;
-        const double tm = g.tmid + um, ym = g.ymid + wm;
-        const double icpt = ym - slope * tm;
-        const double sres = syy - slope * sty;               // residual sum of squares of the least-squares line
-        const bool neg = slope < 0.0;                        // also false for NaN (stt == 0)
-        o[0] = neg ? 1.0 : 0.0;
-        o[1] = g.ts; o[2] = g.te; o[3] = slope; o[4] = icpt;
-        o[5] = syy > 0.0 ? 1.0 - fmax(sres, 0.0) / syy : 0.0;
-        o[6] = -60.0 / slope;
-        o[7] = (double)npts;
-      }
+    __syncthreads();                                         // sh.db is rewritten by the next tile
+    if (j > j_lo) {
+#pragma unroll
+      for (int r = 0; r < EDC_PER_THREAD; ++r) xv[r] = xn[r];
+      carry = carry_next;
     }
   }
+  if (tid < FIT_MAX_RANGES * 6) {
+    const int r = tid / 6, k = tid - 6 * r;
+    double v = 0.0;
+    for (int w = 0; w < EDC_WAVES; ++w) v += sh.part[w][r][k];
+    sc[FITREC_PART + (c * FIT_MAX_RANGES + r) * 6 + k] = v;
+  }
+}
+
+// One thread per (segment, range): the chunks' partial moments in chunk order, then the least-squares line.
+__global__ __launch_bounds__(256) void edc_line_kernel(int nseg, FitParams P, const double* __restrict__ scratch,
+                                                       double* __restrict__ fit_out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nseg * P.nranges) return;
+  const int seg = t / P.nranges, r = t - seg * P.nranges;
+  const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+  const double* sc = scratch + (int64_t)seg * IRA_EDC_SCRATCH_DOUBLES;
+  const int nchunks = (int)sc[3];
+  if (nchunks < 0) return;                                   // empty segment: written by edc_fit_kernel
+  const double* rec = sc + FITREC_HDR + FITREC_RANGE * r;
+  const double ts = rec[0], te = rec[1], tmid = rec[2], ymid = rec[3];
+  const bool ok = rec[6] != 0.0;
+  double* o = fit_out + ((int64_t)seg * P.nranges + r) * IRA_FIT_DOUBLES;
+  if (!ok) {
+    o[0] = 0.0; o[1] = ts; o[2] = te; for (int k = 3; k < IRA_FIT_DOUBLES; ++k) o[k] = qnan;
+    return;
+  }
+  double cnt = 0.0, su = 0.0, sw = 0.0, suu = 0.0, suw = 0.0, sww = 0.0;
+  for (int c = 0; c < nchunks; ++c) {
+    const double* pp = sc + FITREC_PART + (c * FIT_MAX_RANGES + r) * 6;
+    cnt += pp[0]; su += pp[1]; sw += pp[2]; suu += pp[3]; suw += pp[4]; sww += pp[5];
+  }
+  const long long npts = (long long)cnt;
+  if (npts < P.min_points) {
+    o[0] = 0.0; o[1] = ts; o[2] = te; for (int k = 3; k < 7; ++k) o[k] = qnan; o[7] = (double)npts;
+    return;
+  }
+  // centred moments from the shifted sums (shift = mid-range: the subtractions lose nothing that matters in f64)
+  const double um = su / cnt, wm = sw / cnt;
+  const double stt = suu - su * um, sty = suw - su * wm, syy = sww - sw * wm;
+  const double slope = sty / stt;
+  const double tm = tmid + um, ym = ymid + wm;
+  const double icpt = ym - slope * tm;
+  const double sres = syy - slope * sty;                     // residual sum of squares of the least-squares line
+  const bool neg = slope < 0.0;                              // also false for NaN (stt == 0)
+  o[0] = neg ? 1.0 : 0.0;
+  o[1] = ts; o[2] = te; o[3] = slope; o[4] = icpt;
+  o[5] = syy > 0.0 ? 1.0 - fmax(sres, 0.0) / syy : 0.0;
+  o[6] = -60.0 / slope;
+  o[7] = (double)npts;
 }
 
 }  // namespace
@@ -974,6 +1077,13 @@ extern "C" int32_t ira_edc_fits(const float* x_dev, const int64_t* off_dev, cons
     edc_fit_kernel<<<nseg, EDC_THREADS, sizeof(EdcFitShared), st>>>(x_dev, off_dev, len_dev, eps, floor_db, P,
                                                                      scratch_dev, fit_out_dev,
                                                                      ncross > 0 ? cross_out_dev : nullptr);
+  if (nranges > 0) {
+    int max_chunks = (ntiles + FIT_MIN_CHUNK_TILES - 1) / FIT_MIN_CHUNK_TILES;
+    if (max_chunks > FIT_MAX_CHUNKS) max_chunks = FIT_MAX_CHUNKS;
+    edc_moments_kernel<<<dim3(max_chunks, nseg), EDC_THREADS, 0, st>>>(x_dev, off_dev, len_dev, eps, floor_db, P,
+                                                                       scratch_dev);
+    edc_line_kernel<<<(nseg * nranges + 255) / 256, 256, 0, st>>>(nseg, P, scratch_dev, fit_out_dev);
+  }
   if (edc_db_dev != nullptr)
     edc_emit_kernel<<<dim3(ntiles, nseg), EDC_THREADS, 0, st>>>(x_dev, off_dev, len_dev, eps, floor_db, edc_db_dev,
                                                                 nullptr, edc_off_dev, scratch_dev);

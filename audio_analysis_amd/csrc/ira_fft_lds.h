@@ -19,17 +19,42 @@ __device__ __forceinline__ unsigned lds_brev(unsigned k, int log2m) {
   return log2m == 0 ? 0u : (__brev(k) >> (32 - log2m));
 }
 
-template <typename T>
+// Twiddle source of the passes.  SPLIT = false: `tw` is the table itself (global memory: one DEPENDENT load per butterfly
+// and pass -- a memory round trip on the critical path of every pass).  SPLIT = true: `tw` points at a two-level copy in
+// LDS, built once per workgroup (tw_split_fetch / tw_split_put): TW_COARSE entries W^(32 i) followed by 32 entries W^j;
+// W^t = coarse[t >> 5] * fine[t & 31], two LDS reads and one complex multiply.  Covers half <= 32 * TW_COARSE = 4096.
+constexpr int TW_COARSE = 128;
+constexpr int TW_SPLIT_ENTRIES = TW_COARSE + 32;
+
+template <typename T, bool SPLIT>
+__device__ __forceinline__ cplx<T> tw_get(const cplx<T>* __restrict__ tw, unsigned idx) {
+  if constexpr (SPLIT) return cmul(tw[idx >> 5], tw[TW_COARSE + (idx & 31u)]);
+  else return tw[idx];
+}
+
+template <typename T, bool SPLIT = false>
 __device__ __forceinline__ cplx<T> tw_lookup(const cplx<T>* __restrict__ tw, unsigned idx, unsigned half) {
   // idx in [0, 2*half)
   if (idx >= half) {
-    const cplx<T> w = tw[idx - half];
+    const cplx<T> w = tw_get<T, SPLIT>(tw, idx - half);
     return {-w.re, -w.im};
   }
-  return tw[idx];
+  return tw_get<T, SPLIT>(tw, idx);
 }
 
-template <typename T, int LR = 4>
+// The split table in two halves, so that its global load can be issued BEFORE a tile's loads and its LDS write after them
+// (one round trip for both).  `half` = entries of the source table that the passes use (M * tw_per_m / 2).
+template <typename T>
+__device__ __forceinline__ cplx<T> tw_split_fetch(const cplx<T>* __restrict__ tw, unsigned half, int tid) {
+  const unsigned idx = tid < TW_COARSE ? 32u * (unsigned)tid : (unsigned)(tid - TW_COARSE);
+  return (tid < TW_SPLIT_ENTRIES && idx < half) ? tw[idx] : cplx<T>{(T)1, (T)0};
+}
+template <typename T>
+__device__ __forceinline__ void tw_split_put(cplx<T>* tab, cplx<T> v, int tid) {
+  if (tid < TW_SPLIT_ENTRIES) tab[tid] = v;
+}
+
+template <typename T, int LR = 4, bool SPLIT = false>
 __device__ __forceinline__ void lds_fft_dif(cplx<T>* buf, int log2m, const cplx<T>* __restrict__ tw,
                                             unsigned tw_per_m, int tid, int nt, int nbat = 1,
                                             unsigned bstride = 0) {
@@ -52,7 +77,7 @@ __device__ __forceinline__ void lds_fft_dif(cplx<T>* buf, int log2m, const cplx<
 #pragma unroll
       for (int r = 0; r < R; ++r) v[r] = p[base + r * q];
       dft_dif<T, R>(v);
-      if (j != 0) twiddle_r<T, LR, true>(v, tw[j * step]);     // W_S^(j k), k < R  (j*step < half/(R/2))
+      if (j != 0) twiddle_r<T, LR, true>(v, tw_get<T, SPLIT>(tw, j * step));     // W_S^(j k), k < R  (j*step < half/(R/2))
 #pragma unroll
       for (int i = 0; i < R; ++i) p[base + i * q] = v[i];
     }
@@ -76,9 +101,9 @@ __device__ __forceinline__ void lds_fft_dif(cplx<T>* buf, int log2m, const cplx<
       cplx<T> c2 = cadd(m02, m13);
       cplx<T> c3 = csub(m02, m13);
       if (j != 0) {
-        const cplx<T> w1 = tw[j * step];                       // W_S^j      (j*step < half/2)
-        const cplx<T> w2 = tw[2 * j * step];                   // W_S^(2j)   (< half)
-        const cplx<T> w3 = tw_lookup(tw, 3 * j * step, half);  // W_S^(3j)   (< 3/2 half)
+        const cplx<T> w1 = tw_get<T, SPLIT>(tw, j * step);                  // W_S^j      (j*step < half/2)
+        const cplx<T> w2 = tw_get<T, SPLIT>(tw, 2 * j * step);              // W_S^(2j)   (< half)
+        const cplx<T> w3 = tw_lookup<T, SPLIT>(tw, 3 * j * step, half);     // W_S^(3j)   (< 3/2 half)
         c1 = cmul(c1, w2);
         c2 = cmul(c2, w1);
         c3 = cmul(c3, w3);
@@ -103,7 +128,7 @@ __device__ __forceinline__ void lds_fft_dif(cplx<T>* buf, int log2m, const cplx<
 
 // Bit-reversed input -> natural output.  conj_tw = true uses exp(+i...) twiddles (inverse transform,
 // unnormalised); false gives the forward transform of a bit-reversed-order input.
-template <typename T, int LR = 4>
+template <typename T, int LR = 4, bool SPLIT = false>
 __device__ __forceinline__ void lds_fft_dit(cplx<T>* buf, int log2m, const cplx<T>* __restrict__ tw,
                                             unsigned tw_per_m, bool conj_tw, int tid, int nt, int nbat = 1,
                                             unsigned bstride = 0) {
@@ -138,9 +163,9 @@ __device__ __forceinline__ void lds_fft_dit(cplx<T>* buf, int log2m, const cplx<
       const cplx<T> a0 = p[base];
       cplx<T> t1 = p[base + q], t2 = p[base + 2 * q], t3 = p[base + 3 * q];
       if (j != 0) {
-        cplx<T> w1 = tw[j * step];
-        cplx<T> w2 = tw[2 * j * step];
-        cplx<T> w3 = tw_lookup(tw, 3 * j * step, half);
+        cplx<T> w1 = tw_get<T, SPLIT>(tw, j * step);
+        cplx<T> w2 = tw_get<T, SPLIT>(tw, 2 * j * step);
+        cplx<T> w3 = tw_lookup<T, SPLIT>(tw, 3 * j * step, half);
         if (conj_tw) { w1.im = -w1.im; w2.im = -w2.im; w3.im = -w3.im; }
         t1 = cmul(t1, w2);
         t2 = cmul(t2, w1);
@@ -173,7 +198,7 @@ __device__ __forceinline__ void lds_fft_dit(cplx<T>* buf, int log2m, const cplx<
 #pragma unroll
       for (int k = 0; k < R; ++k) u[k] = p[base + brev_bits(k, LR) * q];
       if (j != 0) {
-        cplx<T> w = tw[j * step];
+        cplx<T> w = tw_get<T, SPLIT>(tw, j * step);
         if (conj_tw) w.im = -w.im;
         twiddle_r<T, LR, false>(u, w);
       }

@@ -266,6 +266,8 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   const unsigned lc = 31u - (unsigned)__builtin_clz((unsigned)C), cm = (unsigned)C - 1u;   // C is a power of two (make_plan)
   const unsigned stride = N1 + 1;
   const int tid = threadIdx.x;
+  cd* twl = lds + (size_t)C * stride;                                  // two-level twiddle table of the sub-FFT (ira_fft_lds.h)
+  const cd twv = ira::tw_split_fetch<double>(g.t1, N1 >> 1, tid);      // load issued first, LDS write after the tile's loads
   // A thread's elements are n_k = n_0 + k*dn (same column, rows FL_THREADS/C apart).  The chirp exp(-i pi n^2/L) along
   // them obeys  w_{k+1} = w_k d_k,  d_{k+1} = d_k e2  with  d_k = exp(-i pi (2 n_k dn + dn^2)/L),  e2 = exp(-i pi 2 dn^2/L):
   // three exactly reduced sincospi per thread instead of one per element; the Hann window is a plain rotation.
@@ -330,8 +332,9 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       }
     }
   }
+  ira::tw_split_put(twl, twv, tid);
   __syncthreads();
-  if (!(g.ablate & 2)) ira::lds_fft_dif<double, FL_LR>(lds, g.log2n1, g.t1, 1u, tid, FL_THREADS, C, stride);
+  if (!(g.ablate & 2)) ira::lds_fft_dif<double, FL_LR, true>(lds, g.log2n1, twl, 1u, tid, FL_THREADS, C, stride);
   cd* w = work + (long long)e * M;
   const unsigned total_o = N1 * (unsigned)C;
   for (unsigned base = 0; base < total_o; base += FL_THREADS * FL_UI) {
@@ -373,6 +376,8 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   const int filt = MODE == ROW_CONV ? ira::uniform(J.bidx[e]) : 0;            // before the tile loop (see Ctx)
   cd* w = work + (long long)e * M + (long long)r0 * N2;
   const unsigned total = N2 * (unsigned)R;
+  cd* twl = lds + total;                                               // two-level twiddle table of the sub-FFT
+  const cd twv = ira::tw_split_fetch<double>(g.t2, N2 >> 1, tid);
   for (unsigned base = 0; base < total; base += FL_THREADS * FL_U) {
     // All loads of the batch in flight together.  Index clamped, and the LDS store NOT guarded (a lane past the end stores
     // the last element's own value onto itself): behind an `if (i < total)` the compiler sinks each load into its store's
@@ -389,8 +394,9 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       lds[i < total ? i : total - 1] = raw[u];
     }
   }
+  ira::tw_split_put(twl, twv, tid);
   __syncthreads();
-  if (!(g.ablate & 8)) ira::lds_fft_dif<double, FL_LR>(lds, g.log2n2, g.t2, 1u, tid, FL_THREADS, R, N2);
+  if (!(g.ablate & 8)) ira::lds_fft_dif<double, FL_LR, true>(lds, g.log2n2, twl, 1u, tid, FL_THREADS, R, N2);
   if (MODE == ROW_CONV) {
     const cd* b = J.bfilt + (long long)filt * M + (long long)r0 * N2;
     if (!(g.ablate & 16))
@@ -408,7 +414,7 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         }
       }
     __syncthreads();
-    if (!(g.ablate & 8)) ira::lds_fft_dit<double, FL_LR>(lds, g.log2n2, g.t2, 1u, true, tid, FL_THREADS, R, N2);
+    if (!(g.ablate & 8)) ira::lds_fft_dit<double, FL_LR, true>(lds, g.log2n2, twl, 1u, true, tid, FL_THREADS, R, N2);
     for (unsigned base = 0; base < total; base += FL_THREADS * FL_UI) {
       cd th[FL_UI], tl[FL_UI];
 #pragma unroll
@@ -472,6 +478,8 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   const long long n_need = (MODE == OUT_SPECTRUM && !paired) ? L / 2 + 1 : L;
   const cd* w = work + (long long)e * M;
   const unsigned total = N1 * (unsigned)C;
+  cd* twl = lds + (size_t)C * stride;                                  // two-level twiddle table of the sub-FFT
+  const cd twv = ira::tw_split_fetch<double>(g.t1, N1 >> 1, tid);
   for (unsigned base = 0; base < total; base += FL_THREADS * FL_U) {
     cd raw[FL_U];
 #pragma unroll
@@ -486,8 +494,9 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       if (i < total) lds[(i & cm) * stride + (i >> lc)] = raw[u];
     }
   }
+  ira::tw_split_put(twl, twv, tid);
   __syncthreads();
-  if (!(g.ablate & 32)) ira::lds_fft_dit<double, FL_LR>(lds, g.log2n1, g.t1, 1u, true, tid, FL_THREADS, C, stride);
+  if (!(g.ablate & 32)) ira::lds_fft_dit<double, FL_LR, true>(lds, g.log2n1, twl, 1u, true, tid, FL_THREADS, C, stride);
   const double inv_m = 1.0 / (double)M;
   // The output chirp exp(-i pi n^2 / L) along a thread's elements n_j = n_0 + j dn by the same recurrence as in K1
   // (w_{j+1} = w_j d_j, d_{j+1} = d_j e2: three exactly reduced sincospi per thread instead of a 64-bit modulo and a
@@ -597,8 +606,8 @@ int32_t make_plan(int log2m, const void* t1, const void* t2, const void* tf, Pla
   { const int v = ira_tune_int("IRA_FFT_R", 0); if (v >= 1 && v <= N1) R = v; }
   p->C = C;
   p->R = R;
-  p->lds_cols = (size_t)C * (N1 + 1) * sizeof(cd);
-  p->lds_rows = (size_t)R * N2 * sizeof(cd);
+  p->lds_cols = ((size_t)C * (N1 + 1) + ira::TW_SPLIT_ENTRIES) * sizeof(cd);      // tile + two-level twiddle table
+  p->lds_rows = ((size_t)R * N2 + ira::TW_SPLIT_ENTRIES) * sizeof(cd);
   return IRA_OK;
 }
 
