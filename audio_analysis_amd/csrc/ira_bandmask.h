@@ -79,4 +79,75 @@ __device__ __forceinline__ float mask_at(const BandMask& b, float f) {
   return 0.0f;
 }
 
+// ---- the same masks without the per-bin float32 division ---------------------------------------------------------------
+// Outside its transition bands (almost every bin) a mask is exactly 0 or 1, and WHICH bins those are follows from two
+// float32 comparisons per edge, f(k) <= edge and f(k) >= edge with f(k) = float32(float64(k) * step) -- both monotone in k.
+// So the first bin that passes each comparison is found once per wave (MaskCuts, eight lanes in parallel), and a bin then
+// needs four integer compares; only bins inside a transition go through mask_at (the identical code as before, so the
+// values are bit for bit the same).  The full formula was ~140 of the ~290 VALU instructions per element of the inverse
+// pass-1 kernel, which is VALU-bound.
+struct MaskCuts {
+  int hp_a, hp_b;     // high-pass: k < hp_a -> 0,  k >= hp_b -> 1
+  int lp_a, lp_b;     // low-pass:  k < lp_a -> 1,  k >= lp_b -> 0
+};
+
+__device__ __forceinline__ float bin_freq(int k, double step) { return (float)((double)k * step); }
+
+// min { k in [0, kmax] : f(k) > c (strict) or f(k) >= c }, kmax + 1 if there is none; -1 if the walk from the estimate
+// does not settle (the caller then sends every bin through the full formula)
+__device__ __forceinline__ int first_bin(float c, bool strict, double step, int kmax) {
+  if (!(fabsf(c) < 3.0e38f)) return c < 0.0f ? 0 : kmax + 1;                   // infinite edge (NaN never gets here)
+  const double est = (double)c / step;
+  if (est >= (double)kmax + 2.0) return kmax + 1;
+  int k = est > 3.0 ? (int)est - 3 : 0;
+  for (int it = 0; it < 10; ++it) {
+    if (k > kmax) return kmax + 1;
+    const float f = bin_freq(k, step);
+    if (strict ? f > c : f >= c) return (it == 0 && k > 0) ? -1 : k;            // true at the start: estimate too high
+    ++k;
+  }
+  return -1;
+}
+
+// Wave-cooperative (lanes 0..7, every lane gets the result): the cuts of the two bands of a job.
+__device__ __forceinline__ void band_cuts(const BandMask& b1, const BandMask& b2, double step, int kmax, MaskCuts& c1,
+                                          MaskCuts& c2) {
+  const int lane = threadIdx.x & 63;
+  const int which = lane & 3;
+  const bool second = (lane & 4) != 0;
+  const double hx0 = second ? b2.hp_x0 : b1.hp_x0, hx1 = second ? b2.hp_x1 : b1.hp_x1;
+  const double lx0 = second ? b2.lp_x0 : b1.lp_x0, lx1 = second ? b2.lp_x1 : b1.lp_x1;
+  const double x = which == 0 ? hx0 : which == 1 ? hx1 : which == 2 ? lx0 : lx1;
+  // an edge pair that is not strictly ordered in float32 (or NaN) takes the full formula everywhere
+  const bool degenerate = which < 2 ? !((float)hx0 < (float)hx1) : !((float)lx0 < (float)lx1);
+  int v = degenerate ? -1 : first_bin((float)x, (which & 1) == 0, step, kmax);
+  int cut[8];
+#pragma unroll
+  for (int l = 0; l < 8; ++l) cut[l] = __builtin_amdgcn_readlane(v, l);
+  auto fill = [](MaskCuts& c, const int* q) {
+    const bool hp_ok = q[0] >= 0 && q[1] >= 0, lp_ok = q[2] >= 0 && q[3] >= 0;
+    c.hp_a = hp_ok ? q[0] : 0;  c.hp_b = hp_ok ? q[1] : 0x7fffffff;
+    c.lp_a = lp_ok ? q[2] : 0;  c.lp_b = lp_ok ? q[3] : 0x7fffffff;
+  };
+  fill(c1, cut);
+  fill(c2, cut + 4);
+}
+
+__device__ __forceinline__ float mask_cut(const BandMask& b, const MaskCuts& c, int k, double step) {
+  const int kind = (int)b.kind;                          // uniform
+  if (kind < 1 || kind > 3) return 0.0f;
+  float hp = 1.0f, lp = 1.0f;
+  bool inside = false;
+  if (kind & 2) {
+    if (k < c.hp_a) hp = 0.0f;
+    else if (k < c.hp_b) inside = true;
+  }
+  if (kind & 1) {
+    if (k >= c.lp_b) lp = 0.0f;
+    else if (k >= c.lp_a) inside = true;
+  }
+  if (inside) return mask_at(b, bin_freq(k, step));
+  return hp * lp;
+}
+
 }  // namespace ira

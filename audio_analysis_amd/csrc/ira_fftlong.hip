@@ -49,20 +49,43 @@ __device__ __forceinline__ cd twiddle_m(const Geom& g, unsigned p) {
   return ira::cmul(g.t1[hi], g.tf[lo]);
 }
 
-// exp(-i*pi*n^2/L) with the phase reduced exactly in integers (n < 2^31, L < 2^31).
-__device__ __forceinline__ cd chirp(long long n, long long L) {
-  const long long q = (n * n) % (2 * L);
+// Phase of a chirp value: q / L half-turns reduced to [0, 2), for an exact non-negative integer q < 2^53 held in a double
+// (n^2, 2 n dn + dn^2, 2 dn^2 with n, dn < 2^22).  q mod 2L comes out EXACTLY from one fma -- the quotient estimate is off
+// by at most one, the remainder is an integer below 2^33 -- instead of a 64-bit integer division (85 instructions; the
+// three per-thread chirp start values of K1 / K3 were a third of those kernels' VALU work).
+struct ChirpScale {
+  double l2, inv_l2, inv_l;       // 2L, 1/(2L), 1/L
+};
+__device__ __forceinline__ ChirpScale chirp_scale(long long L) {
+  const double l = (double)L;
+  return {2.0 * l, 0.5 / l, 1.0 / l};
+}
+__device__ __forceinline__ double chirp_angle(double q, const ChirpScale& cs) {
+  const double k = floor(q * cs.inv_l2);
+  double r = fma(-k, cs.l2, q);
+  r = r < 0.0 ? r + cs.l2 : (r >= cs.l2 ? r - cs.l2 : r);
+  return r * cs.inv_l;
+}
+// exp(-i*pi*q/L)
+__device__ __forceinline__ cd unit_q(double q, const ChirpScale& cs) {
   double s, c;
-  sincospi((double)q / (double)L, &s, &c);
+  sincospi(chirp_angle(q, cs), &s, &c);
   return {c, -s};
 }
+// exp(-i*pi*n^2/L), n < 2^26
+__device__ __forceinline__ cd chirp(long long n, const ChirpScale& cs) {
+  const double x = (double)n;
+  return unit_q(x * x, cs);
+}
 
-// exp(-i*pi*q/L) for an integer phase numerator q >= 0 (reduced exactly mod 2L first)
-__device__ __forceinline__ cd unit_q(long long q, long long L) {
-  q %= 2 * L;
-  double s, c;
-  sincospi((double)q / (double)L, &s, &c);
-  return {c, -s};
+// value of lane `lane` of the wave in every lane (scalar registers)
+__device__ __forceinline__ double lane_value(double v, int lane) {
+  int w[2];
+  __builtin_memcpy(w, &v, 8);
+  w[0] = __builtin_amdgcn_readlane(w[0], lane);
+  w[1] = __builtin_amdgcn_readlane(w[1], lane);
+  __builtin_memcpy(&v, w, 8);
+  return v;
 }
 
 // numpy.hanning(L)[i] = 0.5 + 0.5*cos(pi*(2i + 1 - L)/(L - 1)), hanning(1) = 1: evaluated in cols_fwd_kernel as a rotation
@@ -121,6 +144,7 @@ struct Ctx {
   long long nd1, nd2, lw1, lw2;     // IN_SIGNAL: samples actually read / Hann window lengths of the two signals
   bool two;                         // IN_SPECTRUM: the two bands come from two different spectra
   BandMask b1, b2;
+  ira::MaskCuts k1, k2;             // first bins past each mask edge (ira_bandmask.h)
   double fv;
 };
 
@@ -162,6 +186,7 @@ __device__ __forceinline__ Ctx job_ctx(const Jobs& J, int e) {
     c.b1 = uniform_band(b1);
     c.b2 = uniform_band(b2);
     c.fv = ira::uniform(fv);
+    ira::band_cuts(c.b1, c.b2, c.fv, (int)(c.L / 2), c.k1, c.k2);
   } else {
     c.L = ira::uniform(L);
   }
@@ -215,7 +240,7 @@ __device__ __forceinline__ cd value_input(const Jobs& J, const Ctx& c, long long
       m = M - n;
       if (m >= L) return {0.0, 0.0};
     }
-    const cd wm = chirp(m, L);
+    const cd wm = chirp(m, chirp_scale(L));
     return {wm.re, -wm.im};  // conj(w)
   } else {
     if (n >= L) return {0.0, 0.0};
@@ -223,9 +248,8 @@ __device__ __forceinline__ cd value_input(const Jobs& J, const Ctx& c, long long
     const bool upper = n > L / 2;
     const long long k = upper ? L - n : n;
     const cd xk = {r.a, upper ? -r.b : r.b};
-    const float f = (float)((double)k * c.fv);
-    const double m1 = (double)mask_at(c.b1, f);
-    const double m2 = (double)mask_at(c.b2, f);
+    const double m1 = (double)ira::mask_cut(c.b1, c.k1, (int)k, c.fv);
+    const double m2 = (double)ira::mask_cut(c.b2, c.k2, (int)k, c.fv);
     cd wk;
     if (!c.two) {
       wk = ira::cmul(xk, cd{m1, m2});
@@ -270,12 +294,24 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   const cd twv = ira::tw_split_fetch<double>(g.t1, N1 >> 1, tid);      // load issued first, LDS write after the tile's loads
   // A thread's elements are n_k = n_0 + k*dn (same column, rows FL_THREADS/C apart).  The chirp exp(-i pi n^2/L) along
   // them obeys  w_{k+1} = w_k d_k,  d_{k+1} = d_k e2  with  d_k = exp(-i pi (2 n_k dn + dn^2)/L),  e2 = exp(-i pi 2 dn^2/L):
-  // three exactly reduced sincospi per thread instead of one per element; the Hann window is a plain rotation.
+  // exactly reduced start values per thread instead of one sincospi per element; the Hann window is a plain rotation.
   // (<= N1*C/FL_THREADS = 8 steps, so the recurrences add a few 1e-16.)
   {
     const unsigned c = tid & cm, n1_0 = tid >> lc;
     const long long dn = (long long)(FL_THREADS >> lc) * N2;
     const long long n0 = (long long)n1_0 * N2 + n2_0 + c;
+    const unsigned total = N1 * (unsigned)C;
+    const unsigned cnt = total > (unsigned)tid ? (total - (unsigned)tid + FL_THREADS - 1) / FL_THREADS : 0u;   // my elements
+    // The first batch of loads goes out BEFORE the trigonometric set-up below (~400 instructions that need no memory).
+    constexpr int UI = (MODE == IN_SIGNAL) ? 2 * FL_UI : FL_UI;             // a signal fetch is two floats: all eight at once
+    RawL raw[UI];
+    if (cnt > 0) {
+#pragma unroll
+      for (int u = 0; u < UI; ++u) {
+        const unsigned j = (unsigned)u < cnt ? (unsigned)u : cnt - 1;       // clamp: unconditional loads
+        raw[u] = fetch_input<MODE>(J, ctx, n0 + (long long)j * dn);
+      }
+    }
     cd w = {1.0, 0.0}, d = {1.0, 0.0}, e2 = {1.0, 0.0};
     // Hann windows of the (up to) two signals: window length and sample count may differ from the transform length
     long long lw1 = L, lw2 = L;
@@ -283,36 +319,52 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       lw1 = ctx.lw1;
       lw2 = ctx.lw2;
     }
+    const bool second = MODE == IN_SIGNAL && ctx.o2 >= 0;                   // a second signal (and so a second window) exists
     double hc = 1.0, hs = 0.0, rc = 1.0, rs = 0.0, hc2 = 1.0, hs2 = 0.0, rc2 = 1.0, rs2 = 0.0;
     if (MODE != IN_FILTER) {
-      w = unit_q(n0 * n0, L);
-      d = unit_q(2 * n0 * dn + dn * dn, L);
-      e2 = unit_q(2 * dn * dn, L);
-      if (MODE == IN_SIGNAL && J.use_hann) {
+      const ChirpScale cs = chirp_scale(L);
+      const double n0d = (double)n0, dnd = (double)dn;
+      w = unit_q(n0d * n0d, cs);
+      d = unit_q(2.0 * n0d * dnd + dnd * dnd, cs);
+      const bool hann = MODE == IN_SIGNAL && J.use_hann;
+      const double st = (double)ctx.st;
+      const double inv1 = lw1 > 1 ? 1.0 / (double)(lw1 - 1) : 0.0, inv2 = lw2 > 1 ? 1.0 / (double)(lw2 - 1) : 0.0;
+      // The three values every thread of the job shares -- e2 and the two window rotation steps -- in ONE sincospi: lanes
+      // 0 / 1 / 2 of each wave evaluate one of them each, everybody reads the results from those lanes.
+      {
+        const int lane = tid & 63;
+        const double a = lane == 0 ? chirp_angle(2.0 * dnd * dnd, cs) : (2.0 * st * dnd) * (lane == 1 ? inv1 : inv2);
+        double s3, c3;
+        sincospi(a, &s3, &c3);
+        e2 = {lane_value(c3, 0), -lane_value(s3, 0)};
+        if (hann && lw1 > 1) { rs = lane_value(s3, 1); rc = lane_value(c3, 1); }
+        if (hann && second && lw2 > 1) { rs2 = lane_value(s3, 2); rc2 = lane_value(c3, 2); }
+      }
+      if (hann) {
         // window index of transform index n: n (plain), or 2n / 2n+1 for the even / odd samples of an interleaved job
-        const long long st = ctx.st;
-        const long long i1 = st * n0, i2 = st * n0 + (st - 1);
-        if (lw1 > 1) {
-          sincospi((double)(2 * i1 + 1 - lw1) / (double)(lw1 - 1), &hs, &hc);
-          sincospi((double)(2 * st * dn) / (double)(lw1 - 1), &rs, &rc);
-        }
-        if (lw2 > 1) {
-          sincospi((double)(2 * i2 + 1 - lw2) / (double)(lw2 - 1), &hs2, &hc2);
-          sincospi((double)(2 * st * dn) / (double)(lw2 - 1), &rs2, &rc2);
-        }
+        const double i1 = st * n0d, i2 = st * n0d + (st - 1.0);
+        if (lw1 > 1) sincospi((2.0 * i1 + 1.0 - (double)lw1) * inv1, &hs, &hc);
+        if (second && lw2 > 1) sincospi((2.0 * i2 + 1.0 - (double)lw2) * inv2, &hs2, &hc2);
       }
     }
-    const unsigned total = N1 * (unsigned)C;
-    const unsigned cnt = total > (unsigned)tid ? (total - (unsigned)tid + FL_THREADS - 1) / FL_THREADS : 0u;   // my elements
-    for (unsigned jb = 0; jb < cnt; jb += FL_UI) {
-      RawL raw[FL_UI];
+    // (nothing of the value phase -- not even the float -> double conversions of the loaded samples, which the optimiser
+    // otherwise hoists to right behind the loads -- may come before this line: the first use of a load is where the wave
+    // starts to wait for memory; the empty asm pins the loaded values here)
+    if (MODE == IN_SIGNAL) {
 #pragma unroll
-      for (int u = 0; u < FL_UI; ++u) {
-        const unsigned j = jb + u < cnt ? jb + u : cnt - 1;                 // clamp: unconditional loads
-        raw[u] = fetch_input<MODE>(J, ctx, n0 + (long long)j * dn);
+      for (int u = 0; u < UI; ++u) asm volatile("" : "+v"(raw[u].fa), "+v"(raw[u].fb));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    for (unsigned jb = 0; jb < cnt; jb += UI) {
+      if (jb > 0) {
+#pragma unroll
+        for (int u = 0; u < UI; ++u) {
+          const unsigned j = jb + u < cnt ? jb + u : cnt - 1;
+          raw[u] = fetch_input<MODE>(J, ctx, n0 + (long long)j * dn);
+        }
       }
 #pragma unroll
-      for (int u = 0; u < FL_UI; ++u) {
+      for (int u = 0; u < UI; ++u) {
         const unsigned j = jb + u;
         if (j < cnt) {
           const unsigned n1 = (tid + FL_THREADS * j) >> lc;
@@ -325,9 +377,11 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
           const double nc = hc * rc - hs * rs;
           hs = hs * rc + hc * rs;
           hc = nc;
-          const double nc2 = hc2 * rc2 - hs2 * rs2;
-          hs2 = hs2 * rc2 + hc2 * rs2;
-          hc2 = nc2;
+          if (second) {
+            const double nc2 = hc2 * rc2 - hs2 * rs2;
+            hs2 = hs2 * rc2 + hc2 * rs2;
+            hc2 = nc2;
+          }
         }
       }
     }
@@ -503,8 +557,10 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   // sincospi per element, which were most of this kernel's instructions; <= 8 steps, a few 1e-16).
   const long long dn = (long long)(FL_THREADS >> lc) * N2;
   const long long n0 = (long long)((unsigned)tid >> lc) * N2 + n2_0 + ((unsigned)tid & cm);
-  cd cw = unit_q(n0 * n0, L), cdl = unit_q(2 * n0 * dn + dn * dn, L);
-  const cd ce2 = unit_q(2 * dn * dn, L);
+  const ChirpScale cs = chirp_scale(L);
+  const double n0d = (double)n0, dnd = (double)dn;
+  cd cw = unit_q(n0d * n0d, cs), cdl = unit_q(2.0 * n0d * dnd + dnd * dnd, cs);
+  const cd ce2 = unit_q(2.0 * dnd * dnd, cs);
   for (unsigned i = tid; i < N1 * (unsigned)C; i += FL_THREADS) {
     const unsigned c = i & cm, n1 = i >> lc;
     const long long n = (long long)n1 * N2 + n2_0 + c;

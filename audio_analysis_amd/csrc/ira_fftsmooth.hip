@@ -341,6 +341,7 @@ struct SCtx {
   long long nd1, nd2, lw1, lw2;     // SM_SIGNAL: samples actually read / Hann window lengths of the two signals
   bool two;                         // SM_SPECTRUM: the two bands come from two different spectra
   BandMaskS b1, b2;
+  ira::MaskCuts k1, k2;             // first bins past each mask edge (ira_bandmask.h)
   double fv;
 };
 
@@ -379,6 +380,7 @@ __device__ __forceinline__ SCtx smooth_ctx(const SmoothPlan& P, const SJobs& J, 
     c.b1 = uniform_band(b1);
     c.b2 = uniform_band(b2);
     c.fv = ira::uniform(fv);
+    ira::band_cuts(c.b1, c.b2, c.fv, (int)(n / 2), c.k1, c.k2);
   }
   return c;
 }
@@ -424,9 +426,8 @@ __device__ __forceinline__ cd smooth_value(const SmoothPlan& P, const SJobs& J, 
     const bool upper = i > n / 2;
     const long long k = upper ? n - i : i;
     cd x1 = {r.a, upper ? -r.b : r.b};
-    const float f = (float)((double)k * c.fv);
-    const double m1 = (double)mask_s(c.b1, f);
-    const double m2 = (double)mask_s(c.b2, f);
+    const double m1 = (double)ira::mask_cut(c.b1, c.k1, (int)k, c.fv);
+    const double m2 = (double)ira::mask_cut(c.b2, c.k2, (int)k, c.fv);
     cd w;
     if (!c.two) {
       w = ira::cmul(x1, cd{m1, m2});
