@@ -158,9 +158,13 @@ __global__ __launch_bounds__(64) void ar_gram_kernel(const float* __restrict__ x
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Lag sums.  grid (chunks of LAG_CHUNK rows, 1, nb), 256 threads.  The chunk (plus a p+3 sample halo) is staged in
-// LDS as float64; a thread owns FOUR consecutive lags and a sub-range of the rows, sliding a 4-value window so
-// that each row costs two LDS reads for four FMAs; sub-range sums are combined in a fixed order.
+// Lag sums.  grid (chunks of LAG_CHUNK rows, 1, nb), 256 threads.  The chunk (plus a halo of earlier samples) is staged
+// in LDS as float64; a thread owns LPT consecutive lags and a sub-range of the rows and slides an LPT-value window, so
+// that a row costs TWO LDS reads for LPT FMAs.  The kernel is bound by LDS data return, not by the FMAs: with four lags
+// per thread (the first version) the 12 waves of a CU asked LDS for twice the cycles their FMAs took, and neither
+// unrolling nor fewer instructions moved its 0.28 ms (64 x 10 s, p = 64); LPT = 13 (65 lags = 5 x 13) reads 3.25x less.
+// The window lives in registers under compile-time renaming (an LPT-row unrolled body, no moves).  Every accumulator sees
+// its rows in order, so the sums do not depend on LPT.  Sub-range sums are combined in a fixed order.
 // Partial record of element e (doubles):  [nchunks_max][p+1] lag sums | head s[0..p] | tail s[N-1], s[N-2] .. s[N-1-p]
 // ------------------------------------------------------------------------------------------------------------
 constexpr int LAG_CHUNK = 4096;
@@ -172,7 +176,17 @@ __host__ __device__ inline int lag_chunks(long long max_len, int p) {
 __host__ __device__ inline long long lag_record_doubles(long long max_len, int p) {
   return (long long)lag_chunks(max_len, p) * (p + 1) + 2ll * (p + 1);
 }
+// lags per thread: the candidate that wastes the fewest lag slots (ties: the wider one)
+inline int lag_per_thread(int nlag) {
+  int best = 8, best_waste = 1 << 30;
+  for (int c : {16, 13, 12, 10, 8}) {
+    const int waste = (nlag + c - 1) / c * c - nlag;
+    if (waste < best_waste) { best_waste = waste; best = c; }
+  }
+  return best;
+}
 
+template <int LPT>
 __global__ __launch_bounds__(LAG_THREADS) void ar_lag_kernel(const float* __restrict__ x,
                                                              const double* __restrict__ x64,
                                                              const int64_t* __restrict__ xoff,
@@ -188,22 +202,40 @@ __global__ __launch_bounds__(LAG_THREADS) void ar_lag_kernel(const float* __rest
   if (row0 >= N) return;
   const long long n_end = (row0 + LAG_CHUNK < N) ? row0 + LAG_CHUNK : N;
   const int rows = (int)(n_end - row0);
-  const int halo = p + 3;
+  const int nlag = p + 1, ngroups = (nlag + LPT - 1) / LPT;
+  const int halo = LPT * ngroups;                      // the last group's window reaches back LPT * ngroups - 1 samples
   const long long origin = row0 - halo;              // sample index of lds[0]
-  double* lds = reinterpret_cast<double*>(smem_raw);                 // halo + LAG_CHUNK samples
-  const int nlag = p + 1, ngroups = (nlag + 3) / 4;
+  double* lds = reinterpret_cast<double*>(smem_raw);                 // halo + LAG_CHUNK samples; reused for the partials
   const int nsub = ngroups >= LAG_THREADS ? 1 : LAG_THREADS / ngroups;
-  double* red = lds + halo + LAG_CHUNK;                              // [nsub][4 * ngroups]
   const float* xs = x ? x + xoff[e] : nullptr;
   const double* xd = x64 ? x64 + xoff[e] : nullptr;
   const double div = divisor ? divisor[e] : 1.0;
   const int tid = threadIdx.x;
   double* rec = part + (long long)e * rec_doubles;
 
-  for (int m = tid; m < halo + rows; m += LAG_THREADS) {
-    const long long idx = origin + m;
-    lds[m] = (idx >= 0 && idx < N) ? (xd ? xd[idx] : (double)xs[idx]) / div : 0.0;
-  }
+  // Staging in batches of nine loads (index clamped, value dropped afterwards: a load inside the range test is waited
+  // for on the spot, i.e. one memory round trip per sample and thread -- 17 of them in a row before).
+  constexpr int LAG_STAGE = 9;                                        // two batches cover halo + LAG_CHUNK at p <= 64
+  auto stage = [&](auto src) {                                        // float or double samples: one code path each
+    for (int m0 = tid; m0 < halo + rows; m0 += LAG_STAGE * LAG_THREADS) {
+      decltype(src[0] + 0) v[LAG_STAGE];
+#pragma unroll
+      for (int u = 0; u < LAG_STAGE; ++u) {
+        long long idx = origin + m0 + u * LAG_THREADS;
+        idx = idx < 0 ? 0 : (idx < N ? idx : N - 1);
+        v[u] = src[idx];
+      }
+#pragma unroll
+      for (int u = 0; u < LAG_STAGE; ++u) asm volatile("" : "+v"(v[u]));   // no conversion hoisted up to the loads
+#pragma unroll
+      for (int u = 0; u < LAG_STAGE; ++u) {
+        const int m = m0 + u * LAG_THREADS;
+        const long long idx = origin + m;
+        if (m < halo + rows) lds[m] = (idx >= 0 && idx < N) ? (double)v[u] / div : 0.0;
+      }
+    }
+  };
+  if (xd) stage(xd); else stage(xs);
   if (chunk == 0) {
     // head and tail samples for the O(p^2) corrections of the solve kernel
     double* head = rec + (long long)nchunks_max * nlag;
@@ -216,33 +248,54 @@ __global__ __launch_bounds__(LAG_THREADS) void ar_lag_kernel(const float* __rest
   __syncthreads();
 
   const int sub_len = (rows + nsub - 1) / nsub;
-  for (int item = tid; item < ngroups * nsub; item += LAG_THREADS) {
-    const int g = item % ngroups, sub = item / ngroups;
-    const int b0 = 4 * g;
+  const int item = tid;                                 // ngroups * nsub <= LAG_THREADS items
+  const bool active = item < ngroups * nsub;
+  const int g = active ? item % ngroups : 0, sub = active ? item / ngroups : 0;
+  const int b0 = LPT * g;
+  double acc[LPT];
+#pragma unroll
+  for (int j = 0; j < LPT; ++j) acc[j] = 0.0;
+  if (active) {
     const int r_begin = sub * sub_len;
     const int r_end = (r_begin + sub_len < rows) ? r_begin + sub_len : rows;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     if (r_begin < r_end) {
       const double* cur = lds + halo + r_begin;       // s[n] for the first row of the sub-range
       const double* lag = cur - b0;                   // s[n - b0]
-      double w1 = lag[-1], w2 = lag[-2], w3 = lag[-3];
-      for (int r = r_begin; r < r_end; ++r) {
+      double w[LPT];                                  // window: at unrolled step u, slot (j - u) mod LPT holds s[n - b0 - j]
+#pragma unroll
+      for (int j = 1; j < LPT; ++j) w[j] = lag[-j];
+      w[0] = 0.0;
+      int r = r_begin;
+      for (; r + LPT <= r_end; r += LPT) {
+#pragma unroll
+        for (int u = 0; u < LPT; ++u) {
+          const double sn = cur[u];
+          w[(LPT - u) % LPT] = lag[u];               // the newest value takes the slot of the oldest
+#pragma unroll
+          for (int j = 0; j < LPT; ++j) acc[j] = fma(sn, w[(j - u + LPT) % LPT], acc[j]);
+        }
+        cur += LPT; lag += LPT;
+      }
+      for (; r < r_end; ++r) {                        // fewer than LPT rows left: one at a time, the window moved
         const double sn = *cur++;
-        const double w0 = *lag++;
-        a0 = fma(sn, w0, a0);
-        a1 = fma(sn, w1, a1);
-        a2 = fma(sn, w2, a2);
-        a3 = fma(sn, w3, a3);
-        w3 = w2; w2 = w1; w1 = w0;
+        w[0] = *lag++;
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) acc[j] = fma(sn, w[j], acc[j]);
+#pragma unroll
+        for (int j = LPT - 1; j > 0; --j) w[j] = w[j - 1];
       }
     }
-    double* o = red + (size_t)sub * (4 * ngroups) + b0;
-    o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+  }
+  __syncthreads();                                      // every thread is done with the samples: lds becomes [nsub][LPT * ngroups]
+  if (active) {
+    double* o = lds + (size_t)sub * (LPT * ngroups) + b0;
+#pragma unroll
+    for (int j = 0; j < LPT; ++j) o[j] = acc[j];
   }
   __syncthreads();
   for (int b = tid; b < nlag; b += LAG_THREADS) {
     double sum = 0.0;
-    for (int sub = 0; sub < nsub; ++sub) sum += red[(size_t)sub * (4 * ngroups) + b];
+    for (int sb = 0; sb < nsub; ++sb) sum += lds[(size_t)sb * (LPT * ngroups) + b];
     rec[(long long)chunk * nlag + b] = sum;
   }
 }
@@ -852,17 +905,29 @@ extern "C" int32_t ira_ar_gram(const float* x_dev, const double* x64_dev, const 
   if (rc != IRA_OK || nb == 0) return rc;
   if (!ar_dense(flags)) {
     const int lchunks = lag_chunks(max_len, order);
-    const int ngroups = (order + 1 + 3) / 4;
-    const int nsub = ngroups >= LAG_THREADS ? 1 : LAG_THREADS / ngroups;
-    const size_t lds = sizeof(double) * ((size_t)(order + 3) + LAG_CHUNK + (size_t)nsub * 4 * ngroups);
-    if (lds > 64 * 1024) {
-      hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&ar_lag_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (er != hipSuccess) return ira_hip_status(er);
+    const int lpt = lag_per_thread(order + 1);
+    const int ngroups = (order + 1 + lpt - 1) / lpt;
+    const size_t lds = sizeof(double) * ((size_t)lpt * ngroups + LAG_CHUNK);
+    auto launch = [&](auto kernel) -> int32_t {
+      if (lds > 64 * 1024) {
+        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (er != hipSuccess) return ira_hip_status(er);
+      }
+      kernel<<<dim3(lchunks, 1, nb), LAG_THREADS, lds, (hipStream_t)stream>>>(
+          x64_dev ? nullptr : x_dev, x64_dev, xoff_dev, len_dev, divisor_dev, order, lchunks,
+          lag_record_doubles(max_len, order), partial_dev);
+      return IRA_OK;
+    };
+    int32_t lrc;
+    switch (lpt) {
+      case 16: lrc = launch(&ar_lag_kernel<16>); break;
+      case 13: lrc = launch(&ar_lag_kernel<13>); break;
+      case 12: lrc = launch(&ar_lag_kernel<12>); break;
+      case 10: lrc = launch(&ar_lag_kernel<10>); break;
+      default: lrc = launch(&ar_lag_kernel<8>); break;
     }
-    ar_lag_kernel<<<dim3(lchunks, 1, nb), LAG_THREADS, lds, (hipStream_t)stream>>>(
-        x64_dev ? nullptr : x_dev, x64_dev, xoff_dev, len_dev, divisor_dev, order, lchunks,
-        lag_record_doubles(max_len, order), partial_dev);
+    if (lrc != IRA_OK) return lrc;
     IRA_RETURN_LAUNCH();
   }
   const int nchunks = (int)(((int64_t)max_len - order + GR_CHUNK - 1) / GR_CHUNK);
