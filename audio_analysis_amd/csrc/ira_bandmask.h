@@ -133,6 +133,15 @@ __device__ __forceinline__ void band_cuts(const BandMask& b1, const BandMask& b2
   fill(c2, cut + 4);
 }
 
+// Bins outside [lo, hi) have mask 0 for certain (kind 0: nothing passes).
+__device__ __forceinline__ void band_support(const BandMask& b, const MaskCuts& c, int& lo, int& hi) {
+  const int kind = (int)b.kind;
+  lo = 0; hi = 0;
+  if (kind < 1 || kind > 3) return;
+  lo = (kind & 2) ? c.hp_a : 0;
+  hi = (kind & 1) ? c.lp_b : 0x7fffffff;
+}
+
 __device__ __forceinline__ float mask_cut(const BandMask& b, const MaskCuts& c, int k, double step) {
   const int kind = (int)b.kind;                          // uniform
   if (kind < 1 || kind > 3) return 0.0f;
