@@ -376,7 +376,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=4,
                     help="steps of the serialised (one stream) pass that measures per-kernel durations for the rooflines")
-    ap.add_argument("--literal-steps", type=int, default=5,
+    ap.add_argument("--literal-steps", type=int, default=10,
                     help="config report only: extra steps with the reference's default-on group-delay and diffusion "
                          "blocks added (reported as literal_full_report; 0 = skip)")
     ap.add_argument("--upload", default="copy", choices=["pull", "copy"],
@@ -510,7 +510,7 @@ def main():
     if a.config == "report" and a.literal_steps > 0:
         from dataclasses import replace as _replace
         rep2 = FullReport(eng, _replace(settings, run_group_delay=True, run_diffusion=True))
-        run_fed(2, host_f32, rep2)
+        run_fed(max(2, K), host_f32, rep2)            # plan pass: every rotating batch once (its lengths' plan data), untimed
         el2 = timed(lambda c: run_fed(c, host_f32, rep2), a.literal_steps)
         literal = {"value": B * world * a.literal_steps / el2, "unit": "IRs/s", "steps": a.literal_steps,
                    "ms_per_step": 1e3 * el2 / a.literal_steps, "blocks": rep2.s.blocks(),

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs ONE report block over a synthetic batch a few times -- the program rocprofv3 (--kernel-trace --stats / --pmc) wraps
-when a single kernel family is studied.   python3 tools/block_probe.py --block modal|decay|bands|bands3rd|spectrum|stft|zplane"""
+when a single kernel family is studied.   python3 tools/block_probe.py --block modal|decay|bands|bands3rd|spectrum|stft|zplane|gd|diffusion"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,6 +9,7 @@ from audio_analysis_amd.engine import Engine
 from audio_analysis_amd.synth import synth_ir
 from audio_analysis_amd.pipeline import FullReportSettings
 from audio_analysis_amd.analyse import decay, rt60bands, modalcloud, frequency_response, spectrogram, zplane
+from audio_analysis_amd.analyse import group_delay, diffusion
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--block", default="modal")
@@ -30,6 +31,8 @@ run = {
     "spectrum": lambda: frequency_response.spectrum_device(eng, b, 48000, s.frequency_response, "spectrum", want_phase=True),
     "stft": lambda: spectrogram.spectrogram_device(eng, b, 48000, s.spectrogram, frame_major=True),
     "zplane": lambda: zplane.zplane_device(eng, b, 48000, s.zplane),
+    "gd": lambda: group_delay.group_delay_device(eng, b, 48000, s.group_delay),
+    "diffusion": lambda: diffusion.diffusion_device(eng, b, 48000, s.diffusion),
 }[a.block]
 for _ in range(2):
     run()
