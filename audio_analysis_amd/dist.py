@@ -32,7 +32,9 @@ def init_process_group(backend: Optional[str] = None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # IRA_DIST_BACKEND=gloo: rehearsal of the multi-rank host logic on a box with fewer GPUs than ranks (several
+            # ranks then share a device; RCCL refuses that).  Never set in production runs.
+            backend = os.environ.get("IRA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -405,6 +405,8 @@ def main():
     rank, local_rank, world = D.init_process_group()
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("IRA_DIST_BACKEND") == "gloo":          # rehearsal only (dist.init_process_group): ranks may share a device
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     eng = Engine(f"cuda:{local_rank}")
     import audio_analysis_amd.engine as _engine_mod

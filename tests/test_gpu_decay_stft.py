@@ -196,6 +196,9 @@ def test_fused_edc_fits_match_the_curve_path():
     chans.append(slow)
     nan = synth_ir(78, 0, 50000, rt60_seconds=0.2, pre_delay=0).copy(); nan[1234] = np.nan
     chans.append(nan)
+    # a 60 s file whose 0 .. -10 dB range spans ~370 tiles: more than 80 chunks of four, so the moments kernel takes
+    # five tiles per chunk (edc_moments_kernel's K > FIT_MIN_CHUNK_TILES branch)
+    chans.append(synth_ir(79, 0, 2_880_000, rt60_seconds=200.0, pre_delay=0))
     b = eng.upload(chans)
     ranges = [(0.0, -10.0), (-5.0, -25.0), (-5.0, -35.0)]
     cross = (0.0, -10.0)
