@@ -122,7 +122,7 @@ __device__ float np_pairwise_sum_f32(const float* a, int n, PwShared& pw) {
 }
 
 // sum_n cur[n] * lagsrc[n - b] for b = b0..b0+LG-1 over n in [r_begin, r_end); lagsrc has a zero halo below index 0.
-constexpr int LG = 8;    // lags per thread: two LDS reads feed LG FMAs
+constexpr int LG = 8;    // lags per thread: two LDS reads feed LG FMAs (16 lags: 32 KB of partials, one workgroup fewer per CU: 1.79 vs 1.27 ms)
 __device__ __forceinline__ void lag_group(const double* cur, const double* lagsrc, int b0, int r_begin, int r_end,
                                           double (&acc)[LG]) {
   double a[LG], w[LG];
@@ -133,7 +133,22 @@ __device__ __forceinline__ void lag_group(const double* cur, const double* lagsr
     const double* l = lagsrc + r_begin - b0;
 #pragma unroll
     for (int j = 1; j < LG; ++j) w[j] = l[-j];
-    for (int r = r_begin; r < r_end; ++r) {
+    w[0] = 0.0;
+    int r = r_begin;
+    // LG rows per trip with the window renamed at compile time instead of moved (at unrolled step u slot (j - u) mod LG
+    // holds the value for lag offset j; the newest value takes the oldest one's slot): 2 LG LDS reads in flight together, no
+    // register moves; every accumulator still sees its rows in order (same sums as the one-row loop below).
+    for (; r + LG <= r_end; r += LG) {
+#pragma unroll
+      for (int u = 0; u < LG; ++u) {
+        const double sn = c[u];
+        w[(LG - u) % LG] = l[u];
+#pragma unroll
+        for (int j = 0; j < LG; ++j) a[j] = fma(sn, w[(j - u + LG) % LG], a[j]);
+      }
+      c += LG; l += LG;
+    }
+    for (; r < r_end; ++r) {
       const double sn = *c++;
       w[0] = *l++;
 #pragma unroll
@@ -196,6 +211,14 @@ __device__ double block_sum(double v, double* wave_tmp) {
   return s;
 }
 
+// Partial sums of max_abs_lag_sum: nsub * LG * ngroups doubles with nsub = floor(DF_THREADS / ngroups) for ANY lag count up to
+// the largest one a kernel asks for (2 max_lag + 1, stereo) -- not just for that count itself: fewer lags mean more row
+// sub-ranges, and nsub * ngroups can come closer to DF_THREADS (the mono kernel clips its lag range to the window length).
+__host__ __device__ inline size_t red_doubles(int max_lag) {
+  const int ngroups_max = (2 * max_lag + 1 + LG - 1) / LG;
+  return (size_t)LG * (ngroups_max > DF_THREADS ? ngroups_max : DF_THREADS);
+}
+
 struct DiffLayout {
   // dynamic LDS carve-up for a window of n samples and max_lag
   float* wf;        // n raw float32 samples, then reused for w0 (float32) and w0^2
@@ -218,20 +241,14 @@ __device__ __forceinline__ DiffLayout carve(unsigned char* smem, int n, int max_
     L.b0 = nullptr;
   }
   L.red = d;
-  const int nl = max_lag + 1;
-  const int ngroups = (nl + LG - 1) / LG;
-  const int nsub = ngroups >= DF_THREADS ? 1 : DF_THREADS / ngroups;
-  d += (size_t)nsub * LG * ngroups;
+  d += red_doubles(max_lag);
   L.wf = reinterpret_cast<float*>(d);
   return L;
 }
 
 size_t diff_lds_bytes(int n, int max_lag, bool stereo) {
   const int halo = max_lag + LG;
-  const int nl = max_lag + 1;
-  const int ngroups = (nl + LG - 1) / LG;
-  const int nsub = ngroups >= DF_THREADS ? 1 : DF_THREADS / ngroups;
-  size_t doubles = (size_t)(halo + n) * (stereo ? 2 : 1) + (size_t)nsub * LG * ngroups;
+  size_t doubles = (size_t)(halo + n) * (stereo ? 2 : 1) + red_doubles(max_lag);
   return doubles * sizeof(double) + (size_t)n * sizeof(float);
 }
 
