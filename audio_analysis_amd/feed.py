@@ -17,6 +17,9 @@ within run-to-run noise, so the copy engine stays the default.  What does NOT wo
 keep so many PCIe reads in flight that the fabric queues the analysis kernels' HBM reads share back up (the peak pick
 went from 0.09 to 1.2 ms, the step from 6.9 to 8.4 ms).
 
+A float32 / int16 batch crosses as `copy_streams` pieces on as many streams (default 2: one copy of 492 MB ran at 9.6 k or
+11.8 k IRs/s depending on the box, two halves at 11.9-12.1 k on all of them; four pieces 11.5 k).
+
 A ChannelBatch handed out by push() carries the event recorded behind its upload (+ conversion): the peak pick and
 every report lane wait for THAT event only (pipeline.FullReport.submit), never for the copy stream as a whole.
 
@@ -67,9 +70,13 @@ class HostBatch:
 
 
 class DeviceFeed:
-    def __init__(self, eng: Engine, max_samples: int, depth: int = 4, pull: bool = False, pull_workgroups: int = 8):
+    def __init__(self, eng: Engine, max_samples: int, depth: int = 4, pull: bool = False, pull_workgroups: int = 8,
+                 copy_streams: int = 2):
         t = eng.torch
         self.eng = eng
+        # copy_streams > 1: a batch crosses PCIe as that many pieces on that many streams (copy engines) at once; the
+        # batch's ready event waits for all of them
+        self.side_streams = [t.cuda.Stream(device=eng.device) for _ in range(max(0, int(copy_streams) - 1))]
         self.pull = bool(pull)                     # True: the batch crosses PCIe under ira_host_pull instead of hipMemcpyAsync
         self.pull_workgroups = int(pull_workgroups)
         self.depth = int(depth)
@@ -109,6 +116,19 @@ class DeviceFeed:
                 # mono channels laid end to end convert like ONE mono file of `total` frames
                 check(eng.lib.ira_pcm16_to_channels(int(pcm.data_ptr()), int(hb.total), 1, 0, int(x.data_ptr()),
                                                     eng.stream), "ira_pcm16_to_channels")
+            elif self.side_streams and hb.total >= (1 << 20):
+                pieces = len(self.side_streams) + 1
+                step = -(-hb.total // pieces)
+                for i, side in enumerate(self.side_streams):
+                    lo, hi = (i + 1) * step, min(hb.total, (i + 2) * step)
+                    if lo >= hi:
+                        continue
+                    side.wait_stream(self.copy_stream)      # ordered behind whatever used this slot before
+                    with t.cuda.stream(side):
+                        x[lo:hi].copy_(hb.pinned[lo:hi], non_blocking=True)
+                x[: min(step, hb.total)].copy_(hb.pinned[: min(step, hb.total)], non_blocking=True)
+                for side in self.side_streams:
+                    self.copy_stream.wait_stream(side)
             else:
                 x[: hb.total].copy_(hb.pinned[: hb.total], non_blocking=True)
             batch = eng.wrap(x, hb.off, hb.length)          # offsets/lengths + the ready event, all on the copy stream

@@ -382,6 +382,8 @@ def main():
     ap.add_argument("--upload", default="copy", choices=["pull", "copy"],
                     help="pull: the batch crosses PCIe under a pull kernel (ira_host_pull); copy: hipMemcpyAsync on the copy engine")
     ap.add_argument("--pull-workgroups", type=int, default=8)
+    ap.add_argument("--upload-streams", type=int, default=2,
+                    help="float32 / int16 upload as this many pieces on as many copy streams (A/B)")
     ap.add_argument("--variants", default="all", choices=["all", "value"],
                     help="'value' skips the int16 / resident variants (profiling runs)")
     a = ap.parse_args()
@@ -430,7 +432,8 @@ def main():
                     for k in range(K)]
     del chans
     note(f"{K} host batches of {B} x {seconds:g} s synthesised and pinned")
-    feed = DeviceFeed(eng, B * n, depth=4, pull=(a.upload == "pull"), pull_workgroups=a.pull_workgroups)
+    feed = DeviceFeed(eng, B * n, depth=4, pull=(a.upload == "pull"), pull_workgroups=a.pull_workgroups,
+                      copy_streams=a.upload_streams)
     last = {}
 
     def gather(rec):
