@@ -5,6 +5,7 @@
 #include <cmath>
 
 #include "ira_common.h"
+#include "ira_log.h"
 
 namespace {
 
@@ -12,19 +13,67 @@ typedef ira::cplx<double> cd;
 constexpr double kPi = 3.14159265358979323846;
 
 // ---- |X| -> dB (float32) and angle(X) (float64) --------------------------------------------------------------
-__global__ void mag_phase_kernel(const cd* __restrict__ spec, const int64_t* __restrict__ spec_off,
+// 20 log10(hypot(re, im)) = 10 log10(re^2 + im^2) through the table log2 of ira_log.h (25 instructions instead of ~160 for
+// hypot + log10; the float32 result is the same unless the float64 value lies within 1e-15 of a rounding tie), and the angle
+// through a 65-entry arctangent table: t = min / max of |re|, |im|, atan t = atan(k/64) + atan((t - k/64) / (1 + t k/64))
+// with the second term by its series to r^9 (|r| <= 1/128: next term < 1e-24), then the usual octant / sign fix-ups:
+// ~50 instructions instead of ~150, 1-2 ulp.  Zero, infinite and NaN operands take the library routines.  With both the
+// kernel is bound by its 28 bytes per bin instead of by the VALU (times: DESIGN.md section 4).
+constexpr int ATAN_TAB = 64;
+
+__device__ __forceinline__ void build_atan_table(double* tab, int tid) {
+  if (tid <= ATAN_TAB) tab[tid] = atan((double)tid * (1.0 / ATAN_TAB));
+}
+
+__device__ __forceinline__ double atan2_table(double y, double x, const double* tab) {
+  const double ax = fabs(x), ay = fabs(y);
+  const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+  if (!(mx > 0.0 && mx < 1.0e300 && mn > 1.0e-300)) return atan2(y, x);        // zero / tiny / huge / infinite / NaN: library
+  const double t = mn / mx;
+  const int k = (int)(t * (double)ATAN_TAB + 0.5);
+  const double t0 = (double)k * (1.0 / ATAN_TAB);
+  const double r = (t - t0) / fma(t, t0, 1.0);
+  const double r2 = r * r;
+  double s = fma(r2, 1.0 / 9.0, -1.0 / 7.0);
+  s = fma(r2, s, 0.2);
+  s = fma(r2, s, -1.0 / 3.0);
+  s = fma(r2, s, 1.0);
+  double a = fma(r, s, tab[k]);                                                // atan(t), 0 <= t <= 1
+  if (ay > ax) a = 1.5707963267948966 - a;
+  if (x < 0.0) a = kPi - a;
+  return copysign(a, y);
+}
+
+__global__ __launch_bounds__(256) void mag_phase_kernel(const cd* __restrict__ spec, const int64_t* __restrict__ spec_off,
                                  const int32_t* __restrict__ L, double floor_lin, float* __restrict__ mag_db,
                                  const int64_t* __restrict__ mag_off, double* __restrict__ phase,
                                  const int64_t* __restrict__ phase_off) {
+  __shared__ ira::LogTabEntry ltab[ira::LOGTAB_N];
+  __shared__ double atab[ATAN_TAB + 1];
+  ira::build_log_table(ltab, threadIdx.x);
+  build_atan_table(atab, threadIdx.x);
+  __syncthreads();
   const int e = blockIdx.y;
   const long long nb = (long long)L[e] / 2 + 1;
   const cd* s = spec + spec_off[e];
+  float* mo = mag_db + mag_off[e];
+  double* po = phase ? phase + phase_off[e] : nullptr;
+  const double floor_p = floor_lin * floor_lin;
+  const float floor_db32 = (float)(20.0 * log10(floor_lin));
   for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nb; k += (long long)gridDim.x * blockDim.x) {
     const cd v = s[k];
-    const double a = hypot(v.re, v.im);
-    const double m = (a != a) ? a : fmax(a, floor_lin);          // numpy.maximum keeps NaN (frequency_response.py:215-218)
-    mag_db[mag_off[e] + k] = (float)(20.0 * log10(m));
-    if (phase) phase[phase_off[e] + k] = atan2(v.im, v.re);
+    const double p = v.re * v.re + v.im * v.im;
+    float db;
+    if (p > 1.0e-280 && p < 1.0e280 && floor_lin > 1.0e-140) {
+      // numpy.maximum(|X|, floor) in the squared domain; a value AT the floor gives the floor's own float32 dB value
+      db = p > floor_p ? (float)(3.0102999566398120 * ira::log2_table(p, ltab)) : floor_db32;
+    } else {
+      const double a = hypot(v.re, v.im);
+      const double m = (a != a) ? a : fmax(a, floor_lin);        // numpy.maximum keeps NaN (frequency_response.py:215-218)
+      db = (float)(20.0 * log10(m));
+    }
+    mo[k] = db;
+    if (po) po[k] = atan2_table(v.im, v.re, atab);
   }
 }
 
@@ -470,7 +519,7 @@ extern "C" int32_t ira_spectrum_mag_phase(const double* spec_dev, const int64_t*
   if (phase_dev != nullptr && phase_off_dev == nullptr) return IRA_E_NULL;
   if (nb <= 0) return nb == 0 ? IRA_OK : IRA_E_SIZE;
   const double floor_lin = std::pow(10.0, floor_db / 20.0);
-  int blocks = (max_len / 2 + 1 + 255) / 256;
+  int blocks = (max_len / 2 + 1 + 256 * 16 - 1) / (256 * 16);      // 16 bins per thread: the LDS tables are built once per workgroup
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
   mag_phase_kernel<<<dim3(blocks, nb), 256, 0, (hipStream_t)stream>>>(
