@@ -18,7 +18,8 @@ keep so many PCIe reads in flight that the fabric queues the analysis kernels' H
 went from 0.09 to 1.2 ms, the step from 6.9 to 8.4 ms).
 
 A float32 / int16 batch crosses as `copy_streams` pieces on as many streams (default 2: one copy of 492 MB ran at 9.6 k or
-11.8 k IRs/s depending on the box, two halves at 11.9-12.1 k on all of them; four pieces 11.5 k).
+11.8 k IRs/s depending on the box, two halves at 11.9-12.1 k on all of them; four pieces 11.5 k); batches below 192 MB go as
+one copy (the cross-stream events cost more than they buy: 256 x 2 s IRs per step ran at 96 k instead of 137 k IRs/s split).
 
 A ChannelBatch handed out by push() carries the event recorded behind its upload (+ conversion): the peak pick and
 every report lane wait for THAT event only (pipeline.FullReport.submit), never for the copy stream as a whole.
@@ -77,6 +78,7 @@ class DeviceFeed:
         # copy_streams > 1: a batch crosses PCIe as that many pieces on that many streams (copy engines) at once; the
         # batch's ready event waits for all of them
         self.side_streams = [t.cuda.Stream(device=eng.device) for _ in range(max(0, int(copy_streams) - 1))]
+        self.split_bytes = 192 << 20                # smaller batches go as one copy (256 x 2 s = 98 MB: 137 k vs 96 k IRs/s)
         self.pull = bool(pull)                     # True: the batch crosses PCIe under ira_host_pull instead of hipMemcpyAsync
         self.pull_workgroups = int(pull_workgroups)
         self.depth = int(depth)
@@ -116,7 +118,7 @@ class DeviceFeed:
                 # mono channels laid end to end convert like ONE mono file of `total` frames
                 check(eng.lib.ira_pcm16_to_channels(int(pcm.data_ptr()), int(hb.total), 1, 0, int(x.data_ptr()),
                                                     eng.stream), "ira_pcm16_to_channels")
-            elif self.side_streams and hb.total >= (1 << 20):
+            elif self.side_streams and hb.nbytes >= self.split_bytes:
                 pieces = len(self.side_streams) + 1
                 step = -(-hb.total // pieces)
                 for i, side in enumerate(self.side_streams):
