@@ -43,12 +43,6 @@ struct Geom {
                  // 16 K2 no filter multiply, 32 K3 no FFT, 64 K3 plain epilogue, 128 K2 no store, 256 K3 no load
 };
 
-// W_M^p for p < M as a product of a coarse (N1-entry) and a fine (N2-entry) table value.
-__device__ __forceinline__ cd twiddle_m(const Geom& g, unsigned p) {
-  const unsigned hi = p >> g.log2n2, lo = p & ((1u << g.log2n2) - 1u);
-  return ira::cmul(g.t1[hi], g.tf[lo]);
-}
-
 // Phase of a chirp value: q / L half-turns reduced to [0, 2), for an exact non-negative integer q < 2^53 held in a double
 // (n^2, 2 n dn + dn^2, 2 dn^2 with n, dn < 2^22).  q mod 2L comes out EXACTLY from one fma -- the quotient estimate is off
 // by at most one, the remainder is an integer below 2^33 -- instead of a 64-bit integer division (85 instructions; the

@@ -136,17 +136,6 @@ __device__ __forceinline__ void bfly<8>(cd (&a)[8]) {
   t = a[1]; a[1] = a[4]; a[4] = t;
   t = a[3]; a[3] = a[6]; a[6] = t;
 }
-template <>
-__device__ __forceinline__ void bfly<16>(cd (&a)[16]) {
-  ira::dft_dif<double, 16>(a);
-  cd t;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int j = ira::brev_bits(i, 4);
-    if (j > i) { t = a[i]; a[i] = a[j]; a[j] = t; }
-  }
-}
-
 // One Stockham pass of radix R on sub-length m*R with stride s (= product of the previous radices), nbat transforms:
 //   y[q + s (R p + k)] = W_N^(s p k) * sum_j x[q + s (p + m j)] W_R^(j k),   p < m, q < s.
 // p = bf / s by a multiply-high with magic = floor(2^32 / s) + 1 (exact for bf < 2^16); the R-1 twiddles of a butterfly
@@ -296,14 +285,7 @@ __device__ __forceinline__ int dif_slot(int k, const FastDiv* radices, const int
   return slot;
 }
 
-// W_n^p for p < n = N1*N2 as a coarse (N1 entries) times a fine (N2 entries) table value.
-__device__ __forceinline__ cd twiddle_n(const SmoothPlan& P, unsigned p) {      // p < n <= 2^20
-  const unsigned hi = fdiv(p, P.dn2), lo = p - hi * (unsigned)P.n2;
-  return ira::cmul(P.t1[hi], P.tf[lo]);
-}
-
 using BandMaskS = ira::BandMask;
-__device__ __forceinline__ float mask_s(const BandMaskS& b, float f) { return ira::mask_at(b, f); }
 
 struct SJobs {
   // forward: one or two real signals per job
