@@ -11,6 +11,9 @@ from pathlib import Path
 
 _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libira.so"
 _lib = None
+# must equal IRA_ABI_VERSION of include/ira.h: a stale .so called with this file's prototypes would read shifted
+# arguments or undersized scratch (memory corruption on the GPU instead of a clean error)
+ABI_VERSION = 3
 
 c_f32p = C.c_void_p
 c_i64p = C.c_void_p
@@ -85,7 +88,10 @@ def load():
     if _lib is not None:
         return _lib
     import os
-    path = Path(os.environ["IRA_LIBRARY"]) if os.environ.get("IRA_LIBRARY") else _LIB_PATH   # profiling: the tuning build
+    # IRA_LIBRARY: the separately built tuning / ablation library (python -m audio_analysis_amd.build --tuning), honoured
+    # only together with IRA_TUNING=1 (profiling tools set both); it passes the same ABI check as the product library
+    tuning = os.environ.get("IRA_LIBRARY") if os.environ.get("IRA_TUNING") == "1" else None
+    path = Path(tuning) if tuning else _LIB_PATH
     if not path.exists():
         raise IraError(
             f"{path} not found. The HIP library is the product path and has no fallback; "
@@ -100,6 +106,10 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    have = int(lib.ira_abi_version())
+    if have != ABI_VERSION:
+        raise IraError(f"{path} has ABI version {have}, this package binds version {ABI_VERSION}: rebuild it with "
+                       "`python -m audio_analysis_amd.build`" + (" --tuning" if tuning else ""))
     _lib = lib
     return lib
 

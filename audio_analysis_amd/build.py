@@ -60,8 +60,9 @@ def _stale(obj: Path, deps) -> bool:
 
 def build_tuning(verbose: bool = True) -> Path:
     """The TUNING build: the same sources with -DIRA_TUNING_BUILD, i.e. with the IRA_* environment knobs (ablations, tile
-    and radix overrides, A/B kernel selection) compiled in -> csrc/libira_tuning.so.  Never loaded by the product; point
-    IRA_LIBRARY at it to profile (audio_analysis_amd._lib honours that variable for this purpose only)."""
+    and radix overrides, A/B kernel selection) compiled in -> csrc/libira_tuning.so.  Never loaded by the product; set
+    IRA_TUNING=1 and point IRA_LIBRARY at it to profile (audio_analysis_amd._lib honours the pair for this purpose only and
+    checks its ABI version like the product library's)."""
     hipcc = _hipcc()
     objs = []
     out = CSRC / "libira_tuning.so"

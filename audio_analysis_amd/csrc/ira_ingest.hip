@@ -55,7 +55,19 @@ int32_t parse_wav(FILE* f, WavInfo* w) {
         w->frames = block_align ? (int64_t)size / block_align : 0;           // header facts for the caller's validation
         return IRA_E_UNSUPPORTED;
       }
-      w->frames = (int64_t)size / (2 * w->channels);
+      // A payload shorter than the header says: the reference's reader (scipy.io.wavfile.read behind analyse/io.py:200)
+      // warns "Reached EOF prematurely" and returns the samples the file holds (numpy.fromfile reads what is there); the
+      // reference then analyses them.  Whole samples that do not make whole stereo frames fail its reshape(-1, channels)
+      // with a ValueError -> IRA_E_FORMAT here.
+      int64_t samples = (int64_t)size / 2;
+      const long here = std::ftell(f);
+      if (std::fseek(f, 0, SEEK_END) == 0) {
+        const int64_t avail = ((int64_t)std::ftell(f) - (int64_t)here) / 2;
+        if (avail < samples) samples = avail < 0 ? 0 : avail;
+      }
+      (void)std::fseek(f, here, SEEK_SET);
+      if (samples % w->channels != 0) return IRA_E_FORMAT;
+      w->frames = samples / w->channels;
       return IRA_OK;
     } else {
       if (std::fseek(f, (long)(size + (size & 1)), SEEK_CUR) != 0) return IRA_E_IO;   // LIST, fact, ... (word aligned)

@@ -49,12 +49,14 @@ def shard_files(num_files: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, hi
 
 
-def gather_metrics(local: np.ndarray, device=None, stream=None) -> Optional[np.ndarray]:
+def gather_metrics(local: np.ndarray, device=None, stream=None, equal_rows: bool = False) -> Optional[np.ndarray]:
     """
     Gather per-channel records (n_local, width) float64 from every rank to rank 0, in rank order (= file order
     under shard_files).  Returns the concatenated array on rank 0 and None elsewhere.  Single process: identity.
     `stream` (RCCL only): enqueue the collective relative to THIS stream instead of the current one, so that a
     gather of step k does not queue behind the kernels of step k+1 that are already on the compute stream.
+    `equal_rows`: every rank holds the same number of rows (fixed shard sizes): the row-count exchange and its host
+    synchronisation are skipped -- the whole exchange is ONE collective.
     """
     import torch
     import torch.distributed as dist
@@ -64,22 +66,25 @@ def gather_metrics(local: np.ndarray, device=None, stream=None) -> Optional[np.n
         return local
     if stream is not None and dist.get_backend() == "nccl":
         with torch.cuda.stream(stream):
-            return _gather_metrics(local, device)
-    return _gather_metrics(local, device)
+            return _gather_metrics(local, device, equal_rows)
+    return _gather_metrics(local, device, equal_rows)
 
 
-def _gather_metrics(local: np.ndarray, device=None) -> Optional[np.ndarray]:
+def _gather_metrics(local: np.ndarray, device=None, equal_rows: bool = False) -> Optional[np.ndarray]:
     import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(), dist.get_rank()
     on_gpu = dist.get_backend() == "nccl"
     dev = (device or torch.device("cuda", torch.cuda.current_device())) if on_gpu else torch.device("cpu")
     width = int(local.shape[1])
-    # 1) row counts (so ragged shards are handled), 2) one padded gather of the records
-    counts = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
-    all_counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(all_counts, counts)
-    all_counts = [int(c.item()) for c in all_counts]
+    if equal_rows:
+        all_counts = [int(local.shape[0])] * world
+    else:
+        # 1) row counts (so ragged shards are handled), 2) one padded gather of the records
+        counts = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
+        all_counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(all_counts, counts)
+        all_counts = [int(c.item()) for c in all_counts]
     cap = max(all_counts) if all_counts else 0
     send = torch.zeros((cap, width), dtype=torch.float64, device=dev)
     if local.shape[0]:

@@ -38,7 +38,10 @@ IRA_E_FORMAT = -5
 def _raise_like_scipy(rc: int, path: Path) -> None:
     """Errors of the reference's reader for the same files (scipy.io.wavfile.read behind analyse/io.py:200): a missing
     or unreadable file is an OSError (FileNotFoundError when it does not exist), a file that is not RIFF/WAVE a
-    ValueError.  bundle.run_bundle_report's abort semantics (reference bundle.py:56-67) depend on the types."""
+    ValueError.  bundle.run_bundle_report's abort semantics (reference bundle.py:56-67) depend on the types.
+    A data chunk shorter than its header says is NOT an error there: scipy warns "Reached EOF prematurely" and returns
+    the samples the file holds, so ira_wav_probe reports that many frames and the tap is analysed (tests/golden/
+    truncated_wav.json, written by the reference's reader)."""
     import errno
     import os
     if rc == IRA_E_IO:

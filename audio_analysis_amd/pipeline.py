@@ -116,6 +116,11 @@ def _same_spectrum(a, b) -> bool:
     """fr and filter analyse the identical windowed segment when these fields agree -> share one rFFT."""
     keys = ("trim_to_peak", "ignore_leading_seconds", "analysis_duration_seconds", "use_hann_window",
             "magnitude_floor_db", "f_min_hz", "f_max_hz")
+    # The fr block log-smooths its dB curve IN PLACE on the device when smoothing_log_bins > 1
+    # (frequency_response.py:117-169); the reference's filterplot has no smoothing and reads the raw spectrum
+    # (filterplot.py:152-170), so a smoothed curve is never shared.
+    if int(getattr(a, "smoothing_log_bins", 0) or 0) > 1:
+        return False
     return all(getattr(a, k) == getattr(b, k) for k in keys)
 
 
@@ -289,6 +294,12 @@ class FullReport:
         groups = [bands_group, spectrum_group, zplane_group, decay_group, modal_group, stft_group]
         done = []
         if lanes is None:
+            # one stream: the batch may have been uploaded (and its offset / length tables allocated) on a feed's copy
+            # stream -- wait for its upload and keep the allocator from recycling its arrays under this stream's kernels
+            if batch.ready is not None:
+                main.wait_event(batch.ready)
+            for buf in (batch.x, batch.off_dev, batch.len_dev):
+                buf.record_stream(main)
             for work in groups:
                 work()
             ev = t.cuda.Event()
@@ -315,7 +326,8 @@ class FullReport:
                     ev.record(lane)
                     done.append(ev)
         spectrum, filt = state["spectrum"], state["filt"]
-        return dict(n=n, m=m, res=res, fut=fut, done=done, spectrum=spectrum, filt=filt)
+        # the handle keeps the batch (its device tables) alive until finish() has seen every lane's event
+        return dict(n=n, m=m, res=res, fut=fut, done=done, spectrum=spectrum, filt=filt, batch=batch)
 
     def finish(self, h: dict) -> np.ndarray:
         if h.get("scatter"):
@@ -403,4 +415,5 @@ class FullReport:
                     m[i, M_DIFF_AC_MEDIAN] = float(np.nanmedian(ac[o : o + f]))
                     m[i, M_DIFF_ED_MEDIAN] = float(np.nanmedian(ed[o : o + f]))
         self.device_results = res
+        h.pop("batch", None)
         return m

@@ -284,6 +284,15 @@ def make_roof(ev, roof_steps, settings, L, n, nchan, traffic_tab):
             M = 2.0 ** np.ceil(np.log2(2 * tlen - 1))
             stream_b = float(np.sum(4.0 * L + 16.0 * M * 5 + 16.0 * (L // 2 + 1)))
             flops = float(np.sum(2 * 5.0 * M * np.log2(M) + 6.0 * M))
+        if name.startswith("ira_stft_logbin") or (name.startswith("ira_stft_mag_db") and "[f64" in name and ",sel]" not in name):
+            # 2.5 n_fft log2(n_fft) flop per frame (a real transform of n_fft points), float64 vector work
+            nf = settings.modal_cloud.n_fft
+            frames = 1 + (L - nf) // settings.modal_cloud.hop_length
+            flops = float(np.sum(2.5 * nf * np.log2(nf) * frames))
+            out["flops_model"] = {"flop": flops, "achieved_TFLOPs": flops / (step_ms * 1e-3) / 1e12,
+                                  "f64_vector_peak_TFLOPs": F64_VECTOR_PEAK_TFLOPS,
+                                  "frac_of_f64_vector_peak": flops / (step_ms * 1e-3) / 1e12 / F64_VECTOR_PEAK_TFLOPS,
+                                  "model": "2.5 n_fft log2(n_fft) flop per frame (SURVEY.md 8d); the kernel computes in float64"}
         if stream_b is not None:
             out["streaming_model"] = {"bytes": stream_b, "achieved_GBps": stream_b / (step_ms * 1e-3) / 1e9,
                                       "frac_of_hbm_peak": stream_b / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -297,6 +306,45 @@ def make_roof(ev, roof_steps, settings, L, n, nchan, traffic_tab):
         return out
 
     return tot, roof
+
+
+def load_traffic(cfg: str):
+    """Per-call HBM traffic from the PMC passes committed under profiles/ (tools/profile_config.sh + traffic_profile.py;
+    MI355X_MICROARCH.md's 2 x FETCH_SIZE + WRITE_SIZE rule): the newest round's table for this configuration."""
+    for rnd in ("r03", "r02"):
+        try:
+            return json.load(open(os.path.join(REPO, "profiles", f"{rnd}_traffic_{cfg}.json")))["calls"]
+        except Exception:
+            continue
+    return {}
+
+
+# ABI calls that are ONE kernel launch: their live per-call time is that kernel's own duration
+SINGLE_KERNEL_CALLS = {"ira_stft_logbin": "stft5_kernel", "ira_stft_mag_db_tf": "stft3_kernel", "ira_ar_gram": "ar_lag_kernel",
+                       "ira_spectrum_mag_phase": "mag_phase_kernel", "ira_phase_unwrap": "unwrap_kernel",
+                       "ira_spectrum_stats": "stats_kernel", "ira_poly_roots": "poly_roots_kernel"}
+
+
+def dominant_kernel_of_profile(cfg: str):
+    """The kernel with the largest total duration in the committed rocprofv3 --kernel-trace --stats summary of this
+    configuration (profiles/rNN_kernel_stats_cfg<cfg>.csv): (short name, share of device time) or None."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", f"r0[3-9]*_kernel_stats_cfg{cfg}.csv")))
+    if not files:
+        files = sorted(glob.glob(os.path.join(REPO, "profiles", f"r02_v2_kernel_stats_cfg{cfg}.csv")))
+    if not files:
+        return None
+    best, total = None, 0.0
+    for r in csv.DictReader(open(files[-1])):
+        t = float(r["TotalDurationNs"])
+        total += t
+        if best is None or t > best[1]:
+            best = (r["Name"], t)
+    if best is None or total <= 0:
+        return None
+    name = best[0].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0]
+    return name, best[1] / total, os.path.basename(files[-1])
 
 
 def stft_error_distribution(eng, batch, settings, channels: int = 4):
@@ -333,6 +381,30 @@ def stft_error_distribution(eng, batch, settings, channels: int = 4):
             "max_abs_err_db": worst, "fraction_within_1e-3_db": (inside / total) if total else None}
 
 
+def roofline_kernel(cfg, tot, roof):
+    """`roofline` is per ABI CALL (a call may be several kernels: ira_rfft_any is four).  This entry is per KERNEL: the
+    kernel rocprofv3 ranks first in the committed profile of this configuration, timed live when its call is a single
+    launch (then the call's HIP-event time is the kernel's own duration)."""
+    dom = dominant_kernel_of_profile(cfg)
+    if dom is None:
+        return None
+    kname, share, src = dom
+    call = next((c for c, k in SINGLE_KERNEL_CALLS.items() if k == kname), None)
+    live = next((n for n in tot if call and n.startswith(call)), None)
+    out = {"kernel": kname, "share_of_device_time_in_profile": share, "profile": f"profiles/{src}"}
+    if live is None:
+        out["note"] = "not a single-launch call: no live per-kernel duration (see the per-kernel CSV of the profile)"
+        return out
+    r = roof(live)
+    r["call"] = r.pop("kernel")
+    out.update(r)
+    if "flops_model" in r:
+        fm = r["flops_model"]
+        out.update(bound="vector-f64", achieved=fm["achieved_TFLOPs"], peak=fm["f64_vector_peak_TFLOPs"], unit="TFLOP/s",
+                   frac=fm["frac_of_f64_vector_peak"], hbm_frac=r.get("frac"))
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------
 def make_bundle(root, taps: int, distinct: int, frames: int, first_index: int):
     """A bundle in the reference recorder's on-disk format (recorder.hpp:55-126): stereo PCM16 taps + meta.json.
@@ -364,6 +436,39 @@ def note(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` outside a torchrun environment: start the N rank processes ourselves (one per GPU, fresh
+    interpreters started BEFORE this process has imported torch or touched a GPU; never an exec), hand them the
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* environment torch.distributed.run would, and wait.  Rank 0 inherits stdout,
+    so its one JSON line is this command's output.  Returns the largest exit code; when a rank dies the others (which
+    would wait for it in the next barrier forever) are terminated."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            rc = max(rc, abs(code))
+            if code != 0:
+                for q in live:
+                    q.terminate()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -386,7 +491,24 @@ def main():
                     help="float32 / int16 upload as this many pieces on as many copy streams (A/B)")
     ap.add_argument("--variants", default="all", choices=["all", "value"],
                     help="'value' skips the int16 / resident variants (profiling runs)")
+    ap.add_argument("--gather", default="final", choices=["final", "step"],
+                    help="final: the records of every step stay on their rank and ONE gather to rank 0 closes the timed "
+                         "region (north star: a single RCCL gather for the final metrics); step: one gather per step (A/B)")
+    ap.add_argument("--spawn-probe", action="store_true",
+                    help="launch check without a GPU: every rank joins a gloo group, rank 0 prints the ranks it gathered "
+                         "(tests/test_host_cpu.py runs `bench.py --gpus 2 --spawn-probe`)")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))
+    if a.spawn_probe:
+        import numpy as np
+        from audio_analysis_amd import dist as D
+        rank, local_rank, world = D.init_process_group("gloo")
+        got = D.gather_metrics(np.full((3, 4), float(rank)), equal_rows=True)
+        D.barrier()
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "ranks": sorted(set(got[:, 0].tolist())), "rows": int(got.shape[0])}))
+        return
 
     import numpy as np
     import torch
@@ -435,17 +557,32 @@ def main():
     feed = DeviceFeed(eng, B * n, depth=4, pull=(a.upload == "pull"), pull_workgroups=a.pull_workgroups,
                       copy_streams=a.upload_streams)
     last = {}
+    kept = []                                          # this rank's records of the steps since the last flush
+    counters = {"steps": 0}
 
     def gather(rec):
-        last["g"] = D.gather_metrics(rec, eng.device, eng.side_stream())
+        counters["steps"] += 1
+        if a.gather == "step":
+            last["g"] = D.gather_metrics(rec, eng.device, eng.side_stream(), equal_rows=True)
+        else:
+            kept.append(rec)
+
+    def flush():
+        """--gather final: ONE gather of all the records this rank produced since the last flush (every rank holds the
+        same number of rows: no count exchange, no host synchronisation before the collective)."""
+        if a.gather == "final" and kept:
+            last["g"] = D.gather_metrics(np.concatenate(kept, axis=0), eng.device, equal_rows=True)
+        kept.clear()
 
     def run_fed(count, host, rep=None):
         run_pipelined(rep or report, feed, (host[i % K] for i in range(count)), gather)
 
     def timed(fn, count):
+        flush()
         D.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         fn(count)
+        flush()                                        # inside the timed region: the gather is part of the job
         D.barrier(); torch.cuda.synchronize()
         return D.max_over_ranks(time.perf_counter() - t0, eng.device)
 
@@ -522,24 +659,23 @@ def main():
                    "note": "same step (H2D included) plus the reference's default-on group-delay and diffusion blocks "
                            "(SURVEY.md 8f); only the IR waveform plots and PNG rendering remain excluded"}
 
+    flush()
     stft_err = None
-    if settings.run_spectrogram:
-        probe = feed.push(host_f32[0])
+    if settings.run_spectrogram and a.variants == "all":      # (profiling runs skip the probe: its extra peak pick and STFT
+        probe = feed.push(host_f32[0])                        # launches would be counted as a step by the traffic tools)
         eng.peaks_begin(probe); eng.peaks(probe)
         stft_err = stft_error_distribution(eng, probe, settings)
 
     if rank != 0:
         return
-    assert gathered is not None and gathered.shape == (B * world, METRICS_WIDTH)
+    rows = B * world * (steps if a.gather == "final" else 1)
+    assert gathered is not None and gathered.shape == (rows, METRICS_WIDTH), (None if gathered is None else gathered.shape, rows)
     assert np.all(gathered[:, 0] == 0.0), "a channel of the timed region did not report status ok"
     total_irs = B * world * steps
     # trimmed lengths of the batch the serialised pass saw last (synthetic pre-delays are 240 + i mod 512)
     pre = np.array([240 + ((first + i) % 512) for i in range(B)], dtype=np.float64)
     L = n - pre
-    try:
-        traffic_tab = json.load(open(os.path.join(REPO, "profiles", f"r02_traffic_{a.config}.json")))["calls"]
-    except Exception:
-        traffic_tab = {}
+    traffic_tab = load_traffic(a.config)
     tot, roof = make_roof(ev, roof_steps, settings, L, n, B, traffic_tab)
     dev_ms = sum(tot.values())
     analysis = {k: v for k, v in tot.items() if k not in INGEST_CALLS}
@@ -572,8 +708,12 @@ def main():
             "batch_per_gpu": B, "ir_seconds": seconds, "parallelism": f"file-sharded dp{world}",
             "arithmetic": "f64 (EDC scan, long FFTs, modal/waterfall STFT, AR Gram/solve/roots); "
                           "f32 butterflies for the spectrogram STFT",
-            "timed_region": "H2D + peak pick + all kernels + metric pack + D2H of records + gather to rank 0",
+            "timed_region": "H2D + peak pick + all kernels + metric pack + D2H of records + "
+                            + ("ONE gather of every step's records to rank 0 after the last step" if a.gather == "final"
+                               else "a gather to rank 0 per step"),
+            "gather": a.gather,
         },
+        "steps_in_process": counters["steps"],
         "value_int16": None if el_i16 is None else total_irs / el_i16,
         "value_resident": None if el_res is None else total_irs / el_res,
         "value_pull_kernel": None if el_pull is None else total_irs / el_pull,
@@ -584,6 +724,7 @@ def main():
                      "value_pull_kernel": "float32 upload by the pull kernel (ira_host_pull) instead of hipMemcpyAsync (A/B)"},
         "h2d_GBps": B * n * 4.0 * steps / elapsed / 1e9,
         "roofline": roof(dominant),
+        "roofline_kernel": roofline_kernel(a.config, tot, roof),
         "roofline_stft": rs,
         "roofline_measured": f"serialised pass of {roof_steps} steps in this run (one stream, kernels one at a time, H2D "
                              f"included); the timed region deals the report blocks onto {lanes_used} streams",
@@ -651,10 +792,7 @@ def bench_bundle(a, cfg, eng, rank, world, B, n, steps, blocks):
     assert gathered.shape == (2 * B * steps * world, METRICS_WIDTH)
     pre = np.repeat(np.array([240 + ((100000 + i) % 512) for i in range(B)], dtype=np.float64), 2)
     L = n - pre
-    try:
-        traffic_tab = json.load(open(os.path.join(REPO, "profiles", "r02_traffic_5.json")))["calls"]
-    except Exception:
-        traffic_tab = {}
+    traffic_tab = load_traffic("5")
     tot, roof = make_roof(ev, roof_steps, settings, L, n, 2 * B, traffic_tab)
     analysis = {k: v for k, v in tot.items() if k not in INGEST_CALLS}
     dominant = max(analysis, key=analysis.get)

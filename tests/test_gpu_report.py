@@ -318,3 +318,53 @@ def test_degenerate_inputs_match_the_reference():
             wf = waterfall.analyse_waterfall_for_channel(xs[tag], 48000, "m", waterfall.WaterfallAnalysisSettings())
             assert list(wf.slice_magnitude_rel_db.shape) == g["waterfall"]["shape"], tag
             assert int(np.isnan(wf.slice_magnitude_rel_db).sum()) == g["waterfall"]["nan"], tag
+
+
+def test_ragged_batches_through_the_feed_on_one_stream():
+    """Round-2 advisor finding: on ONE stream (Engine.num_lanes = 1) a DeviceFeed batch's offset / length tables live in
+    a block allocated on the feed's copy stream; run_pipelined drops the batch before finish(), so the next push could
+    recycle that block under the step's queued kernels.  Ragged batches make that visible: every step's records must
+    equal the records of the same channels analysed on their own."""
+    from audio_analysis_amd import pipeline as P
+    from audio_analysis_amd.engine import get_engine
+    from audio_analysis_amd.feed import DeviceFeed, HostBatch, run_pipelined
+    from audio_analysis_amd.synth import synth_ir
+    eng = get_engine()
+    groups = [[synth_ir(900 + 10 * g + i, 0, 20000 + 1777 * ((3 * g + i) % 5), rt60_seconds=0.12) for i in range(3 + g % 2)]
+              for g in range(6)]
+    rep = P.FullReport(eng)
+    want = [rep.run(eng.upload(chs)) for chs in groups]
+    lanes = eng.num_lanes
+    eng.num_lanes = 1
+    try:
+        feed = DeviceFeed(eng, max(sum(c.size for c in chs) for chs in groups), depth=4)
+        got = []
+        run_pipelined(rep, feed, [HostBatch(eng, chs) for chs in groups], got.append)
+    finally:
+        eng.num_lanes = lanes
+    assert len(got) == len(want)
+    for g, (a, b) in enumerate(zip(got, want)):
+        assert a.tobytes() == b.tobytes(), g
+
+
+def test_filter_block_reads_the_raw_spectrum_when_fr_smoothing_is_on():
+    """Round-2 advisor finding: with frequency-response log smoothing on, the fr block smooths its dB curve in place on
+    the device; the filter block (reference filterplot.py: no smoothing) must not share that curve."""
+    from dataclasses import replace
+    from audio_analysis_amd import pipeline as P
+    from audio_analysis_amd.engine import get_engine
+    from audio_analysis_amd.synth import synth_ir
+    eng = get_engine()
+    chans = [synth_ir(700 + i, 0, 30000 + 999 * i, rt60_seconds=0.15) for i in range(3)]
+    base = P.FullReportSettings()
+    st = replace(base, frequency_response=replace(base.frequency_response, smoothing_log_bins=9))
+    m = P.FullReport(eng, st).run(eng.upload(chans))
+    plain = P.FullReport(eng, base).run(eng.upload(chans))
+    for i, x in enumerate(chans):
+        f = O.analyse_filter_response(x)
+        assert abs(m[i, P.M_FILT_1K] - f["mag_1k_db"]) <= 2e-5 and m[i, P.M_FILT_PEAK] == f["peak_hz"]
+        r = O.analyse_frequency_response(x, smoothing_log_bins=9)
+        assert m[i, P.M_FR_PEAK] == r["peak_hz"]
+        assert abs(m[i, P.M_FR_CENTROID] - r["centroid_hz"]) <= 1e-6 * r["centroid_hz"]
+    assert np.array_equal(m[:, P.M_FILT_1K], plain[:, P.M_FILT_1K])
+    assert not np.array_equal(m[:, P.M_FR_CENTROID], plain[:, P.M_FR_CENTROID])

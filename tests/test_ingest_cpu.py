@@ -90,8 +90,9 @@ def test_native_probe_edge_cases(tmp_path):
     p = tmp_path / "short.wav"
     blob = _wav(fmt16, pcm.tobytes())
     p.write_bytes(blob[:-6])
-    with pytest.raises(OSError):                                          # truncated payload: the reference's reader fails in I/O
-        read_tap_pcm16(probe_tap(p))
+    info = probe_tap(p)                                                   # truncated payload: the reference's reader returns
+    assert info.frames == 12                                              # the samples the file holds (golden test below)
+    assert np.array_equal(read_tap_pcm16(info).reshape(-1), pcm[:12])
     p = tmp_path / "junk.wav"
     p.write_bytes(b"not a wav file at all, sorry")
     with pytest.raises(ValueError):                                       # not RIFF/WAVE: scipy's reader raises ValueError
@@ -103,6 +104,29 @@ def test_native_probe_edge_cases(tmp_path):
     p.write_bytes(b"RIFF" + struct.pack("<I", 12 + 8) + b"WAVE" + b"data" + struct.pack("<I", 0))
     with pytest.raises((ValueError, OSError)):
         probe_tap(p)
+
+
+def test_truncated_taps_read_like_the_reference_reader(tmp_path):
+    """tests/golden/truncated_wav.json (made by make_truncated_wav_golden.py with the reference's load_wav_file): a data
+    chunk shorter than its header says yields the whole frames the file holds; samples that make no whole stereo frame
+    raise ValueError (scipy's reshape)."""
+    import json
+    from audio_analysis_amd.ingest import probe_tap, read_tap_pcm16
+    gold = json.loads((GOLD / "truncated_wav.json").read_text())
+    for name, rec in gold.items():
+        if name.startswith("_"):
+            continue
+        p = tmp_path / f"{name}.wav"
+        p.write_bytes(bytes.fromhex(rec["file_hex"]))
+        if "raises" in rec:
+            with pytest.raises({"ValueError": ValueError, "OSError": OSError}[rec["raises"]]):
+                probe_tap(p)
+            continue
+        info = probe_tap(p)
+        assert [info.frames, info.channels] == rec["shape"], name
+        want = np.frombuffer(bytes.fromhex(rec["samples_f32_hex"]), dtype="<f4").reshape(rec["shape"])
+        got = O.pcm_to_float32(read_tap_pcm16(info)) if info.frames else np.zeros(rec["shape"], np.float32)
+        assert np.array_equal(got, want), name
 
 
 def test_ingest_validation_messages(tmp_path):

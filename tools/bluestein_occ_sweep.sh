@@ -1,7 +1,7 @@
 #!/bin/bash
 # Bluestein passes with radix-8 sub-FFT passes (fewer registers) AND smaller tiles (less LDS): more workgroups per CU?
 # The tuning library must have been built with FL_LR = 3 and without the waves-per-SIMD attribute.
-export IRA_LIBRARY=audio_analysis_amd/csrc/libira_tuning.so
+export IRA_TUNING=1 IRA_LIBRARY=audio_analysis_amd/csrc/libira_tuning.so
 out=gpurun_out/bluestein_occ.txt; : > $out
 for cr in "0 0" "2 2" "1 1" "2 1" "1 2" "4 2"; do
   set -- $cr

@@ -7,6 +7,6 @@ for c in report 2 3 4 5; do
   grep "timed region" $O/bench_cfg$c.err
 done
 for c in report 2 3 4; do
-  bash $R/tools/profile_round2.sh $c gpurun_out/r2_final/prof_$c > $O/prof_$c.log 2>&1 || echo "profile $c failed" >> $O/fail.log
+  bash $R/tools/profile_config.sh $c gpurun_out/r2_final/prof_$c > $O/prof_$c.log 2>&1 || echo "profile $c failed" >> $O/fail.log
 done
 ls $O

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Start-up stagger of the FFT pass kernels (ira::stagger_start): block times for a few delays.  Tuning build only.
 set -e
-export IRA_LIBRARY=audio_analysis_amd/csrc/libira_tuning.so
+export IRA_TUNING=1 IRA_LIBRARY=audio_analysis_amd/csrc/libira_tuning.so
 mkdir -p gpurun_out
 out=gpurun_out/stagger_sweep.txt
 : > $out

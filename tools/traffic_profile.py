@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
-"""Reduce the passes of tools/profile_round2.sh: per-kernel durations and HBM-side counters, per-ABI-call traffic.
+"""Reduce the passes of tools/profile_config.sh: per-kernel durations and HBM-side counters, per-ABI-call traffic.
 
 Byte estimates (MI355X_MICROARCH.md, HBM / rocprofv3 section):
   hbm_bytes_guide   = (2 * FETCH_SIZE + WRITE_SIZE) KiB   -- the guide's rule for wide coalesced reads (FETCH_SIZE tallies
                       128-byte requests at 64 bytes)
   fetch_bytes_req   = 32 * RDREQ_32B + 128 * (RDREQ - RDREQ_32B)   -- by request size, where the 32-byte request counter exists
                       (a blanket 2x over-counts patterns made of 32-byte pieces)
-Per step = divided by the number of steps the run made (= dispatches of the once-per-step peak_decode_kernel).
+Per step = divided by the number of steps the run made: `steps_in_process` of the bench line in stats.log (bench.py counts
+every step it submits; profiling runs skip the STFT-error probe, whose extra peak pick round 2's version of this tool
+counted as a ninth step: every per-step figure of profiles/r02_traffic_{report,2}.json is 8/9 of the truth).  The
+dispatch count of the once-per-step peak_decode_kernel must agree with it, or the tool stops.
 """
 import collections, csv, glob, json, os, sys
 
@@ -14,6 +17,9 @@ d, cfg = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "report")
 
 CALLS = [   # (substring of the kernel name, ABI call)
     ("stft3_kernel", "ira_stft_mag_db_tf[f32,n4096]"), ("stft4_kernel", "ira_stft_logbin[f64,n8192]"),
+    ("stft5_kernel", "ira_stft_logbin[f64,n8192]"), ("stft6_kernel", "ira_stft_mag_db_tf[f32,n4096]"),
+    ("smooth_half_split", "ira_rfft_smooth"), ("rows3_kernel", "ira_rfft_any"), ("edc_moments", "ira_edc_fits"),
+    ("edc_line", "ira_edc_fits"), ("pcm16_jobs", "ira_pcm16_to_channels"),
     ("stft2_kernel<double, 1", "ira_stft_mag_db[f64,n4096,sel]"), ("stft2_kernel", "ira_stft_mag_db"),
     ("smooth_cols_kernel<0>", "ira_rfft_smooth"), ("smooth_rows_kernel<0>", "ira_rfft_smooth"), ("smooth_pair_split", "ira_rfft_smooth"),
     ("smooth_cols_kernel<1>", "ira_band_irfft_smooth"), ("smooth_rows_kernel<1>", "ira_band_irfft_smooth"),
@@ -64,6 +70,14 @@ steps = None
 for k, v in kern.items():
     if "peak_decode" in k and v.get("calls"):
         steps = v["calls"]
+try:
+    line = json.loads(open(os.path.join(d, "stats.log")).read().strip().splitlines()[-1])
+    said = int(line["steps_in_process"])
+    if steps is not None and said != steps and cfg != "5":
+        sys.exit(f"bench says {said} steps, rocprof saw {steps} peak_decode_kernel dispatches: something else launched a peak pick")
+    steps = said
+except (OSError, KeyError, ValueError, IndexError):
+    pass
 steps = steps or 1
 rows = []
 calls = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -96,7 +110,7 @@ try:
     batch = json.loads(open(os.path.join(d, "stats.log")).read().strip().splitlines()[-1])["config"]["batch_per_gpu"]
 except Exception:
     batch = {"report": 256, "2": 256, "3": 256, "4": 256}.get(cfg, 64)
-out = {"source": f"tools/profile_round2.sh {cfg}: rocprofv3 --kernel-trace [--stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc "
+out = {"source": f"tools/profile_config.sh {cfg}: rocprofv3 --kernel-trace [--stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc "
                  "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum], one pass each, IRA_STREAMS=1, copy-engine upload",
        "steps_in_run": steps, "batch": batch,
        "correction": "hbm_bytes_per_channel = (2*FETCH_SIZE + WRITE_SIZE)*1024 per step / batch (guide rule); the by-request "
