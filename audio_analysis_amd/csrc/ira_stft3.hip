@@ -23,6 +23,7 @@
 // buffers and store 64-byte runs of the C-contiguous (F, T) matrix.
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "ira_fft_reg.h"
 
@@ -328,6 +329,304 @@ int32_t launch3(const float* x, const int64_t* off, const int32_t* nframes, int3
   IRA_RETURN_LAUNCH();
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// STFT v6: the frame-major (T, F) variant as a PERSISTENT kernel -- one 16-wave workgroup per CU that walks many tiles of
+// 16 frames, every wave transforming "its" frame of each tile on its own, with NO workgroup barrier inside the loop.
+//
+// Why (round 3, tools/micro/dft16_rate.hip, profiles/r03_dft16_rate.txt): the frame's own instruction stream (1915 VALU
+// instructions, the LDS exchanges included) issues at 1.27 wave-instructions per CU-cycle when 16 waves free-run through
+// it, but stft3_kernel<16, true> ran at 0.65 -- and still at 0.79 with every load and store ablated.  A 16-wave / 150 KB
+// workgroup is the only one its CU can hold, so with one workgroup PER TILE each CU went through launch -> window staging
+// -> barrier -> 16 waves loading at once (L1-bound) -> 16 waves computing in lock-step -> stores -> drain, one phase at a
+// time, ~230 times per launch.  Here the window is staged once per CU, waves drift out of phase within a few tiles, and
+// one wave's loads / stores / LDS round trips run under the arithmetic of the other three on its SIMD.
+// The grid is the CU count (every wave has a fixed trip count: no work queue, nothing to drain).
+// ------------------------------------------------------------------------------------------------------------
+// element at a 32-bit BYTE offset from a wave-uniform base: written this way the access compiles to the scalar-base +
+// 32-bit-lane-offset form (an element index is widened to 64 bits first: two extra VALU instructions per access)
+template <typename T>
+__device__ __forceinline__ T& at32(T* base, unsigned byte_off) {
+  return *reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(base)) + byte_off);
+}
+
+// NT: one-wave teams per workgroup (16 = four waves per SIMD and <= 128 registers; 12 = three per SIMD and <= 170).
+// PF: software pipeline -- the NEXT frame's half-0 samples are requested before this frame's results are computed and
+//     stored, half 1 before half 0 is transformed.  gfx950 counts loads and stores in ONE in-order counter, so a load
+//     issued after a frame's 33 stores cannot be consumed before those stores are acknowledged; issued before them it can.
+// AB: ablation bits, instantiated only by the tuning build (IRA_STFT6_ABLATE): 1 no sample loads, 2 no window reads,
+//     4 no stores, 8 post-stage twiddles without the scalar table loads.  The product runs AB = 0.
+template <int NT, bool PF, int AB>
+__global__ __launch_bounds__(64 * NT) void stft6_kernel(
+    const float* __restrict__ x, const int64_t* __restrict__ off, const int32_t* __restrict__ nframes, int hop,
+    const float* __restrict__ window, const cf* __restrict__ tw, float floor_lin, float floor_db,
+    float* __restrict__ out, const int64_t* __restrict__ out_off, const int32_t* __restrict__ frame_sel,
+    const int64_t* __restrict__ sel_off, unsigned gx, unsigned ntiles, unsigned win_lds_off, int stagger) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x;
+  const int team = __builtin_amdgcn_readfirstlane(tid >> 6), q0 = tid & 63;
+  cf* ex = reinterpret_cast<cf*>(smem_raw) + (size_t)team * EXC;
+  float* exf = reinterpret_cast<float*>(ex);
+  float* winl = reinterpret_cast<float*>(smem_raw + win_lds_off);
+  for (int i = tid; i < 2 * M3; i += 64 * NT) winl[i] = window[i];
+  __syncthreads();                                        // the only workgroup barrier of the kernel
+
+  // Tiles of NT frames in (segment, frame group) order.  Workgroups are dealt round-robin over the 8 XCDs (each with its
+  // own L2): XCD c takes the contiguous range [c * per, (c + 1) * per) and its workgroups walk it interleaved, so that the
+  // tiles in flight at any time are neighbours (7/8 of a frame's samples are shared with the next one).
+  const unsigned nwg = gridDim.x, wg = blockIdx.x;
+  const unsigned xcd = wg & 7u, lane_wg = wg >> 3, wg_per_xcd = (nwg + 7u - xcd) >> 3;
+  const unsigned per = (ntiles + 7u) >> 3;
+  const unsigned t_end = (xcd + 1u) * per < ntiles ? (xcd + 1u) * per : ntiles;
+  const float floor_pow = floor_lin * floor_lin;
+  const float qn = __uint_as_float(0x7fc00000u);
+
+  auto locate = [&](unsigned t, const float*& fxp, float*& fop) -> bool {       // wave-uniform
+    const int seg = (int)(t / gx);
+    const int col = (int)(t - (unsigned)seg * gx) * NT + team;
+    if (col >= nframes[seg]) return false;
+    const int64_t frame = frame_sel ? (int64_t)frame_sel[sel_off[seg] + col] : (int64_t)col;
+    // wave-uniform bases in scalar registers: every access below is base + 32-bit lane offset
+    fxp = x + ira::uniform((long long)(off[seg] + frame * hop));
+    fop = out + ira::uniform((long long)(out_off[seg] + (int64_t)col * F3));
+    return true;
+  };
+  auto load_half = [&](const float* fxp, int qq, int h, float (&xa)[16], float (&xb)[16]) {
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+      const unsigned n = (unsigned)(n1 * 128 + qq + 64 * h);        // unsigned 32-bit lane offsets: scalar base + offset
+      if (AB & 1) { xa[n1] = __uint_as_float(0x3f800000u + n); xb[n1] = __uint_as_float(0x3f000000u + n); }
+      else { xa[n1] = at32(fxp, 8u * n); xb[n1] = at32(fxp, 8u * n + 4u); }
+    }
+  };
+  // optional one-off phase offset between the waves of a SIMD (tuning build; measured: no effect, default 0)
+  for (int i = 0; i < (team >> 2) * stagger; ++i) __builtin_amdgcn_s_sleep(16);
+
+  const unsigned t_step = wg_per_xcd;
+  unsigned t = xcd * per + lane_wg;
+  const float* fx = x;
+  float* fo = out;
+  bool have = false;
+  while (t < t_end && !(have = locate(t, fx, fo))) t += t_step;
+  float xa0[16], xb0[16];                                  // half 0 of the frame about to be transformed (PF)
+  if (PF && have) load_half(fx, q0, 0, xa0, xb0);
+
+  while (have) {
+    unsigned tn = t + t_step;
+    const float* fxn = fx;
+    float* fon = fo;
+    bool have_n = false;
+    while (tn < t_end && !(have_n = locate(tn, fxn, fon))) tn += t_step;
+    // The lane's twiddle factors and their powers are the same for every frame; left to itself the optimiser hoists all of
+    // them out of this loop (~190 registers) and spills them.  An opaque copy of the lane index keeps them per-frame work,
+    // as in the one-frame kernels: three 8-byte L1 hits and ~220 multiply-adds per frame instead of scratch traffic.
+    int q = q0;
+    asm volatile("" : "+v"(q));
+    const int k1l = q & 15, n3a = q >> 4;
+    const cf wlane = tw[(unsigned)q];
+
+    // ---- step 1 ---------------------------------------------------------------------------------------------------
+    cf a1[16];
+    float xa1[16], xb1[16];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int m = q + 64 * h;
+      float xa[16], xb[16], wa[16], wb[16];
+      if (!PF) load_half(fx, q, h, xa, xb);                // (all loads first, one wait)
+#pragma unroll
+      for (int n1 = 0; n1 < 16; ++n1) {
+        const unsigned n = (unsigned)(n1 * 128 + m);
+        if (PF) { xa[n1] = h ? xa1[n1] : xa0[n1]; xb[n1] = h ? xb1[n1] : xb0[n1]; }
+        if (AB & 2) { wa[n1] = 0.5f; wb[n1] = 0.25f; }
+        else { wa[n1] = winl[2u * n]; wb[n1] = winl[2u * n + 1u]; }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      cf v[16];
+#pragma unroll
+      for (int n1 = 0; n1 < 16; ++n1) v[n1] = {xa[n1] * wa[n1], xb[n1] * wb[n1]};
+      if (PF && h == 0) {                                  // half 1's samples: in flight under half 0's DFT
+        __builtin_amdgcn_sched_barrier(0);
+        load_half(fx, q, 1, xa1, xb1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      dft_dif<float, 16>(v);
+      cf p[16];
+      powers16<float>(tw[(unsigned)(2 * m)], p);           // W_M^m = W_N^(2m)
+      if (h == 0) {
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) {
+          const cf a = v[brev_bits(k1, 4)];
+          ex[k1 * ROWH + q] = (k1 == 0) ? a : ira::cmul(a, p[k1]);
+        }
+      } else {
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) {
+          const cf a = v[brev_bits(k1, 4)];
+          a1[k1] = (k1 == 0) ? a : ira::cmul(a, p[k1]);
+        }
+      }
+    }
+    wave_sync();
+
+    // ---- E1 -> step-2 operands ----------------------------------------------------------------------------------------
+    cf b2[2][16];
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+      for (int n2 = 0; n2 < 8; ++n2) b2[hb][n2] = ex[k1l * ROWH + n2 * 8 + n3a + 4 * hb];
+    wave_sync();
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) ex[k1 * ROWH + q] = a1[k1];
+    wave_sync();
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+      for (int n2 = 0; n2 < 8; ++n2) b2[hb][8 + n2] = ex[k1l * ROWH + n2 * 8 + n3a + 4 * hb];
+    wave_sync();
+
+    // ---- step 2 and E2 ---------------------------------------------------------------------------------------------------
+    cf z3[4][8];
+    {
+      cf p[16];
+      dft_dif<float, 16>(b2[0]);
+      powers16<float>(tw[(unsigned)(32 * n3a)], p);
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) {
+        const cf a = b2[0][brev_bits(k2, 4)];
+        ex[k1l + 16 * k2 + E2N3 * n3a] = (k2 == 0) ? a : ira::cmul(a, p[k2]);
+      }
+      dft_dif<float, 16>(b2[1]);
+      powers16<float>(tw[(unsigned)(32 * (n3a + 4))], p);
+#pragma unroll
+      for (int k2 = 1; k2 < 16; ++k2) b2[1][brev_bits(k2, 4)] = ira::cmul(b2[1][brev_bits(k2, 4)], p[k2]);
+    }
+    wave_sync();
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh)
+#pragma unroll
+      for (int n3 = 0; n3 < 4; ++n3) z3[hh][n3] = ex[k1l + 16 * (n3a + 4 * hh) + E2N3 * n3];
+    wave_sync();
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) ex[k1l + 16 * k2 + E2N3 * n3a] = b2[1][brev_bits(k2, 4)];
+    wave_sync();
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh)
+#pragma unroll
+      for (int n3 = 0; n3 < 4; ++n3) z3[hh][4 + n3] = ex[k1l + 16 * (n3a + 4 * hh) + E2N3 * n3];
+    wave_sync();
+
+    // ---- step 3 ---------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh) dft_dif<float, 8>(z3[hh]);
+
+    // ---- E3 ------------------------------------------------------------------------------------------------------------
+    float zkr[16], zpr[16], zki[16], zpi[16], midr, midi;
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh)
+#pragma unroll
+      for (int k3 = 0; k3 < 8; ++k3) exf[q + 64 * hh + 256 * k3] = z3[hh][brev_bits(k3, 3)].re;
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int k = q + 64 * i;
+      zkr[i] = exf[k];
+      zpr[i] = exf[(M3 - k) & (M3 - 1)];
+    }
+    midr = exf[M3 / 2];
+    wave_sync();
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh)
+#pragma unroll
+      for (int k3 = 0; k3 < 8; ++k3) exf[q + 64 * hh + 256 * k3] = z3[hh][brev_bits(k3, 3)].im;
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int k = q + 64 * i;
+      zki[i] = exf[k];
+      zpi[i] = exf[(M3 - k) & (M3 - 1)];
+    }
+    midi = exf[M3 / 2];
+    wave_sync();                                          // the next frame's step 1 writes this buffer again
+
+    // ---- next frame, half 0 (PF): requested BEFORE this frame's results are computed and stored ---------------------------
+    if (PF) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (have_n) load_half(fxn, q, 0, xa0, xb0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- post: X[k] = E + P, X[M-k] = conj(E - P) with E = (Zk + conj Zp)/2, P = W_N^k (-i)(Zk - conj Zp)/2 -> dB -> store.
+    // A NaN (or infinite) sample anywhere in the frame makes every bin of numpy's rfft NaN (spectrogram.py:150): it shows
+    // in Z[0] = sum of the packed inputs, which lane 0 holds as its first pair -- one flag per frame.  Every result is
+    // stored as soon as it exists (nothing of it stays live).
+    const float z0 = (zkr[0] - zkr[0]) + (zki[0] - zki[0]);                // 0 if finite, NaN otherwise
+    const bool bad = __shfl(z0, 0, 64) != 0.0f;
+    float sacc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const cf e = {0.5f * (zkr[i] + zpr[i]), 0.5f * (zki[i] - zpi[i])};
+      const cf d = {0.5f * (zkr[i] - zpr[i]), 0.5f * (zki[i] + zpi[i])};
+      const cf o = {d.im, -d.re};
+      const cf wk = ira::cmul(wlane, (AB & 8) ? cf{wlane.im * (float)(i + 1), wlane.re} : tw[64 * i]);
+      const cf pp = ira::cmul(wk, o);
+      const float lo = bad ? qn : db_of(e.re + pp.re, e.im + pp.im, floor_pow, floor_db);
+      const float hi = bad ? qn : db_of(e.re - pp.re, e.im - pp.im, floor_pow, floor_db);
+      if (AB & 4) { sacc += lo + hi; continue; }
+      const unsigned kk = (unsigned)(q + 64 * i);
+      at32(fo, 4u * kk) = lo;
+      at32(fo, 4u * ((unsigned)M3 - kk)) = hi;              // k = 0 -> bin M (Nyquist)
+    }
+    {
+      const float mid = bad ? qn : db_of(midr, midi, floor_pow, floor_db);
+      if (AB & 4) { if (sacc + mid == 12345.678f) fo[q] = sacc; }
+      else if (q == 0) fo[M3 / 2] = mid;
+    }
+    t = tn; fx = fxn; fo = fon; have = have_n;
+  }
+}
+
+template <int NT, bool PF>
+int32_t launch6(const float* x, const int64_t* off, const int32_t* nframes, int32_t nseg, int32_t max_frames, int32_t hop,
+                const void* window, const void* tw, double floor_db, float* out, const int64_t* out_off,
+                const int32_t* frame_sel, const int64_t* sel_off, hipStream_t st) {
+  constexpr size_t lds_main = ((size_t)NT * EXC * sizeof(cf) + 15) & ~(size_t)15;
+  constexpr size_t lds = lds_main + (size_t)2 * M3 * sizeof(float);
+  static_assert(lds <= 160 * 1024, "one workgroup must fit the CU's LDS");
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      cus <= 0)
+    cus = 256;
+  const unsigned gx = (unsigned)((max_frames + NT - 1) / NT);
+  const unsigned long long tiles = (unsigned long long)gx * (unsigned long long)nseg;
+  if (tiles > 0xffffffffull) return IRA_E_SIZE;
+  unsigned grid = (unsigned)cus;
+  if (tiles < grid) grid = (unsigned)tiles;
+  if (grid == 0) return IRA_OK;
+  const double floor_lin = std::pow(10.0, floor_db / 20.0);
+  const int stagger = ira_tune_int("IRA_STFT6_STAGGER", 0);
+#define IRA_LAUNCH6(AB)                                                                                                   \
+  do {                                                                                                                    \
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&stft6_kernel<NT, PF, AB>),                 \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
+    if (attr != hipSuccess) return ira_hip_status(attr);                                                                  \
+    stft6_kernel<NT, PF, AB><<<grid, 64 * NT, lds, st>>>(x, off, nframes, hop, static_cast<const float*>(window),         \
+                                              static_cast<const cf*>(tw), (float)floor_lin, (float)floor_db, out, out_off, \
+                                              frame_sel, sel_off, gx, (unsigned)tiles, (unsigned)lds_main, stagger);      \
+  } while (0)
+#ifdef IRA_TUNING_BUILD
+  switch (ira_tune_int("IRA_STFT6_ABLATE", 0)) {
+    case 1: IRA_LAUNCH6(1); break;
+    case 4: IRA_LAUNCH6(4); break;
+    case 7: IRA_LAUNCH6(7); break;
+    default: IRA_LAUNCH6(0); break;
+  }
+#else
+  IRA_LAUNCH6(0);
+#endif
+#undef IRA_LAUNCH6
+  IRA_RETURN_LAUNCH();
+}
+
 }  // namespace
 
 int32_t ira_stft3_dispatch(const float* x, const int64_t* off, const int32_t* nframes, int32_t nseg,
@@ -349,5 +648,16 @@ int32_t ira_stft3_dispatch_tf(const float* x, const int64_t* off, const int32_t*
                               int32_t precision, double floor_db, float* out, const int64_t* out_off,
                               const int32_t* frame_sel, const int64_t* sel_off, hipStream_t st) {
   if (precision != 32 || n_fft != 4096) return IRA_E_UNSUPPORTED;
-  return launch3<16, true>(x, off, nframes, nseg, max_frames, hop, window, tw, floor_db, out, out_off, frame_sel, sel_off, st);
+  if (ira_tune_flag("IRA_STFT_V3"))                       // tuning build: the one-workgroup-per-tile kernel (A/B, ablations)
+    return launch3<16, true>(x, off, nframes, nseg, max_frames, hop, window, tw, floor_db, out, out_off, frame_sel, sel_off, st);
+#ifdef IRA_TUNING_BUILD
+  switch (ira_tune_int("IRA_STFT6_VARIANT", 0)) {          // A/B: teams per workgroup x software pipeline
+    case 1: return launch6<16, false>(x, off, nframes, nseg, max_frames, hop, window, tw, floor_db, out, out_off, frame_sel, sel_off, st);
+    case 2: return launch6<12, false>(x, off, nframes, nseg, max_frames, hop, window, tw, floor_db, out, out_off, frame_sel, sel_off, st);
+    case 3: return launch6<12, true>(x, off, nframes, nseg, max_frames, hop, window, tw, floor_db, out, out_off, frame_sel, sel_off, st);
+    case 4: return launch6<16, true>(x, off, nframes, nseg, max_frames, hop, window, tw, floor_db, out, out_off, frame_sel, sel_off, st);
+    default: break;
+  }
+#endif
+  return launch6<16, false>(x, off, nframes, nseg, max_frames, hop, window, tw, floor_db, out, out_off, frame_sel, sel_off, st);
 }

@@ -9,6 +9,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64); ap.add_argument("--seconds", type=float, default=10.0)
 ap.add_argument("--nfft", type=int, default=4096); ap.add_argument("--precision", type=int, default=32)
 ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--tf", action="store_true", help="frame-major (T, F) output: what the metrics pipeline asks for")
 a = ap.parse_args()
 eng = Engine("cuda:0")
 n = int(a.seconds * 48000)
@@ -18,11 +19,11 @@ b = eng.wrap(eng.to_dev(x.reshape(-1)), np.arange(a.batch, dtype=np.int64) * n, 
 starts = np.full(a.batch, 300, dtype=np.int64)
 nfr = np.full(a.batch, 1 + (n - 300 - a.nfft) // 512, dtype=np.int32)
 for _ in range(2):
-    eng.stft_mag_db(b.x, b.off + starts, nfr, a.nfft, 512, True, -120.0, a.precision)
+    eng.stft_mag_db(b.x, b.off + starts, nfr, a.nfft, 512, True, -120.0, a.precision, frame_major=a.tf)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(a.iters):
-    out, off, cols = eng.stft_mag_db(b.x, b.off + starts, nfr, a.nfft, 512, True, -120.0, a.precision)
+    out, off, cols = eng.stft_mag_db(b.x, b.off + starts, nfr, a.nfft, 512, True, -120.0, a.precision, frame_major=a.tf)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.iters
 L = n - 300
