@@ -67,6 +67,8 @@ PROTOTYPES = {
     "ira_ar_gram": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp, i32, vp]),
     "ira_ar_solve": (i32, [vp, vp, i32, i32, i32, f64, vp, vp, vp, i32, vp]),
     "ira_ar_minnorm": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, f64, vp]),
+    "ira_ar_exact_doubles": (C.c_int64, [i32, i32, i32]),
+    "ira_ar_exact": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f64, vp, vp, vp, vp, vp, f64, vp]),
     "ira_ar_refine": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, f64, i32, i32, vp]),
     "ira_ar_fit": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, f64, vp, vp, vp, vp, i32, vp]),
     "ira_poly_roots": (i32, [vp, i32, i32, f64, vp, vp, vp]),

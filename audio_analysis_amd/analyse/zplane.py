@@ -127,7 +127,7 @@ def analyse_zplane_batch(
     """Numeric body of the reference's plot function for a whole batch of channels."""
     eng = get_engine()
     batch = eng.upload(list(channels))
-    poles, zeros, status = zplane_device(eng, batch, sample_rate_hz, settings, with_status=True)
+    poles, zeros, status, _ = zplane_device(eng, batch, sample_rate_hz, settings, with_status=True)
     _raise_if_not_finite(status)
     return [ChannelZPlaneResult(channel_name=name, sample_rate_hz=sample_rate_hz, poles=poles[i],
                                 zeros=zeros[i] if settings.derive_zeros else None)
@@ -138,8 +138,9 @@ def zplane_device(eng, batch, sample_rate_hz: int, settings: ZPlaneAnalysisSetti
                   with_status: bool = False):
     """AR fit + roots for a device-resident batch; returns host lists (poles, zeros) of complex128 arrays
     (or, with defer=True, a zero-argument callable producing them after all launches have been enqueued).
-    with_status adds the per-channel solver status (ira_ar_solve / ira_ar_minnorm info[0]: 0 solved, 2 refined, 4 minimum
-    norm over a rank-deficient Gram matrix, 3 not finite -- the reference's lstsq raises LinAlgError there)."""
+    with_status adds the per-channel solver status (info[0] of ira_ar_solve and its followers: 0 solved, 2 refined, 5 solved
+    by the double-double normal equations, 4 minimum norm over a rank-deficient Gram matrix, 3 not finite -- the reference's
+    lstsq raises LinAlgError there) and the condition estimate of the float64 Gram matrix (info[3]; for status 4 the rank)."""
     nch = batch.count
     peaks = eng.peaks(batch) if settings.trim_to_peak else np.zeros(nch, dtype=np.int64)
     skip = int(round(float(settings.ignore_leading_seconds) * sample_rate_hz))
@@ -190,6 +191,7 @@ def zplane_device(eng, batch, sample_rate_hz: int, settings: ZPlaneAnalysisSetti
         pending.append((idx, roots, cnt, zr, zc, info))
 
     status = np.zeros(nch, dtype=np.float64)
+    cond = np.full(nch, np.nan, dtype=np.float64)
 
     def finish():
         for idx, roots, cnt, zr, zc, info in pending:
@@ -200,11 +202,12 @@ def zplane_device(eng, batch, sample_rate_hz: int, settings: ZPlaneAnalysisSetti
                     zeros[k] = r
             st = info.get() if hasattr(info, "get") else info.cpu().numpy()
             status[idx] = st[:, 0]
+            cond[idx] = st[:, 3]
             for k in idx[st[:, 0] == AR_STATUS_NOT_FINITE]:
                 poles[k] = np.array([], dtype=np.complex128)       # no fit: the reference raises for this channel
                 if zeros[k] is not None:
                     zeros[k] = np.array([], dtype=np.complex128)
-        return (poles, zeros, status) if with_status else (poles, zeros)
+        return (poles, zeros, status, cond) if with_status else (poles, zeros)
 
     return finish if defer else finish()
 

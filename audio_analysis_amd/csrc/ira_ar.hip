@@ -310,7 +310,8 @@ __global__ __launch_bounds__(LAG_THREADS) void ar_lag_kernel(const float* __rest
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool ar_needs_refinement(const double* info, int e, double cond_threshold) {
   const double status = info[IRA_AR_INFO_DOUBLES * e + 0];
-  if (status == 1.0) return false;                                     // no factorisation to refine with
+  if (status != 0.0 && status != 2.0) return false;                    // no float64 factorisation to refine with (1, 3, 4), or
+                                                                       // already solved in double-double (5)
   return info[IRA_AR_INFO_DOUBLES * e + 3] > cond_threshold;            // trace(G) * ||G^-1|| estimate
 }
 
@@ -573,6 +574,208 @@ __global__ __launch_bounds__(SV_THREADS) void ar_solve_kernel(const double* __re
     info[IRA_AR_INFO_DOUBLES * e + 2] = dmin;
     info[IRA_AR_INFO_DOUBLES * e + 3] = cond_est;
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Ill-conditioned fits: the normal equations in DOUBLE-DOUBLE arithmetic (~32 significant digits).
+// The reference solves min ||A a + y|| by SVD (numpy.linalg.lstsq, zplane.py:117), accurate to ~cond(A) eps.  float64 normal
+// equations lose cond(A)^2 eps: the corrected-semi-normal-equation steps of ira_ar_refine recover lstsq's accuracy while
+// cond(G) eps < 1 (cond(G) <~ 1e12 in practice); beyond that the float64 Cholesky factor itself is noise.  A float32 recording
+// low-passed at 500 Hz has cond(A) ~ 3e8, cond(G) ~ 1e17 (tests/golden/ar_illcond.npz, SURVEY.md section 7 hard part 1): its
+// float64 normal equations are off by 35 % in the coefficients.  But G = A^T A is made of sums of products of the samples,
+// and those can be formed EXACTLY: a product of two float64 values is hi + lo by one fma, and a double-double accumulator
+// keeps ~106 bits.  With G and r good to 1e-30 and the Cholesky factorisation and the two triangular solves carried in the
+// same arithmetic, the solution is good to cond(G) x 1e-32 -- an exact rational solve of that golden case agrees with it to
+// 1e-15 and with the reference's lstsq to 2e-9 (pole radii 4e-8).  Only flagged elements (Cholesky pivot not positive, or
+// the cond(G) estimate above the threshold) do any work: a rare path, written for clarity.
+//   ar_lag_dd_kernel    grid (chunks of LAG_CHUNK rows, 1, nb): p+1 lag sums of the chunk, one or more lags per thread
+//   ar_solve_dd_kernel  one workgroup per element: G from the lag sums by the same diagonal walk as ar_solve_kernel (exact
+//                       products of head / tail samples), Cholesky + solves in global scratch (p^2 double-doubles).
+// A pivot that is not positive RELATIVE to the trace (1e-26) means G is singular to working precision -- the element keeps
+// status 1 and ira_ar_minnorm returns lstsq's minimum-norm solution as before.
+// ------------------------------------------------------------------------------------------------------------
+struct dd { double hi, lo; };
+// `#pragma clang fp contract(off)` in every routine: this file is compiled with fused multiply-add contraction on, and a
+// product that gets fused into the addition of an error-free transformation (s = a + b*c computed as ONE fma while the error
+// term assumes s = fl(a + fl(b*c))) silently turns double-double into plain float64 -- seen as a 6e-8 instead of 1e-15
+// agreement with an exact rational solve.
+__device__ __forceinline__ dd dd_two_sum(double a, double b) {
+#pragma clang fp contract(off)
+  const double s = a + b, bb = s - a;
+  return {s, (a - (s - bb)) + (b - bb)};
+}
+__device__ __forceinline__ dd dd_fast_two_sum(double a, double b) {      // |a| >= |b|
+#pragma clang fp contract(off)
+  const double s = a + b;
+  return {s, b - (s - a)};
+}
+__device__ __forceinline__ dd dd_two_prod(double a, double b) {
+#pragma clang fp contract(off)
+  const double p = a * b;
+  return {p, fma(a, b, -p)};
+}
+__device__ __forceinline__ dd dd_add(dd x, dd y) {
+#pragma clang fp contract(off)
+  const dd s = dd_two_sum(x.hi, y.hi);
+  const dd t = dd_two_sum(x.lo, y.lo);
+  const dd u = dd_fast_two_sum(s.hi, s.lo + t.hi);
+  return dd_fast_two_sum(u.hi, u.lo + t.lo);
+}
+__device__ __forceinline__ dd dd_neg(dd x) { return {-x.hi, -x.lo}; }
+__device__ __forceinline__ dd dd_mul(dd x, dd y) {
+#pragma clang fp contract(off)
+  dd p = dd_two_prod(x.hi, y.hi);
+  p.lo += x.hi * y.lo + x.lo * y.hi;
+  return dd_fast_two_sum(p.hi, p.lo);
+}
+__device__ __forceinline__ dd dd_div(dd x, dd y) {
+#pragma clang fp contract(off)
+  const double q1 = x.hi / y.hi;
+  dd r = dd_add(x, dd_neg(dd_mul(y, dd{q1, 0.0})));
+  const double q2 = r.hi / y.hi;
+  r = dd_add(r, dd_neg(dd_mul(y, dd{q2, 0.0})));
+  const double q3 = r.hi / y.hi;
+  const dd q = dd_fast_two_sum(q1, q2);
+  return dd_add(q, dd{q3, 0.0});
+}
+__device__ __forceinline__ dd dd_sqrt(dd x) {                            // x > 0
+#pragma clang fp contract(off)
+  const double s = sqrt(x.hi);
+  const dd r = dd_add(x, dd_neg(dd_two_prod(s, s)));
+  return dd_fast_two_sum(s, r.hi / (2.0 * s));
+}
+
+constexpr double AR_DD_SOLVED = 5.0;          // info[0]: solved by the double-double normal equations
+__device__ __forceinline__ bool ar_needs_dd(const double* info, int e, double cond_threshold) {
+  const double status = info[IRA_AR_INFO_DOUBLES * e + 0];
+  if (status == 1.0) return true;                                      // the float64 factorisation broke down
+  if (status != 0.0) return false;                                     // not finite / already handled
+  return !(info[IRA_AR_INFO_DOUBLES * e + 3] <= cond_threshold);        // estimate above the threshold (or NaN)
+}
+
+__global__ __launch_bounds__(LAG_THREADS) void ar_lag_dd_kernel(const float* __restrict__ x, const double* __restrict__ x64,
+                                                                const int64_t* __restrict__ xoff,
+                                                                const int32_t* __restrict__ nlen,
+                                                                const double* __restrict__ divisor, int p, int nchunks_max,
+                                                                const double* __restrict__ info, double cond_threshold,
+                                                                double* __restrict__ ddpart) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int e = blockIdx.z, chunk = blockIdx.x;
+  if (!ar_needs_dd(info, e, cond_threshold)) return;
+  const long long N = nlen[e];
+  const long long row0 = (long long)p + (long long)chunk * LAG_CHUNK;
+  if (row0 >= N) return;
+  const long long n_end = (row0 + LAG_CHUNK < N) ? row0 + LAG_CHUNK : N;
+  const int rows = (int)(n_end - row0);
+  double* lds = reinterpret_cast<double*>(smem_raw);                   // samples row0 - p .. n_end - 1
+  const float* xs = x ? x + xoff[e] : nullptr;
+  const double* xd = x64 ? x64 + xoff[e] : nullptr;
+  const double div = divisor ? divisor[e] : 1.0;
+  const int tid = threadIdx.x;
+  for (int m = tid; m < p + rows; m += LAG_THREADS) {
+    const long long idx = row0 - p + m;                                // >= 0
+    lds[m] = (xd ? xd[idx] : (double)xs[idx]) / div;                   // the same rounded values every other AR kernel uses
+  }
+  __syncthreads();
+  double* out = ddpart + (((long long)e * nchunks_max + chunk) * (p + 1)) * 2;
+  for (int l = tid; l <= p; l += LAG_THREADS) {
+    dd acc = {0.0, 0.0};
+    const double* cur = lds + p;                                       // s[n]
+    const double* lag = lds + p - l;                                   // s[n - l]
+    for (int r = 0; r < rows; ++r) {
+      const dd pr = dd_two_prod(cur[r], lag[r]);
+      const dd s1 = dd_two_sum(acc.hi, pr.hi);
+      acc = dd_fast_two_sum(s1.hi, s1.lo + (acc.lo + pr.lo));
+    }
+    out[2 * l] = acc.hi;
+    out[2 * l + 1] = acc.lo;
+  }
+}
+
+__global__ __launch_bounds__(SV_THREADS) void ar_solve_dd_kernel(const double* __restrict__ part,
+                                                                 const double* __restrict__ ddpart,
+                                                                 const int32_t* __restrict__ nlen, int p, double ridge,
+                                                                 double* __restrict__ ddscratch,
+                                                                 double* __restrict__ coeffs, double* __restrict__ info,
+                                                                 int lag_nchunks_max, long long lag_rec_doubles,
+                                                                 double cond_threshold) {
+  __shared__ dd piv_s, trace_s;
+  __shared__ int fail;
+  const int e = blockIdx.x, tid = threadIdx.x;
+  if (!ar_needs_dd(info, e, cond_threshold)) return;
+  const long long N = nlen[e];
+  const int nlag = p + 1;
+  const double* rec = part + (long long)e * lag_rec_doubles;
+  const double* head = rec + (long long)lag_nchunks_max * nlag;
+  const double* tail = head + nlag;
+  const double* pe = ddpart + ((long long)e * lag_nchunks_max * nlag) * 2;
+  const int lchunks = lag_chunks(N, p);
+  dd* G = reinterpret_cast<dd*>(ddscratch + (long long)e * 2 * ((long long)p * p + p));   // p x p, then the vector
+  dd* vec = G + (long long)p * p;
+  for (int d = tid; d < nlag; d += SV_THREADS) {
+    dd c = {0.0, 0.0};
+    for (int ch = 0; ch < lchunks; ++ch) c = dd_add(c, dd{pe[((long long)ch * nlag + d) * 2], pe[((long long)ch * nlag + d) * 2 + 1]});
+    if (d >= 1) vec[d - 1] = dd_neg(c);                                  // r = -Phi[0][d]
+    dd run = c;
+    for (int a = 1; a + d <= p; ++a) {                                   // Phi[a][a+d], see ar_solve_kernel
+      const int m = a - 1;
+      run = dd_add(run, dd_two_prod(head[p - 1 - m], head[p - 1 - m - d]));
+      run = dd_add(run, dd_neg(dd_two_prod(tail[m], tail[m + d])));
+      dd v = run;
+      if (d == 0) v = dd_add(v, dd{ridge, 0.0});
+      const int r = a + d - 1, cidx = a - 1;
+      G[(long long)r * p + cidx] = v;
+      G[(long long)cidx * p + r] = v;
+    }
+  }
+  if (tid == 0) fail = 0;
+  __syncthreads();
+  if (tid == 0) {
+    dd tr = {0.0, 0.0};
+    for (int k = 0; k < p; ++k) tr = dd_add(tr, G[(long long)k * p + k]);
+    trace_s = tr;
+  }
+  __syncthreads();
+  const double tiny = 1e-26 * trace_s.hi;
+  for (int k = 0; k < p; ++k) {
+    if (tid == 0) {
+      const dd d = G[(long long)k * p + k];
+      if (!(d.hi > tiny)) { fail = 1; piv_s = dd{1.0, 0.0}; }
+      else piv_s = dd_sqrt(d);
+    }
+    __syncthreads();
+    const dd d = piv_s;
+    for (int i = k + tid; i < p; i += SV_THREADS)
+      G[(long long)i * p + k] = (i == k) ? d : dd_div(G[(long long)i * p + k], d);
+    __syncthreads();
+    const int m = p - k - 1;
+    for (int idx = tid; idx < m * m; idx += SV_THREADS) {
+      const int ii = idx / m, jj = idx - ii * m;
+      if (jj > ii) continue;
+      const int i = k + 1 + ii, j = k + 1 + jj;
+      G[(long long)i * p + j] = dd_add(G[(long long)i * p + j], dd_neg(dd_mul(G[(long long)i * p + k], G[(long long)j * p + k])));
+    }
+    __syncthreads();
+  }
+  if (fail) return;                                     // singular to ~1e-26: status stays 1 -> ira_ar_minnorm
+  for (int k = 0; k < p; ++k) {                         // L y = r
+    if (tid == 0) vec[k] = dd_div(vec[k], G[(long long)k * p + k]);
+    __syncthreads();
+    const dd yk = vec[k];
+    for (int i = k + 1 + tid; i < p; i += SV_THREADS) vec[i] = dd_add(vec[i], dd_neg(dd_mul(G[(long long)i * p + k], yk)));
+    __syncthreads();
+  }
+  for (int k = p - 1; k >= 0; --k) {                    // L^T a = y
+    if (tid == 0) vec[k] = dd_div(vec[k], G[(long long)k * p + k]);
+    __syncthreads();
+    const dd ak = vec[k];
+    for (int i = tid; i < k; i += SV_THREADS) vec[i] = dd_add(vec[i], dd_neg(dd_mul(G[(long long)k * p + i], ak)));
+    __syncthreads();
+  }
+  double* co = coeffs + (long long)e * (p + 1);
+  if (tid == 0) co[0] = 1.0;
+  for (int j = tid; j < p; j += SV_THREADS) co[j + 1] = vec[j].hi + vec[j].lo;
+  if (tid == 0) info[IRA_AR_INFO_DOUBLES * e + 0] = AR_DD_SOLVED;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -973,6 +1176,35 @@ extern "C" int32_t ira_ar_minnorm(const double* partial_dev, const int32_t* len_
   ar_minnorm_kernel<<<nb, SV_THREADS, 0, (hipStream_t)stream>>>(partial_dev, len_dev, order, scratch2_dev, coeffs_dev,
                                                                  info_dev, lag_chunks(max_len, order),
                                                                  lag_record_doubles(max_len, order), rel_cut);
+  IRA_RETURN_LAUNCH();
+}
+
+
+extern "C" int64_t ira_ar_exact_doubles(int32_t order, int32_t max_len, int32_t which) {
+  if (order < 1 || order > GR_MAX_P || max_len <= order) return 0;
+  if (which == 0) return 2ll * lag_chunks(max_len, order) * (order + 1);          // double-double lag-sum partials
+  return 2ll * ((int64_t)order * order + order);                                    // Gram matrix + vector
+}
+
+extern "C" int32_t ira_ar_exact(const float* x_dev, const double* x64_dev, const int64_t* xoff_dev, const int32_t* len_dev,
+                                const double* divisor_dev, int32_t nb, int32_t max_len, int32_t order, double ridge,
+                                const double* partial_dev, double* ddpartial_dev, double* ddscratch_dev,
+                                double* coeffs_dev, double* info_dev, double cond_threshold, void* stream) {
+  if (x_dev == nullptr && x64_dev == nullptr) return IRA_E_NULL;
+  IRA_CHECK_PTR(xoff_dev); IRA_CHECK_PTR(len_dev); IRA_CHECK_PTR(partial_dev); IRA_CHECK_PTR(ddpartial_dev);
+  IRA_CHECK_PTR(ddscratch_dev); IRA_CHECK_PTR(coeffs_dev); IRA_CHECK_PTR(info_dev);
+  const int32_t rc = ar_check(nb, max_len, order);
+  if (rc != IRA_OK || nb == 0) return rc;
+  if (!(cond_threshold >= 1.0) || !(ridge >= 0.0)) return IRA_E_SIZE;
+  const int lchunks = lag_chunks(max_len, order);
+  const size_t lds = sizeof(double) * ((size_t)order + LAG_CHUNK);
+  if (lds > 64 * 1024) return IRA_E_SIZE;
+  hipStream_t st = (hipStream_t)stream;
+  ar_lag_dd_kernel<<<dim3(lchunks, 1, nb), LAG_THREADS, lds, st>>>(x64_dev ? nullptr : x_dev, x64_dev, xoff_dev, len_dev,
+                                                                   divisor_dev, order, lchunks, info_dev, cond_threshold,
+                                                                   ddpartial_dev);
+  ar_solve_dd_kernel<<<nb, SV_THREADS, 0, st>>>(partial_dev, ddpartial_dev, len_dev, order, ridge, ddscratch_dev, coeffs_dev,
+                                                info_dev, lchunks, lag_record_doubles(max_len, order), cond_threshold);
   IRA_RETURN_LAUNCH();
 }
 

@@ -39,10 +39,12 @@ static_assert(EXC4 >= 8 * E2N4 && EXC4 * 2 >= M4, "exchange buffer too small");
 
 __device__ __forceinline__ float db_of4(double re, double im, double floor_pow, float floor_db,
                                         const ira::LogTabEntry* tab) {
+  // |X| <= 8192 * max|x| < 3e42 for float32 samples, so p < 1e85 is always a normal double unless the frame holds an
+  // infinity or a NaN -- and those frames are flagged as a whole (bad_frame) and never reach this value.  (Round 2 carried
+  // a hypot + log10 path for p >= 1e300 here: dead for this kernel's inputs, and 40 % of its code size.)
   const double p = fma(re, re, im * im);
   if (!(p > floor_pow)) return floor_db;                                       // also catches NaN
-  if (!(p < 1.0e300)) return (float)(20.0 * log10(hypot(re, im)));             // overflow / infinity: slow exact path
-  return (float)(3.0102999566398120 * ira::log2_table(p, tab));
+  return (float)(3.0102999566398120 * ira::log2_table<4>(p, tab));
 }
 
 // Linear magnitude the reference's aggregation starts from: 10^(float32(dB)/20) with dB = 20 log10 max(|X|, floor)
@@ -53,18 +55,15 @@ __device__ __forceinline__ double lin_of4(double re, double im, double floor_pow
                                           const ira::LogTabEntry* tab) {
   const double p = fma(re, re, im * im);
   if (!(p > floor_pow)) return floor_lin32;                                    // also catches NaN, like db_of4
-  if (!(p < 1.0e300)) return exp10((double)(float)(20.0 * log10(hypot(re, im))) * 0.05);
-  const double db = 3.0102999566398120 * ira::log2_table(p, tab);
+  const double db = 3.0102999566398120 * ira::log2_table<4>(p, tab);           // (p < 1e85: see db_of4)
   const double t = ((double)(float)db - db) * 0.11512925464970228;
-  // sqrt(p) for a normal p (floor_pow < p < 1e300: no scaling needed): hardware reciprocal square root (~26 bits) and two
-  // coupled Newton steps (Goldschmidt form), ~2e-16 relative -- 9 instructions instead of the ~25 of the library sqrt,
-  // whose denormal / special-case handling this range never needs.  (This conversion is 16 of every lane's values and was
-  // more than half of the kernel's VALU work: profiles/r02_stft4_counters.txt.)
+  // sqrt(p) for a normal p (floor_pow < p < 1e85: no scaling needed): hardware reciprocal square root (~26 bits) and ONE
+  // coupled Newton step (Goldschmidt form): relative error 1.5 e0^2 ~ 3e-16 -- the mean of these values is rounded to a
+  // float32 dB value, 1e-12 would do (round 2 ran two steps).  6 instructions instead of the ~25 of the library sqrt.
   const double y0 = __builtin_amdgcn_rsq(p);
-  double g = p * y0, h = 0.5 * y0;
-  double r = fma(-h, g, 0.5);
-  g = fma(g, r, g); h = fma(h, r, h);
-  r = fma(-h, g, 0.5);
+  double g = p * y0;
+  const double h = 0.5 * y0;
+  const double r = fma(-h, g, 0.5);
   g = fma(g, r, g);
   return g * fma(t, fma(t, 0.5, 1.0), 1.0);
 }

@@ -50,7 +50,7 @@ class _TimedLib:
     bracketed by two HIP events recorded on the SAME stream the kernels are enqueued on, so per-call device
     time can be read back after a synchronise (bench.py's roofline uses this).
     """
-    _PLAIN = {"ira_error_string", "ira_abi_version", "ira_ar_partial_doubles"}
+    _PLAIN = {"ira_error_string", "ira_abi_version", "ira_ar_partial_doubles", "ira_ar_exact_doubles"}
 
     def __init__(self, lib, eng):
         self._lib, self._eng, self._cache = lib, eng, {}
@@ -1083,6 +1083,15 @@ class Engine:
               "ira_ar_gram")
         check(self.lib.ira_ar_solve(_ptr(part), _ptr(d_l), n, max_len, int(order), float(ridge), _ptr(gs),
                                     _ptr(coeffs), _ptr(info), flags, self.stream), "ira_ar_solve")
+        if self.ar_exact_cond > 0.0 and not self.ar_dense_gram:
+            # conditional on the device: only elements whose float64 Cholesky broke down or whose condition estimate says
+            # cond(G) eps is no longer small are solved again, in double-double arithmetic (ira_ar_exact)
+            ddp = self.empty(n * int(self.lib.ira_ar_exact_doubles(int(order), max_len, 0)), t.float64)
+            dds = self.empty(n * int(self.lib.ira_ar_exact_doubles(int(order), max_len, 1)), t.float64)
+            check(self.lib.ira_ar_exact(0 if x_is_f64 else _ptr(x_dev), _ptr(x_dev) if x_is_f64 else 0, _ptr(d_xo),
+                                        _ptr(d_l), _ptr(d_div), n, max_len, int(order), float(ridge), _ptr(part), _ptr(ddp),
+                                        _ptr(dds), _ptr(coeffs), _ptr(info), float(self.ar_exact_cond), self.stream),
+                  "ira_ar_exact")
         if ridge == 0.0 and order <= 512 and self.ar_minnorm_cut > 0.0 and not self.ar_dense_gram:
             # conditional on the device: only elements whose Cholesky failed (rank-deficient Gram matrix) do any work
             scratch2 = self.empty(n * 2 * order * order, t.float64)
@@ -1106,6 +1115,9 @@ class Engine:
     ar_dense_gram = False
     ar_refine_cond = 1e9          # on the estimate trace(G) ||G^-1|| (<= order * cond(G))
     ar_refine_steps = 2
+    # Above this estimate (or when the float64 Cholesky breaks down) the normal equations are solved again in double-double
+    # arithmetic (ira_ar_exact): refinement needs cond(G) eps << 1.  0 disables the path (A/B).
+    ar_exact_cond = 1e13
 
     def poly_roots(self, coeffs_dev, npoly: int, ncoef: int, trail_eps: float = 1e-14):
         """Roots (npoly, ncoef-1, 2) float64 device + counts int32 device."""

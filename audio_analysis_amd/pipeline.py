@@ -41,6 +41,11 @@ M_AR_POLES, M_AR_MAX_R, M_AR_MEDIAN_R, M_AR_UNSTABLE = 117, 118, 119, 120
 M_NBANDS = 121
 M_GD_MEDIAN, M_GD_P10, M_GD_P90 = 122, 123, 124        # section 8f blocks (off by default)
 M_DIFF_AC_MEDIAN, M_DIFF_ED_MEDIAN = 125, 126
+# How far to trust the pole fit: the solver's condition estimate of the float64 Gram matrix A^T A (between cond and
+# order x cond).  <= 1e9: plain normal equations; <= 1e13: refined (corrected semi-normal equations); above: solved in
+# double-double arithmetic (engine.Engine.ar_exact_cond) -- all three agree with the reference's SVD-based lstsq to 1e-8.
+# NaN: no AR block, or a rank-deficient / non-finite fit.
+M_AR_COND = 127
 METRICS_WIDTH = 128
 
 # ---- per-IR status (M_STATUS): 0 = analysed; otherwise the bit of the FIRST report block, in the reference's block order
@@ -354,7 +359,8 @@ class FullReport:
             if nb:
                 m[:, M_BANDS : M_BANDS + 3 * nb] = values[:, :nb, :].reshape(n, 3 * nb)
         if s.run_zplane:
-            poles, _, ar_status = res["zplane"]["finish"]()
+            poles, _, ar_status, ar_cond = res["zplane"]["finish"]()
+            m[:, M_AR_COND] = np.where(ar_status == 4.0, np.nan, ar_cond)      # status 4: info[3] holds the rank instead
             not_finite = ar_status == _zp.AR_STATUS_NOT_FINITE
             m[not_finite & (m[:, M_STATUS] == 0.0), M_STATUS] = float(ST_ZPLANE_NOT_FINITE)
             sizes = np.array([p.size for p in poles])

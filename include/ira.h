@@ -286,7 +286,8 @@ int32_t ira_log_smooth_db(float* mag_dev, const int64_t* off_dev, const int32_t*
  * partial_dev: nb * ira_ar_partial_doubles(order, max_len) doubles of scratch; gscratch_dev: nb*order*order
  * doubles, only needed when order > 128; info_dev (optional): IRA_AR_INFO_DOUBLES doubles per element
  * [0] status: 0 solved, 1 a Cholesky pivot was not positive, 2 solved and refined (ira_ar_refine), 3 not finite,
- * 4 rank-deficient: minimum-norm solution (ira_ar_minnorm, which then redefines [1..3]), [1] largest,
+ * 4 rank-deficient: minimum-norm solution (ira_ar_minnorm, which then redefines [1..3]), 5 solved by the double-double
+ * normal equations (ira_ar_exact), [1] largest,
  * [2] smallest pivot, [3] condition estimate trace(G) * ||G^-1|| (two inverse iterations on the factor; between
  * cond(G) and order * cond(G)).  1 <= order <= 1024 < len. */
 #define IRA_AR_INFO_DOUBLES 4
@@ -312,6 +313,21 @@ int32_t ira_ar_solve(const double* partial_dev, const int32_t* len_dev, int32_t 
  * info buffers, before ira_ar_refine. */
 int32_t ira_ar_minnorm(const double* partial_dev, const int32_t* len_dev, int32_t nb, int32_t max_len, int32_t order,
                        double* scratch2_dev, double* coeffs_dev, double* info_dev, double rel_cut, void* stream);
+/* Ill-conditioned fits beyond the reach of refinement: elements whose float64 Cholesky broke down (status 1) or whose
+ * condition estimate info[3] exceeds cond_threshold (1e13: cond(G) eps is no longer small) are solved again with the normal
+ * equations carried in DOUBLE-DOUBLE arithmetic: the p+1 lag sums accumulated from exact products of the samples (two_prod +
+ * compensated sums, ~106 bits), G assembled from them, Cholesky and both triangular solves in the same arithmetic.  The
+ * result is good to cond(G) x 1e-32 -- better than the reference's SVD-based lstsq (zplane.py:117, ~cond(A) eps), with
+ * which it agrees to 2e-9 on tests/golden/ar_illcond.npz (500 Hz low-passed float32 response, cond(G) ~ 1e17, where the
+ * float64 normal equations are off by 35 %).  info[0] becomes 5; a Gram matrix singular to 1e-26 of its trace keeps status
+ * 1 for ira_ar_minnorm.  Runs after ira_ar_solve, before ira_ar_minnorm / ira_ar_refine, on the same partial / coeffs / info
+ * buffers (lag-sum record only: not with IRA_AR_DENSE_GRAM).  ddpartial_dev: nb * ira_ar_exact_doubles(order, max_len, 0)
+ * doubles, ddscratch_dev: nb * ira_ar_exact_doubles(order, max_len, 1).  Unflagged elements cost nothing but the launches. */
+int64_t ira_ar_exact_doubles(int32_t order, int32_t max_len, int32_t which);
+int32_t ira_ar_exact(const float* x_dev, const double* x64_dev, const int64_t* xoff_dev, const int32_t* len_dev,
+                     const double* divisor_dev, int32_t nb, int32_t max_len, int32_t order, double ridge,
+                     const double* partial_dev, double* ddpartial_dev, double* ddscratch_dev, double* coeffs_dev,
+                     double* info_dev, double cond_threshold, void* stream);
 /* Iterative refinement for ill-conditioned fits (ridge = 0 only).  The reference's SVD-based lstsq is accurate to about
  * cond(A) eps, the normal equations only to cond(A)^2 eps = cond(G) eps; elements whose condition estimate
  * info[3] > cond_threshold get `steps` (1..4) rounds of  a += G^-1 A^T (y - A a)  with the residual and

@@ -1,4 +1,6 @@
 """GPU parity: AR least squares (MFMA Gram + Cholesky), Aberth roots, FIR numerator vs golden vectors."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -210,14 +212,19 @@ def test_rank_deficient_fits_return_the_minimum_norm_solution():
             ref = O.fit_ar(x.astype(np.float64), order)
             scale = max(1.0, float(np.abs(ref).max()))
             assert np.abs(co[i] - ref).max() <= 1e-8 * scale, (order, i, np.abs(co[i] - ref).max())
-    # the AR(2) sequence at order 8: lstsq keeps directions down to 1e-10 of sigma_max, the eigen cut sits at 1e-6 of it;
-    # the two POLES of the generating recursion must come out either way
+    # the AR(2) sequence at order 8: rank 2 plus float32 rounding dust (singular values 3, 1.9, then six around 1e-8).
+    # lstsq keeps every direction down to 1e-10 of sigma_max, so the REFERENCE fits the dust too and returns six more
+    # poles, four of them outside the generating pair.  Round 2's eigenvalue cut dropped those directions (and returned
+    # only the generating poles on top); the double-double normal equations keep them like lstsq: all eight radii agree.
     b2 = eng.upload([ar2])
     co, info = eng.ar_fit(b2.x, b2.off, b2.length.astype(np.int32), None, 8)
+    assert info.cpu().numpy()[0, 0] == 5.0
     roots, cnt = eng.poly_roots(co, 1, 9, 1e-14)
     r = roots.cpu().numpy()[0, : int(cnt.cpu().numpy()[0])]
     rad = np.sort(np.hypot(r[:, 0], r[:, 1]))[::-1]
-    assert abs(rad[0] - np.sqrt(0.72)) < 1e-6 and abs(rad[1] - np.sqrt(0.72)) < 1e-6, rad
+    rad_ref = np.sort(np.abs(np.roots(O.fit_ar(ar2.astype(np.float64), 8))))[::-1]
+    assert rad.size == 8 and np.max(np.abs(rad - rad_ref) / rad_ref) < 1e-6, (rad, rad_ref)
+    assert np.sum(np.abs(rad - np.sqrt(0.72)) < 1e-6) == 2                  # the generating pair is among them
     # NaN input: the reference's lstsq raises LinAlgError; the batch API reports status 3, the drop-in function raises
     bad = good.copy(); bad[100] = np.nan
     b3 = eng.upload([bad, good])
@@ -227,3 +234,69 @@ def test_rank_deficient_fits_return_the_minimum_norm_solution():
     from audio_analysis_amd.analyse import zplane
     with pytest.raises(np.linalg.LinAlgError):
         zplane._fit_ar_least_squares(bad.astype(np.float64), 16)
+
+
+def _match_poles(got, ref):
+    """Greedy nearest-neighbour matching of two pole sets (numpy.roots' order is unspecified): max |got - ref| over pairs."""
+    got = list(got)
+    worst = 0.0
+    for r in ref:
+        j = int(np.argmin([abs(g - r) for g in got]))
+        worst = max(worst, abs(got[j] - r))
+        got.pop(j)
+    return worst
+
+
+@pytest.mark.parametrize("tag", ["lp500_p64", "lp500_p256", "lp2k_p64"])
+def test_ill_conditioned_fits_match_the_reference_svd(tag):
+    """SURVEY.md section 7, hard part 1: float32 responses low-passed at 500 Hz / 2 kHz, cond(A) ~ 1e8..4e8, cond(A^T A) ~
+    1e16..1e17 (tests/golden/ar_illcond.npz: the REFERENCE's _fit_ar_least_squares + poles).  float64 normal equations are
+    off by tens of percent there; the double-double path (ira_ar_exact) matches the reference's SVD solve: coefficients 1e-6
+    of the largest one, pole radii 1e-6 relative (north star: 1e-4), every pole matched to 1e-6, same unstable count."""
+    from audio_analysis_amd.analyse import zplane as zp
+    from audio_analysis_amd.engine import get_engine
+    g = np.load(Path(__file__).resolve().parent / "golden" / "ar_illcond.npz")
+    x = g[f"{tag}/x"]
+    order = int(g[f"{tag}/order_rank"][0])
+    assert int(g[f"{tag}/order_rank"][1]) == order                    # lstsq kept every singular value: a full-rank fit
+    ref_a, ref_p = g[f"{tag}/coeffs"], g[f"{tag}/poles"]
+    eng = get_engine()
+    b = eng.upload([x])
+    co, info = eng.ar_fit(b.x, b.off, b.length.astype(np.int32), None, order)
+    a = co.cpu().numpy()[0]
+    info = info.cpu().numpy()[0]
+    assert info[0] == 5.0, info                                        # solved by the double-double normal equations
+    assert np.max(np.abs(a - ref_a)) / np.max(np.abs(ref_a)) < 1e-6
+    r = zp.analyse_zplane_batch([x], 48000, ["m"], zp.ZPlaneAnalysisSettings(ar_order=order, trim_to_peak=False,
+                                                                             normalise_segment=False))[0]
+    assert r.poles.size == ref_p.size
+    rg, rr = np.sort(np.abs(r.poles)), np.sort(np.abs(ref_p))
+    assert np.max(np.abs(rg - rr) / rr) < 1e-6
+    assert _match_poles(r.poles, ref_p) < 1e-6
+    assert int(np.sum(rg >= 1.0)) == int(np.sum(rr >= 1.0))
+    # without the double-double path the same input is visibly wrong (the test has teeth)
+    saved = eng.ar_exact_cond
+    try:
+        eng.ar_exact_cond = 0.0
+        co0, _ = eng.ar_fit(b.x, b.off, b.length.astype(np.int32), None, order)
+    finally:
+        eng.ar_exact_cond = saved
+    a0 = co0.cpu().numpy()[0]
+    assert not (np.max(np.abs(a0 - ref_a)) / np.max(np.abs(ref_a)) < 1e-4)
+
+
+def test_condition_estimate_travels_in_the_metrics_record():
+    """pipeline.M_AR_COND: the caller sees how ill-conditioned every channel's pole fit was (and so which solver ran)."""
+    from dataclasses import replace
+    from audio_analysis_amd import pipeline as P
+    from audio_analysis_amd.engine import get_engine
+    from audio_analysis_amd.synth import synth_ir
+    g = np.load(Path(__file__).resolve().parent / "golden" / "ar_illcond.npz")
+    eng = get_engine()
+    none = replace(P.FullReportSettings(), run_decay=False, run_rt60_bands=False, run_frequency_response=False,
+                   run_filter=False, run_spectrogram=False, run_waterfall=False, run_modal_cloud=False)
+    m = P.FullReport(eng, none).run(eng.upload([synth_ir(5, 0, 24000, rt60_seconds=0.3), g["lp500_p64/x"]]))
+    assert m[0, P.M_AR_COND] < 1e9 < 1e13 < m[1, P.M_AR_COND]
+    assert np.all(m[:, P.M_STATUS] == 0)
+    z = O.analyse_zplane(g["lp500_p64/x"], ar_order=64)
+    assert abs(m[1, P.M_AR_MAX_R] - z["max_radius"]) < 1e-6 * z["max_radius"]
