@@ -53,6 +53,7 @@ PROTOTYPES = {
     "ira_wav_probe": (i32, [C.c_char_p, vp, vp, vp, vp]),
     "ira_wav_read_pcm16": (i32, [C.c_char_p, C.c_int64, C.c_int64, i32, vp]),
     "ira_pcm16_to_channels": (i32, [vp, C.c_int64, i32, i32, vp, vp]),
+    "ira_pcm16_to_channels_jobs": (i32, [vp, vp, vp, vp, vp, vp, i32, C.c_int64, vp, vp]),
     "ira_band_mask_values": (i32, [C.POINTER(f64), f64, C.c_int64, vp, vp]),
     "ira_host_pull": (i32, [vp, C.c_int64, i32, vp, i32, vp]),
     "ira_deconv_divide": (i32, [vp, vp, vp, vp, vp, i32, i32, f64, vp, vp]),

@@ -97,6 +97,43 @@ __global__ __launch_bounds__(PCM_THREADS) void pcm16_kernel(const int16_t* __res
   }
 }
 
+// The same conversion for a whole GROUP of tap files in ONE launch: grid (frame blocks, files), every file described by a
+// row of the job table.  One launch per tap (round 2) cost 32 launches + as many event pairs per 32-tap step -- 1.7 ms of
+// a 6.2 ms step for 46 MB of traffic; one launch over the table is bandwidth-bound.
+constexpr int PCM_PER_THREAD = 4;
+
+__global__ __launch_bounds__(PCM_THREADS) void pcm16_jobs_kernel(const int16_t* __restrict__ pcm, const long long* __restrict__ src_off,
+                                                                 const long long* __restrict__ nframes,
+                                                                 const int32_t* __restrict__ nchannels,
+                                                                 const int32_t* __restrict__ modes,
+                                                                 const long long* __restrict__ dst_off, float* __restrict__ out) {
+  const int f = blockIdx.y;
+  const long long frames = ira::uniform(nframes[f]);
+  const long long i0 = ((long long)blockIdx.x * PCM_THREADS) * PCM_PER_THREAD + threadIdx.x;
+  if ((long long)blockIdx.x * PCM_THREADS * PCM_PER_THREAD >= frames) return;
+  const int channels = ira::uniform(nchannels[f]), mode = ira::uniform(modes[f]);
+  const int16_t* src = pcm + ira::uniform(src_off[f]);
+  float* dst = out + ira::uniform(dst_off[f]);
+#pragma unroll
+  for (int u = 0; u < PCM_PER_THREAD; ++u) {
+    const long long i = i0 + (long long)u * PCM_THREADS;
+    if (i >= frames) break;
+    if (channels == 1) {
+      dst[i] = fminf(fmaxf((float)src[i] / 32768.0f, -1.0f), 1.0f);
+      continue;
+    }
+    const int32_t both = reinterpret_cast<const int32_t*>(src)[i];           // one 4-byte load: L | R << 16
+    const float l = fminf(fmaxf((float)(int16_t)(both & 0xFFFF) / 32768.0f, -1.0f), 1.0f);
+    const float r = fminf(fmaxf((float)(int16_t)(both >> 16) / 32768.0f, -1.0f), 1.0f);
+    if (mode == 1) {
+      dst[i] = 0.5f * (l + r);
+    } else {
+      dst[i] = l;
+      dst[frames + i] = r;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // ira_host_pull: the batch upload as a KERNEL that reads pinned host memory through the PCIe link and writes HBM -- an
 // alternative to hipMemcpyAsync that converts PCM16 while it copies (no int16 staging buffer in HBM) and leaves the copy
@@ -192,6 +229,25 @@ extern "C" int32_t ira_pcm16_to_channels(const int16_t* pcm_dev, int64_t frames,
   const long long blocks = (frames + PCM_THREADS - 1) / PCM_THREADS;
   pcm16_kernel<<<(unsigned)blocks, PCM_THREADS, 0, (hipStream_t)stream>>>(pcm_dev, frames, channels, mono_downmix ? 1 : 0,
                                                                          out_dev);
+  IRA_RETURN_LAUNCH();
+}
+
+extern "C" int32_t ira_pcm16_to_channels_jobs(const int16_t* pcm_dev, const int64_t* src_off_dev, const int64_t* frames_dev,
+                                              const int32_t* channels_dev, const int32_t* mode_dev,
+                                              const int64_t* dst_off_dev, int32_t nfiles, int64_t max_frames, float* out_dev,
+                                              void* stream) {
+  IRA_CHECK_PTR(pcm_dev); IRA_CHECK_PTR(src_off_dev); IRA_CHECK_PTR(frames_dev); IRA_CHECK_PTR(channels_dev);
+  IRA_CHECK_PTR(mode_dev); IRA_CHECK_PTR(dst_off_dev); IRA_CHECK_PTR(out_dev);
+  if (nfiles < 0 || max_frames < 0 || nfiles > 65535) return IRA_E_SIZE;
+  if (nfiles == 0 || max_frames == 0) return IRA_OK;
+  if ((reinterpret_cast<uintptr_t>(pcm_dev) & 3u) != 0) return IRA_E_SIZE;                     // 4-byte frame loads
+  const long long per_block = (long long)PCM_THREADS * PCM_PER_THREAD;
+  const long long blocks = (max_frames + per_block - 1) / per_block;
+  if (blocks > 0x7fffffffll) return IRA_E_SIZE;
+  static_assert(sizeof(long long) == sizeof(int64_t), "job table element size");
+  pcm16_jobs_kernel<<<dim3((unsigned)blocks, (unsigned)nfiles), PCM_THREADS, 0, (hipStream_t)stream>>>(
+      pcm_dev, reinterpret_cast<const long long*>(src_off_dev), reinterpret_cast<const long long*>(frames_dev), channels_dev,
+      mode_dev, reinterpret_cast<const long long*>(dst_off_dev), out_dev);
   IRA_RETURN_LAUNCH();
 }
 

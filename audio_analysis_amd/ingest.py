@@ -203,13 +203,19 @@ class TapSet:
         first_channel = {}
         for k, (i, _) in enumerate(labels):
             first_channel.setdefault(i, k)
-        for i in self._native:
-            info = infos[i]
-            src = int(self._pcm_dev.data_ptr()) + 2 * self._pcm_off[i]
-            dst = int(x.data_ptr()) + 4 * int(off[first_channel[i]])
-            check(eng.lib.ira_pcm16_to_channels(src, info.frames, info.channels,
-                                                1 if (mono and info.channels == 2) else 0, dst, eng.stream),
-                  "ira_pcm16_to_channels")
+        if self._native:
+            # ONE conversion launch for the whole group: a job table instead of a launch (and an event pair) per tap
+            nat = self._native
+            src_off = np.array([self._pcm_off[i] for i in nat], dtype=np.int64)
+            frames = np.array([infos[i].frames for i in nat], dtype=np.int64)
+            chans = np.array([infos[i].channels for i in nat], dtype=np.int32)
+            modes = np.array([1 if (mono and infos[i].channels == 2) else 0 for i in nat], dtype=np.int32)
+            dst_off = np.array([int(off[first_channel[i]]) for i in nat], dtype=np.int64)
+            d_src, d_fr, d_ch, d_mo, d_dst = eng.to_dev_pack(src_off, frames, chans, modes, dst_off)
+            check(eng.lib.ira_pcm16_to_channels_jobs(int(self._pcm_dev.data_ptr()), int(d_src.data_ptr()),
+                                                     int(d_fr.data_ptr()), int(d_ch.data_ptr()), int(d_mo.data_ptr()),
+                                                     int(d_dst.data_ptr()), len(nat), int(frames.max()),
+                                                     int(x.data_ptr()), eng.stream), "ira_pcm16_to_channels_jobs")
         if self._pcm_dev is not None:
             self._pcm_dev.record_stream(t.cuda.current_stream(eng.device))
         for i, info in enumerate(infos):

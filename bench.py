@@ -18,7 +18,7 @@ stream under the kernels of batch k (audio_analysis_amd.feed).  Weak scaling: B 
   --config 3   third-octave rt60bands + waterfall on 10 s IRs, B = 256 per step (16 steps = the config's 4096 IRs)
   --config 4   zplane AR(64) + modal cloud on 10 s IRs, B = 256 per step (8 steps = 2048 IRs = one GPU's shard of 16384)
   --config 5   bundle: stereo 5 s PCM16 taps from files through bundle.run_bundle_metrics (native ingest, int16 upload,
-               full pipeline), 32 taps per step
+               full pipeline), 128 taps per step
 
 Rank 0 prints ONE JSON line:
   "value"           H2D-inclusive throughput, float32 upload (what section 8d defines)
@@ -44,7 +44,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 # transfers and format conversion of the ingest: reported in device_ms_per_step_by_call, never the "dominant kernel"
-INGEST_CALLS = ("ira_host_pull", "ira_pcm16_to_channels")
+INGEST_CALLS = ("ira_host_pull", "ira_pcm16_to_channels", "ira_pcm16_to_channels_jobs")
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 F64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak (FMA counted as two flops)
 
@@ -178,7 +178,9 @@ def config_table():
                   metric="IRs/sec zplane AR(64) + modalcloud, 48 kHz 10 s IR (BASELINE config 4)",
                   what="zplane AR(order 64) pole fit + modal cloud 8192/512; 8 steps of 256 = one GPU's 2048-IR shard of 16384",
                   excluded=["png rendering"]),
-        "5": dict(settings=full, batch=32, seconds=5.0, steps=20, cpu_s=1.4,
+        # 128 taps (256 channels) per step: the host side (probe + read + ~150 launches per step) is what binds this
+        # configuration; measured 32 / 64 / 128 taps per step: 3.5 / 4.0 / 4.6 k taps/s
+        "5": dict(settings=full, batch=128, seconds=5.0, steps=8, cpu_s=1.4,
                   metric="stereo taps/sec bundle report (full pipeline), 48 kHz 5 s stereo PCM16 taps (BASELINE config 5)",
                   what="bundle.run_bundle_metrics over stereo PCM16 tap files (native ingest, int16 upload, device "
                        "conversion, full metrics-only report of both channels)",

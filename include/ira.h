@@ -426,6 +426,15 @@ int32_t ira_wav_read_pcm16(const char* path, int64_t data_offset, int64_t frames
                            int16_t* dst_host);
 int32_t ira_pcm16_to_channels(const int16_t* pcm_dev, int64_t frames, int32_t channels, int32_t mono_downmix,
                               float* out_dev, void* stream);
+/* The same conversion for a GROUP of tap files in one launch (a bundle step holds 32 taps; one launch per tap was 27 % of a
+ * step's device time).  File f: interleaved int16 at pcm_dev + src_off[f] (even element offset: 4-byte frame loads),
+ * frames[f] frames of channels[f] in {1, 2} channels, mode[f] 1 = stereo mixed down to 0.5 * (L + R) in float32 (reference
+ * analyse/io.py:85-91), 0 = planar channels; output at out_dev + dst_off[f] (channel c at + c * frames[f]).  max_frames >=
+ * every frames[f] sizes the grid.  Replaces the per-file loop over scipy.io.wavfile.read + convert_wav_samples_to_float32
+ * + get_analysis_channels of reference analyse/io.py:46-113, :181-221 for a whole group. */
+int32_t ira_pcm16_to_channels_jobs(const int16_t* pcm_dev, const int64_t* src_off_dev, const int64_t* frames_dev,
+                                   const int32_t* channels_dev, const int32_t* mode_dev, const int64_t* dst_off_dev,
+                                   int32_t nfiles, int64_t max_frames, float* out_dev, void* stream);
 
 /* ---- a8 alone: mask_dev[k] = the float32 mask value the band inverses multiply bin k with, k < nbins, for ONE band record
  * (band_params8: HOST array of 8 doubles, as in ira_band_irfft) on the axis float32(k * freq_val).  The reference's

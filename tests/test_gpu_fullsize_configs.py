@@ -114,11 +114,14 @@ def test_config4_2048_irs_zplane_and_modal_cloud(big):
     assert abs(m[257, P.M_MODAL_MEDIAN] - np.median(rt)) <= 1e-4 * np.median(rt)
 
 
-def test_config5_2048_stereo_taps_through_the_ingest_ring(tmp_path):
+def test_config5_one_gpus_share_of_the_bundle_through_the_ingest_ring(tmp_path):
+    """BASELINE config 5 at its own size: 65 536 stereo 5 s taps over 8 GPUs = 8 192 taps (16 384 channels) per GPU, read from
+    files in the recorder's format (256 distinct taps, the rest hard links to them: the same bytes analysed in 32 different
+    steps must give the same records), 128 taps per step."""
     from audio_analysis_amd import pipeline as P
     from audio_analysis_amd.analyse import bundle
     n = 240000
-    distinct, copies = 256, 8
+    distinct, copies = 256, 32
     root = tmp_path / "bundle"
     (root / "taps").mkdir(parents=True)
     left, right = _synth_many(9000, distinct, n, 0), _synth_many(9000, distinct, n, 1)
@@ -133,12 +136,12 @@ def test_config5_2048_stereo_taps_through_the_ingest_ring(tmp_path):
             else:
                 os.link(root / "taps" / f"tap_0_{i:03d}.wav", path)
     (root / "meta.json").write_text(O.recorder_meta_json(SR, n, names))
-    labels, rec = bundle.run_bundle_metrics(root, taps_per_step=32)
-    assert len(labels) == 2 * distinct * copies and rec.shape == (4096, P.METRICS_WIDTH)
+    labels, rec = bundle.run_bundle_metrics(root, taps_per_step=128)
+    assert len(labels) == 2 * distinct * copies and rec.shape == (16384, P.METRICS_WIDTH)
     assert labels[:2] == [(names[0], "left"), (names[0], "right")] and labels[-1] == (names[-1], "right")
     assert np.all(rec[:, P.M_STATUS] == 0.0) and np.all(rec[:, P.M_NSAMPLES] == n)
     first = rec[: 2 * distinct]
-    for c in range(1, copies):                                        # the same file analysed in eight different steps
+    for c in range(1, copies):                                        # the same file analysed in 32 different steps
         assert rec[c * 2 * distinct : (c + 1) * 2 * distinct].tobytes() == first.tobytes(), c
     # one channel against the oracle, read from the file the way the reference's loader would
     _, raw = O.wav_pcm16_payload((root / "taps" / "tap_0_017.wav").read_bytes())
