@@ -48,8 +48,8 @@ PROTOTYPES = {
     "ira_log_smooth_db": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "ira_group_delay": (i32, [vp, vp, vp, i32, i32, vp, f64, vp, vp, vp]),
     "ira_fft_smooth_split": (i32, [i32, vp, vp]),
-    "ira_rfft_smooth": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
-    "ira_band_irfft_smooth": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "ira_rfft_smooth": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "ira_band_irfft_smooth": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "ira_wav_probe": (i32, [C.c_char_p, vp, vp, vp, vp]),
     "ira_wav_read_pcm16": (i32, [C.c_char_p, C.c_int64, C.c_int64, i32, vp]),
     "ira_pcm16_to_channels": (i32, [vp, C.c_int64, i32, i32, vp, vp]),

@@ -293,6 +293,14 @@ struct SJobs {
   const int64_t* xoff;
   const int64_t* x2off;          // null or -1: single
   int use_hann;
+  // interleave = 1 (forward): every job is ONE real signal of even length 2 n whose even / odd samples are the real /
+  // imaginary parts of an n-point complex sequence (x2off = xoff + 1, both read with stride 2, Hann index 2 i / 2 i + 1 on
+  // the REAL signal's window); smooth_half_split_kernel then untangles the n-point transform into the 2n-point half
+  // spectrum.  half_out = 1 (inverse): the mirror image -- one band of a 2 n-point real signal per n-point transform.
+  // Both keep a channel's transforms to itself: no signal of another channel shares its complex transform, so a channel's
+  // results do not depend on which channels happen to sit beside it in a batch (byte-identical
+  // records for any sharding).
+  int interleave, half_out;
   const int32_t* data_len; const int32_t* win_len; const int32_t* data_len2; const int32_t* win_len2;   // optional
   cd* spec_out;
   const int64_t* spec_off; const int64_t* spec_off2;
@@ -320,6 +328,7 @@ __device__ __forceinline__ double hann_s(long long i, long long L) {
 // pass-1 input phase of the band inverses took 47 k cycles of a 69 k-cycle tile)
 struct SCtx {
   long long o1, o2;                 // SM_SIGNAL: sample offsets (o2 < 0: one signal); SM_SPECTRUM: spectrum offsets
+  long long st;                     // SM_SIGNAL: sample stride (2 = even / odd samples of one real signal)
   long long nd1, nd2, lw1, lw2;     // SM_SIGNAL: samples actually read / Hann window lengths of the two signals
   bool two;                         // SM_SPECTRUM: the two bands come from two different spectra
   BandMaskS b1, b2;
@@ -348,10 +357,21 @@ __device__ __forceinline__ SCtx smooth_ctx(const SmoothPlan& P, const SJobs& J, 
     const int lw1 = J.win_len ? J.win_len[e] : (int)n, lw2 = J.win_len2 ? J.win_len2[e] : -1;
     c.o1 = ira::uniform(o1);
     c.o2 = ira::uniform(o2);
+    c.st = 1;
     c.nd1 = ira::uniform(nd1);
     c.nd2 = J.data_len2 ? (long long)ira::uniform(nd2) : c.nd1;
     c.lw1 = ira::uniform(lw1);
     c.lw2 = J.win_len2 ? (long long)ira::uniform(lw2) : c.lw1;
+    if (J.interleave) {
+      // one real signal of 2 n samples (data_len / win_len, when given, count REAL samples): element i of the transform
+      // is x[2 i] + i x[2 i + 1]
+      const long long real_nd = J.data_len ? c.nd1 : 2 * n, real_lw = J.win_len ? c.lw1 : 2 * n;
+      c.st = 2;
+      c.o2 = c.o1 + 1;
+      c.nd1 = (real_nd + 1) / 2;          // even samples available
+      c.nd2 = real_nd / 2;                // odd samples available
+      c.lw1 = c.lw2 = real_lw;
+    }
   } else {
     const long long o1 = J.sp_off[e];
     const long long o2 = J.sp_off2 ? (long long)J.sp_off2[e] : -1ll;
@@ -363,7 +383,7 @@ __device__ __forceinline__ SCtx smooth_ctx(const SmoothPlan& P, const SJobs& J, 
     c.b1 = uniform_band(b1);
     c.b2 = uniform_band(b2);
     c.fv = ira::uniform(fv);
-    ira::band_cuts(c.b1, c.b2, c.fv, (int)(n / 2), c.k1, c.k2);
+    ira::band_cuts(c.b1, c.b2, c.fv, J.half_out ? (int)n : (int)(n / 2), c.k1, c.k2);   // highest bin of the half spectrum
     ira::band_support(c.b1, c.k1, c.s1_lo, c.s1_hi);
     ira::band_support(c.b2, c.k2, c.s2_lo, c.s2_hi);
   }
@@ -376,14 +396,24 @@ __device__ __forceinline__ SCtx smooth_ctx(const SmoothPlan& P, const SJobs& J, 
 // and nothing is computed from them here: a load inside a per-lane branch, or one converted on the spot, is waited for at
 // once, which made the forward pass-1 input phase ten serial round trips.)
 struct RawIn { double a, b, c, d; float fa, fb; };
+// (half-size inverse) bins ka and kb of ONE spectrum; a bin outside the band's support reads bin 0 (multiplied by 0 later)
+__device__ __forceinline__ void r_load2(const SJobs& J, const SCtx& c, long long ka, long long kb, RawIn& r) {
+  const cd xa = J.spec[c.o1 + ((ka >= c.s1_lo && ka < c.s1_hi) ? ka : 0)];
+  const cd xb = J.spec[c.o1 + ((kb >= c.s1_lo && kb < c.s1_hi) ? kb : 0)];
+  r.a = xa.re; r.b = xa.im; r.c = xb.re; r.d = xb.im;
+}
 
 template <int MODE>
 __device__ __forceinline__ RawIn smooth_fetch(const SmoothPlan& P, const SJobs& J, const SCtx& c, long long i) {
   RawIn r{0.0, 0.0, 0.0, 0.0, 0.0f, 0.0f};
   const long long n = P.n;
   if (MODE == SM_SIGNAL) {
-    r.fa = *(i < c.nd1 ? J.x + c.o1 + i : J.x);
-    r.fb = *((c.o2 >= 0 && i < c.nd2) ? J.x + c.o2 + i : J.x);       // no branch around it either (same reason)
+    r.fa = *(i < c.nd1 ? J.x + c.o1 + c.st * i : J.x);
+    r.fb = *((c.o2 >= 0 && i < c.nd2) ? J.x + c.o2 + c.st * i : J.x);       // no branch around it either (same reason)
+  } else if (J.half_out) {
+    // half-size inverse of ONE band: element i needs the masked bins i and n - i of the (n + 1)-bin half spectrum
+    const long long k2 = n - i;
+    r_load2(J, c, i, k2, r);
   } else {
     const long long k = i > n / 2 ? n - i : i;
     // A bin whose mask is zero for certain reads bin 0 instead (its value is multiplied by 0 either way): the low and mid
@@ -409,10 +439,24 @@ __device__ __forceinline__ cd smooth_value(const SmoothPlan& P, const SJobs& J, 
   if (MODE == SM_SIGNAL) {
     double v = i < c.nd1 ? (double)r.fa : 0.0, v2 = (c.o2 >= 0 && i < c.nd2) ? (double)r.fb : 0.0;
     if (J.use_hann) {
-      v *= hann_s(i, c.lw1);
-      if (c.o2 >= 0) v2 *= hann_s(i, c.lw2);
+      v *= hann_s(c.st * i, c.lw1);
+      if (c.o2 >= 0) v2 *= hann_s(c.st * i + (c.st - 1), c.lw2);
     }
     return {v, v2};
+  } else if (J.half_out) {
+    // One band y of 2 n real samples from an n-point transform: with Xm = X * mask (n + 1 bins),
+    //   E[i] = (Xm[i] + conj Xm[n-i]) / 2,  O[i] = W_2n^(-i) (Xm[i] - conj Xm[n-i]) / 2,  Z = E + i O,
+    //   y[2 m] + i y[2 m + 1] = IDFT_n(Z)[m]        (inverse = conj(DFT(conj .)) / n: feed conj(Z))
+    const double ma = (double)ira::mask_cut(c.b1, c.k1, (int)i, c.fv);
+    const double mb = (double)ira::mask_cut(c.b1, c.k1, (int)(n - i), c.fv);
+    const cd xa = {r.a * ma, r.b * ma}, xb = {r.c * mb, -r.d * mb};            // Xm[i], conj Xm[n - i]
+    const cd e = {0.5 * (xa.re + xb.re), 0.5 * (xa.im + xb.im)};
+    const cd d = {0.5 * (xa.re - xb.re), 0.5 * (xa.im - xb.im)};
+    double sn, cs;
+    sincospi((double)i / (double)n, &sn, &cs);                                  // W_2n^(-i) = exp(+i pi i / n)
+    const cd o = {cs * d.re - sn * d.im, cs * d.im + sn * d.re};
+    const cd z = {e.re - o.im, e.im + o.re};                                     // E + i O
+    return {z.re, -z.im};
   } else {
     // conj of the Hermitian extension of X1 m1 + i X2 m2  (inverse = conj(DFT(conj .)) / n)
     const bool upper = i > n / 2;
@@ -590,6 +634,10 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_rows_kernel(SmoothPlan P, S
         if (k == 0 || 2 * k == n) v.im = 0.0;
         J.spec_out[out1 + k] = v;
       }
+    } else if (J.half_out) {
+      const double sc = 1.0 / (double)n;                    // samples 2 k and 2 k + 1 of the band signal
+      J.y[out1 + 2 * k] = (float)(v.re * sc);
+      J.y[out1 + 2 * k + 1] = (float)(-v.im * sc);
     } else {
       const double sc = 1.0 / (double)n;
       J.y[out1 + k] = (float)(v.re * sc);
@@ -615,6 +663,26 @@ __global__ __launch_bounds__(256) void smooth_pair_split_kernel(SmoothPlan P, SJ
   const cd zk = z[k], zl = z[k == 0 ? 0 : L - k];
   J.spec_out[o1 + k] = {0.5 * (zk.re + zl.re), 0.5 * (zk.im - zl.im)};
   J.spec_out[o2 + k] = {0.5 * (zk.im + zl.im), 0.5 * (zl.re - zk.re)};
+}
+
+// Interleaved jobs: z[m] = x[2m] + i x[2m+1], Z = DFT_L(z); the real signal's spectrum of length 2L is
+//   X[k] = E[k] + W_2L^k O[k],  E = (Z[k] + conj Z[L-k]) / 2,  O = (Z[k] - conj Z[L-k]) / (2i),  k = 0 .. L  (Z index mod L)
+// (same convention as half_split_kernel in ira_fftlong.hip)
+__global__ __launch_bounds__(256) void smooth_half_split_kernel(SmoothPlan P, SJobs J) {
+  const int e = blockIdx.y;
+  const long long L = P.n;
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > L) return;
+  const cd* z = J.zpair + J.zpair_off[e];
+  const long long o1 = J.spec_off[e];                           // before the store (see SCtx)
+  const cd zk = z[k == L ? 0 : k], zl = z[(k == 0 || k == L) ? 0 : L - k];
+  const cd ev = {0.5 * (zk.re + zl.re), 0.5 * (zk.im - zl.im)};
+  const cd od = {0.5 * (zk.im + zl.im), 0.5 * (zl.re - zk.re)};
+  double sn, cs;
+  sincospi(-(double)k / (double)L, &sn, &cs);                 // W_2L^k = exp(-i pi k / L)
+  cd x = {ev.re + (cs * od.re - sn * od.im), ev.im + (cs * od.im + sn * od.re)};
+  if (k == 0 || k == L) x.im = 0.0;                            // DC / Nyquist of a real signal
+  J.spec_out[o1 + k] = x;
 }
 
 // ---- planning ------------------------------------------------------------------------------------------------------------
@@ -766,16 +834,18 @@ extern "C" int32_t ira_rfft_smooth(const float* x_dev, const int64_t* xoff_dev, 
                                    double* spec_out_dev, const int64_t* spec_off_dev, const int64_t* x2off_dev,
                                    const int64_t* spec_off2_dev, double* zpair_dev, const int64_t* zpair_off_dev,
                                    const int32_t* data_len_dev, const int32_t* win_len_dev,
-                                   const int32_t* data_len2_dev, const int32_t* win_len2_dev, void* stream) {
+                                   const int32_t* data_len2_dev, const int32_t* win_len2_dev, int32_t interleave,
+                                   void* stream) {
   IRA_CHECK_PTR(x_dev); IRA_CHECK_PTR(xoff_dev); IRA_CHECK_PTR(t1_dev); IRA_CHECK_PTR(t2_dev); IRA_CHECK_PTR(tf_dev);
   IRA_CHECK_PTR(work_dev); IRA_CHECK_PTR(spec_out_dev); IRA_CHECK_PTR(spec_off_dev);
   if (nb <= 0) return nb == 0 ? IRA_OK : IRA_E_SIZE;
   if (nb > 65535) return IRA_E_SIZE;
+  if (interleave && (x2off_dev == nullptr || data_len2_dev != nullptr || win_len2_dev != nullptr)) return IRA_E_NULL;
   SmoothPlan P;
   const int32_t rc = make_smooth_plan(n, t1_dev, t2_dev, tf_dev, &P);
   if (rc != IRA_OK) return rc;
   SJobs J{};
-  J.x = x_dev; J.xoff = xoff_dev; J.use_hann = use_hann;
+  J.x = x_dev; J.xoff = xoff_dev; J.use_hann = use_hann; J.interleave = interleave ? 1 : 0;
   J.data_len = data_len_dev; J.win_len = win_len_dev; J.data_len2 = data_len2_dev; J.win_len2 = win_len2_dev;
   J.spec_out = reinterpret_cast<cd*>(spec_out_dev); J.spec_off = spec_off_dev;
   if (x2off_dev != nullptr) {
@@ -791,7 +861,9 @@ extern "C" int32_t ira_rfft_smooth(const float* x_dev, const int64_t* xoff_dev, 
   cd* work = reinterpret_cast<cd*>(work_dev);
   smooth_cols_kernel<SM_SIGNAL><<<dim3(P.n2 / P.c1, nb), SM_THREADS, l1, st>>>(P, J, work);
   smooth_rows_kernel<SM_OUT_SPEC><<<dim3(P.n1 / P.c2, nb), SM_THREADS, l2, st>>>(P, J, work);
-  if (x2off_dev != nullptr)
+  if (interleave)
+    smooth_half_split_kernel<<<dim3((n + 1 + 255) / 256, nb), 256, 0, st>>>(P, J);
+  else if (x2off_dev != nullptr)
     smooth_pair_split_kernel<<<dim3((n / 2 + 1 + 255) / 256, nb), 256, 0, st>>>(P, J);
   IRA_RETURN_LAUNCH();
 }
@@ -800,7 +872,7 @@ extern "C" int32_t ira_band_irfft_smooth(const double* spec_dev, const int64_t* 
                                          const double* band_params_dev, const double* freq_val_dev,
                                          const void* t1_dev, const void* t2_dev, const void* tf_dev, double* work_dev,
                                          float* y_dev, const int64_t* y1_off_dev, const int64_t* y2_off_dev,
-                                         const int64_t* spec_off2_dev, void* stream) {
+                                         const int64_t* spec_off2_dev, int32_t half_out, void* stream) {
   IRA_CHECK_PTR(spec_dev); IRA_CHECK_PTR(spec_off_dev); IRA_CHECK_PTR(band_params_dev); IRA_CHECK_PTR(freq_val_dev);
   IRA_CHECK_PTR(t1_dev); IRA_CHECK_PTR(t2_dev); IRA_CHECK_PTR(tf_dev); IRA_CHECK_PTR(work_dev); IRA_CHECK_PTR(y_dev);
   IRA_CHECK_PTR(y1_off_dev); IRA_CHECK_PTR(y2_off_dev);
@@ -814,6 +886,8 @@ extern "C" int32_t ira_band_irfft_smooth(const double* spec_dev, const int64_t* 
   J.spec = reinterpret_cast<const cd*>(spec_dev); J.sp_off = spec_off_dev; J.sp_off2 = spec_off2_dev;
   J.bands = reinterpret_cast<const BandMaskS*>(band_params_dev); J.freq_val = freq_val_dev;
   J.y = y_dev; J.y1_off = y1_off_dev; J.y2_off = y2_off_dev;
+  J.half_out = half_out ? 1 : 0;
+  if (half_out && spec_off2_dev != nullptr) return IRA_E_UNSUPPORTED;       // one band of one spectrum per job
   hipStream_t st = (hipStream_t)stream;
   const size_t nbuf = P.inplace ? 1 : 2;
   const size_t l1 = (nbuf * P.c1 * P.ld1 + SM_TW) * sizeof(cd), l2 = (nbuf * P.c2 * P.ld2 + SM_TW) * sizeof(cd);

@@ -709,10 +709,16 @@ class Engine:
                 i = k + 1
         return pool["buf"], slots[inv].astype(np.int32)
 
-    # Two real signals of equal length share one complex transform (z = x1 + i*x2, Hermitian split), and the odd
-    # band of one channel shares an inverse transform with the odd band of another.  Set False to force one
-    # transform per signal / per channel band pair (A/B switch; results agree to ~1e-16 of the larger signal).
+    # A channel's transforms are its own.  Round 2 let two real signals of equal length from DIFFERENT channels share one
+    # complex transform (z = x1 + i*x2) and the odd band of one channel share an inverse with the odd band of another:
+    # cheaper by half, but then the last bits of a channel's spectrum depend on which channel happened to be its partner,
+    # i.e. on batch composition and shard boundaries (SURVEY.md section 8e asks for byte-identical records for every
+    # world size).  Now a single real signal of EVEN length rides a HALF-length complex transform instead (x[2m] + i
+    # x[2m+1]: the same saving), bands are paired only within one channel, and an odd band out takes the half-length
+    # inverse.  pair_across_channels = True restores round 2's pairing (A/B; results then agree to ~1e-16 of the larger
+    # signal, not bit for bit).  pair_real_ffts = False additionally forbids pairing the bands of one channel.
     pair_real_ffts = True
+    pair_across_channels = False
     # A real signal of EVEN (non-smooth) length L is transformed as the complex sequence x[2m] + i*x[2m+1] of length
     # L/2 (half the Bluestein convolution size) and split with a twiddle.  Set False for an A/B.
     half_real_ffts = True
@@ -752,23 +758,36 @@ class Engine:
             spec_off[1:] = np.cumsum(bins[:-1])
         spec = self.empty(int(bins.sum()) * 2, t.float64)
         # ---- smooth lengths: direct two-pass transform, one call per distinct length ------------------------------------
+        # Even lengths whose half is smooth too ride a HALF-length complex transform each (interleave mode); the rest one
+        # full-length transform each -- or, with pair_across_channels, two per transform as in round 2.
         rest = np.ones(n, dtype=bool)
         for L in np.unique(lengths):
-            if self.smooth_split(int(L)) is None:
+            full_ok = self.smooth_split(int(L)) is not None
+            half_ok = (int(L) % 2 == 0 and int(L) >= 128 and self.half_real_ffts and not self.pair_across_channels
+                       and self.smooth_split(int(L) // 2) is not None)
+            if not (full_ok or half_ok):
                 continue
             grp = np.nonzero(lengths == L)[0]
             rest[grp] = False
-            t1, t2, tf = self.smooth_tables(int(L))
-            for idx in self._chunks_of(grp, 32 * int(L)):
-                if self.pair_real_ffts and idx.size > 1:
+            nt = int(L) // 2 if half_ok else int(L)                  # transform length
+            t1, t2, tf = self.smooth_tables(nt)
+            for idx in self._chunks_of(grp, 32 * nt):
+                if half_ok:
+                    j1, j2 = idx.astype(np.int64), np.full(idx.size, -1, dtype=np.int64)
+                elif self.pair_real_ffts and self.pair_across_channels and idx.size > 1:
                     j1, j2 = self._pair_by_key(idx, lengths)
                 else:
                     j1, j2 = idx.astype(np.int64), np.full(idx.size, -1, dtype=np.int64)
-                work = self.empty(int(j1.size) * 2 * int(L), t.float64)
+                work = self.empty(int(j1.size) * 2 * nt, t.float64)
                 paired = j2 >= 0
                 safe = np.maximum(j2, 0)
                 a_x2 = a_so2 = a_zo = zpair = None
-                if paired.any():
+                if half_ok:
+                    a_x2 = (xoff[j1] + 1).astype(np.int64)
+                    a_so2 = spec_off[j1].astype(np.int64)
+                    a_zo = (np.arange(j1.size, dtype=np.int64) * nt)
+                    zpair = self.empty(int(j1.size) * 2 * nt, t.float64)
+                elif paired.any():
                     a_x2 = np.where(paired, xoff[safe], -1).astype(np.int64)
                     a_so2 = np.where(paired, spec_off[safe], 0).astype(np.int64)
                     zoff = np.cumsum(np.where(paired, int(L), 0)) - np.where(paired, int(L), 0)
@@ -776,13 +795,15 @@ class Engine:
                     a_zo = zoff.astype(np.int64)
                 a_dl = a_wl = a_dl2 = a_wl2 = None
                 if padded:
-                    a_dl, a_wl, a_dl2, a_wl2 = data_len[j1], win_len[j1], data_len[safe], win_len[safe]
+                    a_dl, a_wl = data_len[j1], win_len[j1]
+                    if not half_ok:
+                        a_dl2, a_wl2 = data_len[safe], win_len[safe]
                 d_xo, d_so, d_x2, d_so2, d_zo, d_dl, d_wl, d_dl2, d_wl2 = self.to_dev_pack(
                     xoff[j1], spec_off[j1], a_x2, a_so2, a_zo, a_dl, a_wl, a_dl2, a_wl2)
-                check(self.lib.ira_rfft_smooth(_ptr(x_dev), _ptr(d_xo), int(L), int(j1.size), 1 if use_hann else 0,
+                check(self.lib.ira_rfft_smooth(_ptr(x_dev), _ptr(d_xo), nt, int(j1.size), 1 if use_hann else 0,
                                                _ptr(t1), _ptr(t2), _ptr(tf), _ptr(work), _ptr(spec), _ptr(d_so),
                                                _ptr(d_x2), _ptr(d_so2), _ptr(zpair), _ptr(d_zo), _ptr(d_dl), _ptr(d_wl),
-                                               _ptr(d_dl2), _ptr(d_wl2), self.stream), "ira_rfft_smooth")
+                                               _ptr(d_dl2), _ptr(d_wl2), 1 if half_ok else 0, self.stream), "ira_rfft_smooth")
         if not rest.any():
             return spec, spec_off
         rest_idx = np.nonzero(rest)[0]
@@ -793,7 +814,7 @@ class Engine:
         lr = lengths[rest_idx]
         is_half = ((lr % 2 == 0) & (lr >= 8)) if use_half else np.zeros(rest_idx.size, dtype=bool)
         others = rest_idx[~is_half]
-        if self.pair_real_ffts and others.size > 1:
+        if self.pair_real_ffts and self.pair_across_channels and others.size > 1:
             p1, p2 = self._pair_by_key(others, lengths)
         else:
             p1, p2 = others.astype(np.int64), np.full(others.size, -1, dtype=np.int64)
@@ -839,8 +860,10 @@ class Engine:
         """
         Masked inverse transforms, ONE BAND PER ENTRY: entry j filters the half spectrum at spec_off[j] (length
         lengths[j], bin step freq_val[j]) with the 8-double mask record band_params[j] and writes lengths[j]
-        float32 samples at y_off[j].  Entries with the same (length, bin step) are inverse-transformed two at a
-        time (y1 + i*y2; see ira_band_irfft in include/ira.h) -- bands of one channel or of two different channels.
+        float32 samples at y_off[j].  Two bands of the SAME spectrum are inverse-transformed together (y1 + i*y2; see
+        ira_band_irfft in include/ira.h); a band left over takes a half-length inverse when its length allows it (smooth
+        family, even length) and a full-length one otherwise.  (pair_across_channels = True: round 2's pairing of entries
+        with the same length and bin step from different channels.)
         """
         t = self.torch
         lengths = np.ascontiguousarray(lengths, dtype=np.int32)
@@ -850,10 +873,13 @@ class Engine:
         freq_val = np.ascontiguousarray(freq_val, dtype=np.float64)
         # pair key: same transform length AND same float64 bin step (AND same spectrum when cross-channel pairing is off)
         cols = [lengths.astype(np.float64), freq_val]
-        if not self.pair_real_ffts:
+        if not self.pair_across_channels:
             cols.append(spec_off.astype(np.float64))
         _, key = np.unique(np.stack(cols, axis=1), axis=0, return_inverse=True)
-        j1, j2 = self._pair_by_key(np.arange(lengths.size), key.reshape(-1))
+        if self.pair_real_ffts:
+            j1, j2 = self._pair_by_key(np.arange(lengths.size), key.reshape(-1))
+        else:
+            j1, j2 = np.arange(lengths.size, dtype=np.int64), np.full(lengths.size, -1, dtype=np.int64)
         jl = lengths[j1]
         safe = np.maximum(j2, 0)
         has2 = j2 >= 0
@@ -864,20 +890,31 @@ class Engine:
         el_y2 = np.where(has2, y_off[safe], -1).astype(np.int64)
         rest = np.ones(j1.size, dtype=bool)
         for L in np.unique(jl):
-            if self.smooth_split(int(L)) is None:
-                continue
-            grp = np.nonzero(jl == L)[0]
-            rest[grp] = False
-            t1, t2, tf = self.smooth_tables(int(L))
-            for sel in self._chunks_of(grp, 16 * int(L)):
-                work = self.empty(int(sel.size) * 2 * int(L), t.float64)
-                d_so, d_bp, d_fv, d_y1, d_y2, d_so2 = self.to_dev_pack(
-                    spec_off[j1][sel], np.ascontiguousarray(el_par[sel]), np.ascontiguousarray(freq_val[j1][sel]),
-                    np.ascontiguousarray(y_off[j1][sel]), np.ascontiguousarray(el_y2[sel]), np.ascontiguousarray(el_so2[sel]))
-                check(self.lib.ira_band_irfft_smooth(_ptr(spec_dev), _ptr(d_so), int(L), int(sel.size), _ptr(d_bp),
-                                                     _ptr(d_fv), _ptr(t1), _ptr(t2), _ptr(tf), _ptr(work), _ptr(y_dev),
-                                                     _ptr(d_y1), _ptr(d_y2), _ptr(d_so2), self.stream),
-                      "ira_band_irfft_smooth")
+            full_ok = self.smooth_split(int(L)) is not None
+            half_ok = (int(L) % 2 == 0 and int(L) >= 128 and self.half_real_ffts
+                       and self.smooth_split(int(L) // 2) is not None)
+            for halves in (False, True):
+                # single bands take the half-length inverse when the length allows it, pairs the full-length one
+                if halves and not half_ok:
+                    continue
+                if not halves and not full_ok:
+                    continue
+                grp = np.nonzero((jl == L) & rest & ((~has2) if halves else (has2 | (not half_ok))))[0]
+                if grp.size == 0:
+                    continue
+                rest[grp] = False
+                nt = int(L) // 2 if halves else int(L)
+                t1, t2, tf = self.smooth_tables(nt)
+                for sel in self._chunks_of(grp, 16 * nt):
+                    work = self.empty(int(sel.size) * 2 * nt, t.float64)
+                    d_so, d_bp, d_fv, d_y1, d_y2, d_so2 = self.to_dev_pack(
+                        spec_off[j1][sel], np.ascontiguousarray(el_par[sel]), np.ascontiguousarray(freq_val[j1][sel]),
+                        np.ascontiguousarray(y_off[j1][sel]), np.ascontiguousarray(el_y2[sel]),
+                        None if halves else np.ascontiguousarray(el_so2[sel]))
+                    check(self.lib.ira_band_irfft_smooth(_ptr(spec_dev), _ptr(d_so), nt, int(sel.size), _ptr(d_bp),
+                                                         _ptr(d_fv), _ptr(t1), _ptr(t2), _ptr(tf), _ptr(work), _ptr(y_dev),
+                                                         _ptr(d_y1), _ptr(d_y2), _ptr(d_so2), 1 if halves else 0,
+                                                         self.stream), "ira_band_irfft_smooth")
         if not rest.any():
             return
         rest_idx = np.nonzero(rest)[0]

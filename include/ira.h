@@ -366,19 +366,27 @@ int32_t ira_fir_numerator(const double* coeffs_dev, int32_t order, const float* 
  *   t1_dev[k] = exp(-2 pi i k/n1), k < n1;  t2_dev[k] = exp(-2 pi i k/n2), k < n2;  tf_dev[k] = exp(-2 pi i k/n), k < n2.
  * work_dev: nb * n complex f64.  All other arguments mean what they mean in ira_rfft_any / ira_band_irfft (same
  * reference call sites: frequency_response.py:204-213, filterplot.py:145-152, rt60bands.py:170-175,
- * group_delay.py:95-109). */
+ * group_delay.py:95-109).
+ * Half-size modes (round 3), so that a channel's transforms never share a complex transform with ANOTHER channel's signal
+ * and its results cannot depend on its neighbours in a batch (byte-identical records for any sharding):
+ *   ira_rfft_smooth(..., interleave = 1): every job is ONE real signal of even length 2 n carried as the n-point complex
+ *     sequence x[2m] + i x[2m+1] (x2off_dev[e] = xoff_dev[e] + 1; data_len / win_len, when given, count REAL samples; the
+ *     second signal's length arrays must be NULL); spec_off_dev[e] receives its n + 1 bins.  zpair: n complex per job.
+ *   ira_band_irfft_smooth(..., half_out = 1): every job is ONE band (band record 2e; record 2e+1 is ignored) of a real
+ *     signal of even length 2 n, computed by an n-point transform: the job's half spectrum has n + 1 bins, y1_off_dev[e]
+ *     receives 2 n samples, y2_off_dev is ignored, spec_off2_dev must be NULL. */
 int32_t ira_fft_smooth_split(int32_t n, int32_t* n1, int32_t* n2);
 int32_t ira_rfft_smooth(const float* x_dev, const int64_t* xoff_dev, int32_t n, int32_t nb, int32_t use_hann,
                         const void* t1_dev, const void* t2_dev, const void* tf_dev, double* work_dev,
                         double* spec_out_dev, const int64_t* spec_off_dev, const int64_t* x2off_dev,
                         const int64_t* spec_off2_dev, double* zpair_dev, const int64_t* zpair_off_dev,
                         const int32_t* data_len_dev, const int32_t* win_len_dev, const int32_t* data_len2_dev,
-                        const int32_t* win_len2_dev, void* stream);
+                        const int32_t* win_len2_dev, int32_t interleave, void* stream);
 int32_t ira_band_irfft_smooth(const double* spec_dev, const int64_t* spec_off_dev, int32_t n, int32_t nb,
                               const double* band_params_dev, const double* freq_val_dev, const void* t1_dev,
                               const void* t2_dev, const void* tf_dev, double* work_dev, float* y_dev,
                               const int64_t* y1_off_dev, const int64_t* y2_off_dev, const int64_t* spec_off2_dev,
-                              void* stream);
+                              int32_t half_out, void* stream);
 
 /* k-th smallest values (0-based ranks, clipped to the segment) of float64 segments values_dev + off_dev[e], count_dev[e]
  * long: out_dev[e*nranks + j] = sorted(segment)[ranks_dev[e*nranks + j]], 1 <= nranks <= 8 (radix select, exact).

@@ -128,13 +128,13 @@ def test_config5_one_gpus_share_of_the_bundle_through_the_ingest_ring(tmp_path):
     names = []
     for c in range(copies):
         for i in range(distinct):
-            name = f"tap_{c}_{i:03d}"
+            name = f"tap_{c:02d}_{i:03d}"               # (the recorder's meta.json lists taps in std::map = lexicographic order)
             names.append(name)
             path = root / "taps" / f"{name}.wav"
             if c == 0:
                 path.write_bytes(O.recorder_wav_bytes(np.stack([left[i], right[i]], axis=1)))
             else:
-                os.link(root / "taps" / f"tap_0_{i:03d}.wav", path)
+                os.link(root / "taps" / f"tap_00_{i:03d}.wav", path)
     (root / "meta.json").write_text(O.recorder_meta_json(SR, n, names))
     labels, rec = bundle.run_bundle_metrics(root, taps_per_step=128)
     assert len(labels) == 2 * distinct * copies and rec.shape == (16384, P.METRICS_WIDTH)
@@ -144,7 +144,7 @@ def test_config5_one_gpus_share_of_the_bundle_through_the_ingest_ring(tmp_path):
     for c in range(1, copies):                                        # the same file analysed in 32 different steps
         assert rec[c * 2 * distinct : (c + 1) * 2 * distinct].tobytes() == first.tobytes(), c
     # one channel against the oracle, read from the file the way the reference's loader would
-    _, raw = O.wav_pcm16_payload((root / "taps" / "tap_0_017.wav").read_bytes())
+    _, raw = O.wav_pcm16_payload((root / "taps" / "tap_00_017.wav").read_bytes())
     x = [v for _, v in O.analysis_channels(O.pcm_to_float32(raw), False)][1]
     row = rec[2 * 17 + 1]
     d = O.analyse_decay(x)
