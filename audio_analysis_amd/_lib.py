@@ -13,7 +13,7 @@ _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libira.so"
 _lib = None
 # must equal IRA_ABI_VERSION of include/ira.h: a stale .so called with this file's prototypes would read shifted
 # arguments or undersized scratch (memory corruption on the GPU instead of a clean error)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_f32p = C.c_void_p
 c_i64p = C.c_void_p

@@ -34,14 +34,71 @@ constexpr int FL_THREADS = 256;
 // (4 workgroups per CU) and by memory (K2 moves 3.2 TB/s), not by registers; smaller tiles (C = R = 1) were slower still.
 constexpr int FL_LR = 4;
 
+// M = N1 x N2 with N2 = 2^log2n2 and N1 = rad * Q, Q = 2^log2q, rad = 1 or 3: convolution sizes 2^k and 3 * 2^k, so that
+// M exceeds what a job needs by at most a third instead of up to 2x (half of all real-file lengths are odd and need
+// M >= 1.5 L: 3 * 2^18 instead of 2^20 at 10 s).  A column of N1 = 3 Q points is ONE radix-3 decimation-in-frequency stage
+// (three blocks of Q: block b holds the frequencies k1 = 3 k' + b) around the power-of-two sub-FFTs of ira_fft_lds.h, which
+// then run on rad * C blocks of Q points.  In LDS a block is padded to Q + 1 entries.
 struct Geom {
-  int log2m, log2n1, log2n2;
-  const cd* t1;  // exp(-2 pi i k / N1), k < N1   (full circle; first half doubles as the N1 sub-FFT table)
+  long long m;
+  int n1, rad, log2q, log2n2;
+  const cd* t1;  // exp(-2 pi i k / N1), k < N1   (full circle; first half doubles as the sub-FFT table, period N1 = rad * Q)
   const cd* t2;  // exp(-2 pi i k / N2), k < N2
   const cd* tf;  // exp(-2 pi i k / M),  k < N2
   int ablate;    // diagnostics (IRA_FFT_ABLATE): 1 K1 plain input, 2 K1 no FFT, 4 K1 no store, 8 K2 no FFTs,
                  // 16 K2 no filter multiply, 32 K3 no FFT, 64 K3 plain epilogue, 128 K2 no store, 256 K3 no load
 };
+
+// LDS slot (inside one column) of column element / work-array row `r` < N1, and the column frequency k1 that row r of the
+// work array holds after the forward column pass (rows stay in this permuted order through K2; K3's DIT consumes it).
+__device__ __forceinline__ unsigned col_slot(const Geom& g, unsigned r) {
+  return (r >> g.log2q) * ((1u << g.log2q) + 1u) + (r & ((1u << g.log2q) - 1u));
+}
+__device__ __forceinline__ unsigned row_k1(const Geom& g, unsigned r) {
+  return (unsigned)g.rad * ira::lds_brev(r & ((1u << g.log2q) - 1u), g.log2q) + (r >> g.log2q);
+}
+
+// forward radix-3 butterfly (W = exp(-2 pi i / 3)), natural order in and out
+__device__ __forceinline__ void bfly3(cd& a0, cd& a1, cd& a2) {
+  const cd t1 = ira::cadd(a1, a2);
+  const cd t2 = {a0.re - 0.5 * t1.re, a0.im - 0.5 * t1.im};
+  const cd d = ira::csub(a1, a2);
+  const cd r = {0.86602540378443864676 * d.im, -0.86602540378443864676 * d.re};     // -i sin(pi/3) (a1 - a2)
+  a0 = ira::cadd(a0, t1);
+  a1 = ira::cadd(t2, r);
+  a2 = ira::csub(t2, r);
+}
+
+// The radix-3 stage of a column of N1 = 3 Q points held as three blocks of Q (+1 pad) in LDS, C columns `stride` apart.
+// Forward (decimation in frequency): y_b[j] = W_N1^(j b) sum_r x[j + r Q] W_3^(r b) replaces x[j + b Q]; block b is then
+// the input of the Q-point transform that yields X[3 k' + b].  Inverse: the exact reverse (unnormalised).
+template <bool INVERSE>
+__device__ __forceinline__ void radix3_stage(const Geom& g, cd* lds, const cd* twl, int C, unsigned stride, int tid) {
+  const unsigned Q = 1u << g.log2q, qs = Q + 1u, half = (unsigned)g.n1 >> 1;
+  for (unsigned idx = tid; idx < Q * (unsigned)C; idx += FL_THREADS) {
+    const unsigned c = idx >> g.log2q, j = idx & (Q - 1u);
+    cd* p = lds + c * stride + j;
+    cd a0 = p[0], a1 = p[qs], a2 = p[2 * qs];
+    cd w1 = ira::tw_get<double, true>(twl, j);                       // W_N1^j       (j < Q < N1/2)
+    cd w2 = ira::tw_lookup<double, true>(twl, 2u * j, half);         // W_N1^(2 j)   (2 j < N1)
+    if (INVERSE) {
+      w1.im = -w1.im; w2.im = -w2.im;
+      a1 = ira::cmul(a1, w1);
+      a2 = ira::cmul(a2, w2);
+      a0.im = -a0.im; a1.im = -a1.im; a2.im = -a2.im;                // inverse 3-point DFT = conj(DFT(conj .))
+      bfly3(a0, a1, a2);
+      a0.im = -a0.im; a1.im = -a1.im; a2.im = -a2.im;
+    } else {
+      bfly3(a0, a1, a2);
+      if (j != 0) {
+        a1 = ira::cmul(a1, w1);
+        a2 = ira::cmul(a2, w2);
+      }
+    }
+    p[0] = a0; p[qs] = a1; p[2 * qs] = a2;
+  }
+  __syncthreads();
+}
 
 // Phase of a chirp value: q / L half-turns reduced to [0, 2), for an exact non-negative integer q < 2^53 held in a double
 // (n^2, 2 n dn + dn^2, 2 dn^2 with n, dn < 2^22).  q mod 2L comes out EXACTLY from one fma -- the quotient estimate is off
@@ -229,9 +286,12 @@ __device__ __forceinline__ cd value_input(const Jobs& J, const Ctx& c, long long
     if (c.o2 < 0) return {v * w.re, v * w.im};
     return {v * w.re - v2 * w.im, v * w.im + v2 * w.re};
   } else if (MODE == IN_FILTER) {
-    long long m = n;
-    if (n >= L) {
-      m = M - n;
+    // b[j] = conj(w[|j|]) for -(L-1) <= j <= L-1 at position j mod M.  With M >= 2L - 1 the two sides do not meet; a
+    // smaller M (>= L + L/2, single real signals whose bins k <= L/2 alone are wanted) lets them overlap, and then the
+    // NEGATIVE side wins: output k needs j = k - n in [-(L-1), L/2], and positions above L/2 can only mean j < 0.
+    long long m = M - n;
+    if (m >= L) {
+      m = n;
       if (m >= L) return {0.0, 0.0};
     }
     const cd wm = chirp(m, chirp_scale(L));
@@ -278,11 +338,11 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   const int e = by;
   const Ctx ctx = job_ctx<MODE>(J, e);
   const long long L = ctx.L;
-  const unsigned N1 = 1u << g.log2n1, N2 = 1u << g.log2n2;
-  const long long M = 1ll << g.log2m;
+  const unsigned N1 = (unsigned)g.n1, N2 = 1u << g.log2n2;
+  const long long M = g.m;
   const unsigned n2_0 = bx * C;
   const unsigned lc = 31u - (unsigned)__builtin_clz((unsigned)C), cm = (unsigned)C - 1u;   // C is a power of two (make_plan)
-  const unsigned stride = N1 + 1;
+  const unsigned stride = (unsigned)g.rad * ((1u << g.log2q) + 1u);    // rad blocks of Q + 1
   const int tid = threadIdx.x;
   cd* twl = lds + (size_t)C * stride;                                  // two-level twiddle table of the sub-FFT (ira_fft_lds.h)
   const cd twv = ira::tw_split_fetch<double>(g.t1, N1 >> 1, tid);      // load issued first, LDS write after the tile's loads
@@ -365,7 +425,7 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
           const long long n = n0 + (long long)j * dn;
           const double h = (lw1 > 1) ? 0.5 + 0.5 * hc : 1.0;
           const double h2 = (lw2 > 1) ? 0.5 + 0.5 * hc2 : 1.0;
-          lds[c * stride + n1] = (g.ablate & 1) ? cd{(double)n, 1.0} : value_input<MODE>(J, ctx, n, M, w, h, h2, raw[u]);
+          lds[c * stride + col_slot(g, n1)] = (g.ablate & 1) ? cd{(double)n, 1.0} : value_input<MODE>(J, ctx, n, M, w, h, h2, raw[u]);
           w = ira::cmul(w, d);
           d = ira::cmul(d, e2);
           const double nc = hc * rc - hs * rs;
@@ -382,7 +442,10 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   }
   ira::tw_split_put(twl, twv, tid);
   __syncthreads();
-  if (!(g.ablate & 2)) ira::lds_fft_dif<double, FL_LR, true>(lds, g.log2n1, twl, 1u, tid, FL_THREADS, C, stride);
+  if (!(g.ablate & 2)) {
+    if (g.rad == 3) radix3_stage<false>(g, lds, twl, C, stride, tid);
+    ira::lds_fft_dif<double, FL_LR, true>(lds, g.log2q, twl, (unsigned)g.rad, tid, FL_THREADS, C * g.rad, (1u << g.log2q) + 1u);
+  }
   cd* w = work + (long long)e * M;
   const unsigned total_o = N1 * (unsigned)C;
   for (unsigned base = 0; base < total_o; base += FL_THREADS * FL_UI) {
@@ -391,7 +454,7 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     for (int u = 0; u < FL_UI; ++u) {
       unsigned i = base + tid + FL_THREADS * u;
       i = i < total_o ? i : total_o - 1;
-      const unsigned p = (n2_0 + (i & cm)) * ira::lds_brev(i >> lc, g.log2n1);
+      const unsigned p = (n2_0 + (i & cm)) * row_k1(g, i >> lc);
       th[u] = g.t1[p >> g.log2n2];
       tl[u] = g.tf[p & (N2 - 1u)];
     }
@@ -400,7 +463,7 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       const unsigned i = base + tid + FL_THREADS * u;
       if (i >= total_o) continue;
       const unsigned c = i & cm, r = i >> lc;
-      const cd v = ira::cmul(lds[c * stride + r], ira::cmul(th[u], tl[u]));
+      const cd v = ira::cmul(lds[c * stride + col_slot(g, r)], ira::cmul(th[u], tl[u]));
       if ((g.ablate & 4) && v.re != 12345.678) continue;
       w[(long long)r * N2 + n2_0 + c] = v;
     }
@@ -418,7 +481,7 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   remap_xcd(bx, by);
   const int e = by;
   const unsigned N2 = 1u << g.log2n2;
-  const long long M = 1ll << g.log2m;
+  const long long M = g.m;
   const unsigned r0 = bx * R;
   const int tid = threadIdx.x;
   const int filt = MODE == ROW_CONV ? ira::uniform(J.bidx[e]) : 0;            // before the tile loop (see Ctx)
@@ -469,7 +532,7 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       for (int u = 0; u < FL_UI; ++u) {
         unsigned i = base + tid + FL_THREADS * u;
         i = i < total ? i : total - 1;
-        const unsigned p = (i & (N2 - 1)) * ira::lds_brev(r0 + (i >> g.log2n2), g.log2n1);
+        const unsigned p = (i & (N2 - 1)) * row_k1(g, r0 + (i >> g.log2n2));
         th[u] = g.t1[p >> g.log2n2];
         tl[u] = g.tf[p & (N2 - 1u)];
       }
@@ -516,11 +579,11 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     }
     L = ira::uniform(l);
   }
-  const unsigned N1 = 1u << g.log2n1, N2 = 1u << g.log2n2;
-  const long long M = 1ll << g.log2m;
+  const unsigned N1 = (unsigned)g.n1, N2 = 1u << g.log2n2;
+  const long long M = g.m;
   const unsigned n2_0 = bx * C;
   const unsigned lc = 31u - (unsigned)__builtin_clz((unsigned)C), cm = (unsigned)C - 1u;   // C is a power of two (make_plan)
-  const unsigned stride = N1 + 1;
+  const unsigned stride = (unsigned)g.rad * ((1u << g.log2q) + 1u);    // rad blocks of Q + 1
   const int tid = threadIdx.x;
   // outputs needed: n <= L/2 (spectrum) or n < L (bands); rows beyond that are computed but not stored
   const long long n_need = (MODE == OUT_SPECTRUM && !paired) ? L / 2 + 1 : L;
@@ -539,12 +602,15 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 #pragma unroll
     for (int u = 0; u < FL_U; ++u) {
       const unsigned i = base + tid + FL_THREADS * u;
-      if (i < total) lds[(i & cm) * stride + (i >> lc)] = raw[u];
+      if (i < total) lds[(i & cm) * stride + col_slot(g, i >> lc)] = raw[u];
     }
   }
   ira::tw_split_put(twl, twv, tid);
   __syncthreads();
-  if (!(g.ablate & 32)) ira::lds_fft_dit<double, FL_LR, true>(lds, g.log2n1, twl, 1u, true, tid, FL_THREADS, C, stride);
+  if (!(g.ablate & 32)) {
+    ira::lds_fft_dit<double, FL_LR, true>(lds, g.log2q, twl, (unsigned)g.rad, true, tid, FL_THREADS, C * g.rad, (1u << g.log2q) + 1u);
+    if (g.rad == 3) radix3_stage<true>(g, lds, twl, C, stride, tid);
+  }
   const double inv_m = 1.0 / (double)M;
   // The output chirp exp(-i pi n^2 / L) along a thread's elements n_j = n_0 + j dn by the same recurrence as in K1
   // (w_{j+1} = w_j d_j, d_{j+1} = d_j e2: three exactly reduced sincospi per thread instead of a 64-bit modulo and a
@@ -562,7 +628,7 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     cw = ira::cmul(cw, cdl);
     cdl = ira::cmul(cdl, ce2);
     if (n >= n_need) continue;
-    cd v = lds[c * stride + n1];
+    cd v = lds[c * stride + col_slot(g, n1)];
     if (!(g.ablate & 64)) v = ira::cmul(v, wn);
     if (MODE == OUT_SPECTRUM) {
       v.re *= inv_m; v.im *= inv_m;
@@ -618,15 +684,32 @@ __global__ __launch_bounds__(256) void half_split_kernel(Jobs J) {
 
 // M = N1 x N2.  The column passes (K1, K3) touch C adjacent columns of every row, i.e. C*16-byte pieces at a stride
 // of N2*16 bytes, and C is what fits in LDS: a SHORT column (small N1) buys wide pieces.  IRA_FFT_SPLIT overrides
-// log2(N1) for tuning; ira_fft_split() is the single source of truth the host sizes its tables from.
-int split_log2n1(int log2m) {
-  const int forced = ira_tune_int("IRA_FFT_SPLIT", 0);
-  int l1 = (log2m + 1) / 2;
-  if (forced > 0) l1 = forced;
-  if (l1 < 2) l1 = 2;
-  if (l1 > log2m - 2) l1 = log2m - 2;
-  if (log2m - l1 > 13) l1 = log2m - 13;      // one row (N2 complex f64) must fit in LDS: N2 <= 8192
-  return l1;
+// log2(N1) for tuning (powers of two); split_of() is the single source of truth the host sizes its tables from
+// (ira_fft_split).  Sizes: 2^k (16 <= M <= 2^22) and 3 * 2^k (96 <= M <= 3 * 2^20).
+struct Split { int rad, log2q, log2n2; };
+
+bool split_of(long long m, Split* out) {
+  if (m < 16 || m > (1ll << 22)) return false;
+  int rad = 1;
+  if (m % 3 == 0) { rad = 3; m /= 3; }
+  if ((m & (m - 1)) != 0) return false;
+  int log2p = 0;
+  while ((1ll << log2p) < m) ++log2p;
+  int lq;                                       // log2 of the power-of-two part of N1
+  if (rad == 1) {
+    const int forced = ira_tune_int("IRA_FFT_SPLIT", 0);
+    lq = (log2p + 1) / 2;
+    if (forced > 0) lq = forced;
+    if (lq < 2) lq = 2;
+    if (lq > log2p - 2) lq = log2p - 2;
+    if (log2p - lq > 13) lq = log2p - 13;      // one row (N2 complex f64) must fit in LDS: N2 <= 8192
+  } else {
+    if (log2p < 5) return false;                // M >= 96
+    lq = (log2p - 1) / 2;                       // N1 = 3 * 2^lq just below N2: 768 x 1024 at M = 3 * 2^18
+    if (log2p - lq > 13) lq = log2p - 13;
+  }
+  out->rad = rad; out->log2q = lq; out->log2n2 = log2p - lq;
+  return true;
 }
 
 struct Plan {
@@ -635,28 +718,32 @@ struct Plan {
   size_t lds_cols, lds_rows;
 };
 
-int32_t make_plan(int log2m, const void* t1, const void* t2, const void* tf, Plan* p) {
-  if (log2m < 4 || log2m > 22) return IRA_E_SIZE;
-  p->g.log2m = log2m;
-  p->g.log2n1 = split_log2n1(log2m);
-  p->g.log2n2 = log2m - p->g.log2n1;
+int32_t make_plan(int32_t m, const void* t1, const void* t2, const void* tf, Plan* p) {
+  Split sp;
+  if (!split_of(m, &sp)) return IRA_E_SIZE;
+  p->g.m = m;
+  p->g.rad = sp.rad;
+  p->g.log2q = sp.log2q;
+  p->g.n1 = sp.rad << sp.log2q;
+  p->g.log2n2 = sp.log2n2;
   p->g.t1 = static_cast<const cd*>(t1);
   p->g.t2 = static_cast<const cd*>(t2);
   p->g.tf = static_cast<const cd*>(tf);
   p->g.ablate = ira_tune_int("IRA_FFT_ABLATE", 0);
-  const int N1 = 1 << p->g.log2n1, N2 = 1 << p->g.log2n2;
+  const int N1 = p->g.n1, N2 = 1 << p->g.log2n2;
+  const size_t col = (size_t)sp.rad * ((1u << sp.log2q) + 1);            // LDS entries of one column (blocks of Q + 1)
   // ~32 KB of LDS per workgroup (C = R = 2 at N1 = N2 = 1024): measured fastest on MI355X -- 4 workgroups per CU
   // hide each other's barriers (rfft_any, 64 x 2^20: C/R = 4/4 2.75 ms, 2/2 2.39 ms, 1/1 2.92 ms)
   int C = 8;
-  while (C > 1 && (size_t)C * (N1 + 1) * sizeof(cd) > 33 * 1024) C >>= 1;
+  while (C > 1 && (size_t)C * col * sizeof(cd) > 33 * 1024) C >>= 1;
   if (C > N2) C = N2;
   int R = 1;
-  while (R * 2 * N2 * (int)sizeof(cd) <= 32 * 1024 && R * 2 <= N1 && R < 16) R <<= 1;
+  while (R * 2 * N2 * (int)sizeof(cd) <= 32 * 1024 && N1 % (R * 2) == 0 && R < 16) R <<= 1;
   { const int v = ira_tune_int("IRA_FFT_C", 0); if (v >= 1 && v <= N2 && v <= 64 && (v & (v - 1)) == 0) C = v; }   // tuning (power of two: K1 relies on FL_THREADS % C == 0)
-  { const int v = ira_tune_int("IRA_FFT_R", 0); if (v >= 1 && v <= N1) R = v; }
+  { const int v = ira_tune_int("IRA_FFT_R", 0); if (v >= 1 && v <= N1 && N1 % v == 0) R = v; }
   p->C = C;
   p->R = R;
-  p->lds_cols = ((size_t)C * (N1 + 1) + ira::TW_SPLIT_ENTRIES) * sizeof(cd);      // tile + two-level twiddle table
+  p->lds_cols = ((size_t)C * col + ira::TW_SPLIT_ENTRIES) * sizeof(cd);          // tile + two-level twiddle table
   p->lds_rows = ((size_t)R * N2 + ira::TW_SPLIT_ENTRIES) * sizeof(cd);
   return IRA_OK;
 }
@@ -676,7 +763,7 @@ hipError_t allow_lds(K kernel, size_t bytes) {
 
 template <int IN, int OUT>
 int32_t run_convolution(const Plan& p, const Jobs& J, cd* work, int nb, hipStream_t st) {
-  const int N1 = 1 << p.g.log2n1, N2 = 1 << p.g.log2n2;
+  const int N1 = p.g.n1, N2 = 1 << p.g.log2n2;
   IRA_TRY_HIP(allow_lds(cols_fwd_kernel<IN>, p.lds_cols));
   IRA_TRY_HIP(allow_lds(rows_kernel<ROW_CONV>, p.lds_rows));
   IRA_TRY_HIP(allow_lds(cols_inv_kernel<OUT>, p.lds_cols));
@@ -688,17 +775,17 @@ int32_t run_convolution(const Plan& p, const Jobs& J, cd* work, int nb, hipStrea
 
 }  // namespace
 
-extern "C" int32_t ira_bluestein_filter(const int32_t* L_dev, int32_t nfilt, int32_t log2m, const void* t1_dev,
+extern "C" int32_t ira_bluestein_filter(const int32_t* L_dev, int32_t nfilt, int32_t m, const void* t1_dev,
                                         const void* t2_dev, const void* tf_dev, double* bfilt_dev, void* stream) {
   IRA_CHECK_PTR(L_dev); IRA_CHECK_PTR(t1_dev); IRA_CHECK_PTR(t2_dev); IRA_CHECK_PTR(tf_dev); IRA_CHECK_PTR(bfilt_dev);
   if (nfilt <= 0) return nfilt == 0 ? IRA_OK : IRA_E_SIZE;
   Plan p;
-  int32_t rc = make_plan(log2m, t1_dev, t2_dev, tf_dev, &p);
+  int32_t rc = make_plan(m, t1_dev, t2_dev, tf_dev, &p);
   if (rc != IRA_OK) return rc;
   Jobs J{};
   J.L = L_dev;
   hipStream_t st = (hipStream_t)stream;
-  const int N1 = 1 << p.g.log2n1, N2 = 1 << p.g.log2n2;
+  const int N1 = p.g.n1, N2 = 1 << p.g.log2n2;
   IRA_TRY_HIP(allow_lds(cols_fwd_kernel<IN_FILTER>, p.lds_cols));
   IRA_TRY_HIP(allow_lds(rows_kernel<ROW_FWD>, p.lds_rows));
   cd* b = reinterpret_cast<cd*>(bfilt_dev);
@@ -708,7 +795,7 @@ extern "C" int32_t ira_bluestein_filter(const int32_t* L_dev, int32_t nfilt, int
 }
 
 extern "C" int32_t ira_rfft_any(const float* x_dev, const int64_t* xoff_dev, const int32_t* L_dev, int32_t nb,
-                                int32_t use_hann, int32_t log2m, const void* t1_dev, const void* t2_dev,
+                                int32_t use_hann, int32_t m, const void* t1_dev, const void* t2_dev,
                                 const void* tf_dev, const double* bfilt_dev, const int32_t* bidx_dev,
                                 double* work_dev, double* spec_out_dev, const int64_t* spec_off_dev,
                                 const int64_t* x2off_dev, const int64_t* spec_off2_dev, double* zpair_dev,
@@ -720,7 +807,7 @@ extern "C" int32_t ira_rfft_any(const float* x_dev, const int64_t* xoff_dev, con
   IRA_CHECK_PTR(spec_out_dev); IRA_CHECK_PTR(spec_off_dev);
   if (nb <= 0) return nb == 0 ? IRA_OK : IRA_E_SIZE;
   Plan p;
-  int32_t rc = make_plan(log2m, t1_dev, t2_dev, tf_dev, &p);
+  int32_t rc = make_plan(m, t1_dev, t2_dev, tf_dev, &p);
   if (rc != IRA_OK) return rc;
   Jobs J{};
   J.L = L_dev; J.x = x_dev; J.xoff = xoff_dev; J.use_hann = use_hann;
@@ -745,7 +832,7 @@ extern "C" int32_t ira_rfft_any(const float* x_dev, const int64_t* xoff_dev, con
 
 extern "C" int32_t ira_band_irfft(const double* spec_dev, const int64_t* spec_off_dev, const int32_t* L_dev,
                                   int32_t nb, const double* band_params_dev, const double* freq_val_dev,
-                                  int32_t log2m, const void* t1_dev, const void* t2_dev, const void* tf_dev,
+                                  int32_t m, const void* t1_dev, const void* t2_dev, const void* tf_dev,
                                   const double* bfilt_dev, const int32_t* bidx_dev, double* work_dev, float* y_dev,
                                   const int64_t* y1_off_dev, const int64_t* y2_off_dev,
                                   const int64_t* spec_off2_dev, void* stream) {
@@ -755,7 +842,7 @@ extern "C" int32_t ira_band_irfft(const double* spec_dev, const int64_t* spec_of
   IRA_CHECK_PTR(y1_off_dev); IRA_CHECK_PTR(y2_off_dev);
   if (nb <= 0) return nb == 0 ? IRA_OK : IRA_E_SIZE;
   Plan p;
-  int32_t rc = make_plan(log2m, t1_dev, t2_dev, tf_dev, &p);
+  int32_t rc = make_plan(m, t1_dev, t2_dev, tf_dev, &p);
   if (rc != IRA_OK) return rc;
   static_assert(sizeof(BandMask) == 8 * sizeof(double), "band parameter record is 8 doubles");
   Jobs J{};
@@ -767,10 +854,11 @@ extern "C" int32_t ira_band_irfft(const double* spec_dev, const int64_t* spec_of
   return run_convolution<IN_SPECTRUM, OUT_BANDS>(p, J, reinterpret_cast<cd*>(work_dev), nb, (hipStream_t)stream);
 }
 
-extern "C" int32_t ira_fft_split(int32_t log2m, int32_t* log2n1, int32_t* log2n2) {
-  IRA_CHECK_PTR(log2n1); IRA_CHECK_PTR(log2n2);
-  if (log2m < 4 || log2m > 22) return IRA_E_SIZE;
-  *log2n1 = split_log2n1(log2m);
-  *log2n2 = log2m - *log2n1;
+extern "C" int32_t ira_fft_split(int32_t m, int32_t* n1, int32_t* n2) {
+  IRA_CHECK_PTR(n1); IRA_CHECK_PTR(n2);
+  Split sp;
+  if (!split_of(m, &sp)) return IRA_E_SIZE;
+  *n1 = sp.rad << sp.log2q;
+  *n2 = 1 << sp.log2n2;
   return IRA_OK;
 }

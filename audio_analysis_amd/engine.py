@@ -585,18 +585,25 @@ class Engine:
     # ------------------------------------------------------------------ a9/a17: arbitrary-length f64 DFTs
     workspace_budget_bytes = 48 << 30   # cap for the Bluestein work + filter arrays of one chunk
 
-    @staticmethod
-    def log2m_for(length: int) -> int:
-        need = max(2 * int(length) - 1, 16)
-        return max(4, int(need - 1).bit_length())
+    # Convolution sizes the Bluestein kernels take: 2^k and 3 * 2^k.  three_pow2_sizes = False restricts the choice to
+    # powers of two (round 2's behaviour; A/B).
+    three_pow2_sizes = True
 
-    def long_tables(self, log2m: int):
-        key = ("long", log2m)
+    def conv_size_for(self, need: int) -> int:
+        """Smallest supported convolution size M >= need (a linear convolution of `need` distinct lags)."""
+        need = max(int(need), 16)
+        m = 1 << int(need - 1).bit_length()
+        if self.three_pow2_sizes and m >= 128 and 3 * (m >> 2) >= need:
+            m = 3 * (m >> 2)
+        return m
+
+    def long_tables(self, m: int):
+        key = ("long", int(m))
         if key not in self._tables:
             import ctypes
             l1, l2 = ctypes.c_int32(0), ctypes.c_int32(0)
-            check(self.lib.ira_fft_split(int(log2m), ctypes.byref(l1), ctypes.byref(l2)), "ira_fft_split")
-            n1, n2, m = 1 << l1.value, 1 << l2.value, 1 << log2m
+            check(self.lib.ira_fft_split(int(m), ctypes.byref(l1), ctypes.byref(l2)), "ira_fft_split")
+            n1, n2 = l1.value, l2.value
 
             def tab(count, period):
                 ang = -2.0 * np.pi * np.arange(count, dtype=np.float64) / float(period)
@@ -636,40 +643,62 @@ class Engine:
         for i in range(0, idx.size, step):
             yield idx[i : i + step]
 
-    def _chunks_by_log2m(self, lengths: np.ndarray):
-        """Group element indices by the FFT size they need, then cut each group to the workspace budget."""
-        l2 = np.array([self.log2m_for(int(v)) for v in lengths], dtype=np.int64)
-        for lm in sorted(set(l2.tolist())):
-            idx = np.nonzero(l2 == lm)[0]
-            per = (16 << lm) * 2                       # work + (worst case) one filter per element
+    def _chunks_by_size(self, need: np.ndarray):
+        """Group element indices by the convolution size they need, then cut each group to the workspace budget."""
+        ms = np.array([self.conv_size_for(int(v)) for v in need], dtype=np.int64)
+        for m in sorted(set(ms.tolist())):
+            idx = np.nonzero(ms == m)[0]
+            per = 16 * m * 2                           # work + (worst case) one filter per element
             step = max(1, int(self.workspace_budget_bytes // per))
             for i in range(0, idx.size, step):
-                yield int(lm), idx[i : i + step]
+                yield int(m), idx[i : i + step]
 
-    # Chirp-filter spectra depend only on (length, log2m): they are PLAN data, like twiddle tables, and are kept in a
-    # small LRU pool of device slots so that repeated lengths (every step of a batch job, every band pair of a
-    # file) do not rebuild them.  filter_cache_bytes = 0 disables the cache.
-    filter_cache_bytes = 8 << 30
+    # Chirp-filter spectra depend only on (length, M): they are PLAN data, like twiddle tables, and are kept in LRU pools
+    # of device slots -- one pool per (M, stream), all pools together within filter_cache_bytes -- so that repeated
+    # lengths (every step of a batch job, every band pair of a file) do not rebuild them.  A pool starts at twice the
+    # slots its first call needs and doubles when a call needs more; when the budget is full the pools used least
+    # recently are dropped.  filter_cache_bytes = 0 disables the cache.
+    filter_cache_bytes = 16 << 30
 
-    def _filters(self, lengths: np.ndarray, log2m: int):
+    def _filter_pool(self, m: int, need_slots: int):
+        """The pool for size m on the current stream with room for need_slots filters of one call, or None."""
+        t = self.torch
+        slot_doubles = 2 * int(m)
+        limit = int(self.filter_cache_bytes // (8 * slot_doubles))
+        if limit < need_slots:
+            return None
+        key = (int(m), int(self.stream))
+        self._filter_tick = getattr(self, "_filter_tick", 0) + 1
+        pool = self._filter_pools.get(key)
+        if pool is not None and pool["cap"] >= need_slots:
+            pool["last"] = self._filter_tick
+            return pool
+        cap = max(2 * need_slots, 32, 2 * pool["cap"] if pool is not None else 0)
+        cap = min(cap, limit)
+        self._filter_pools.pop(key, None)                  # a pool that grows starts again (its filters are rebuilt on demand)
+        total = lambda: sum(q["cap"] * 16 * k[0] for k, q in self._filter_pools.items())
+        while self._filter_pools and total() + cap * 8 * slot_doubles > self.filter_cache_bytes:
+            victim = min(self._filter_pools, key=lambda k: self._filter_pools[k]["last"])
+            del self._filter_pools[victim]
+        pool = dict(buf=self.empty(cap * slot_doubles, t.float64), slot_of={}, length_of=[None] * cap, tick=0,
+                    used=[0] * cap, cap=cap, last=self._filter_tick)
+        self._filter_pools[key] = pool
+        return pool
+
+    def _filters(self, lengths: np.ndarray, m: int):
         """Chirp-filter spectra for the distinct lengths in `lengths`; returns (bfilt device, bidx int32 host)."""
         t = self.torch
         uniq, inv = np.unique(lengths.astype(np.int32), return_inverse=True)
-        t1, t2, tf = self.long_tables(log2m)
-        slot_doubles = 2 << log2m
-        cap = int(self.filter_cache_bytes // (8 * slot_doubles))
-        if cap < uniq.size:                       # does not fit the pool: build a private array for this call
+        t1, t2, tf = self.long_tables(m)
+        slot_doubles = 2 * int(m)
+        pool = self._filter_pool(m, int(uniq.size))
+        if pool is None:                          # does not fit the budget: build a private array for this call
             bf = self.empty(int(uniq.size) * slot_doubles, t.float64)
             d_l = self.to_dev(uniq.astype(np.int32))
-            check(self.lib.ira_bluestein_filter(_ptr(d_l), int(uniq.size), log2m, _ptr(t1), _ptr(t2), _ptr(tf),
+            check(self.lib.ira_bluestein_filter(_ptr(d_l), int(uniq.size), int(m), _ptr(t1), _ptr(t2), _ptr(tf),
                                                 _ptr(bf), self.stream), "ira_bluestein_filter")
             return bf, inv.astype(np.int32)
-        pool_key = (log2m, int(self.stream))              # one pool per stream: slots are rebuilt and read in stream order
-        pool = self._filter_pools.get(pool_key)
-        if pool is None:
-            pool = dict(buf=self.empty(cap * slot_doubles, t.float64), slot_of={}, length_of=[None] * cap, tick=0,
-                        used=[0] * cap)
-            self._filter_pools[pool_key] = pool
+        cap = pool["cap"]
         pool["tick"] += 1
         tick = pool["tick"]
         slots = np.empty(uniq.size, dtype=np.int32)
@@ -704,7 +733,7 @@ class Engine:
                 run = todo[i : k + 1]
                 d_l = self.to_dev(np.array([ln for _, ln in run], dtype=np.int32))
                 dst = pool["buf"][run[0][0] * slot_doubles:]
-                check(self.lib.ira_bluestein_filter(_ptr(d_l), len(run), log2m, _ptr(t1), _ptr(t2), _ptr(tf), _ptr(dst),
+                check(self.lib.ira_bluestein_filter(_ptr(d_l), len(run), int(m), _ptr(t1), _ptr(t2), _ptr(tf), _ptr(dst),
                                                     self.stream), "ira_bluestein_filter")
                 i = k + 1
         return pool["buf"], slots[inv].astype(np.int32)
@@ -822,11 +851,15 @@ class Engine:
         e2 = np.concatenate([np.full(int(is_half.sum()), -1, dtype=np.int64), p2])
         half = np.concatenate([np.ones(int(is_half.sum()), dtype=bool), np.zeros(p1.size, dtype=bool)])
         jlen = np.where(half, lengths[e1] // 2, lengths[e1]).astype(np.int32)        # transform length of the job
-        for lm, sel in self._chunks_by_log2m(jlen):
+        # lags the convolution must keep apart: 2 l - 1 when all l outputs of a complex transform are wanted (half and
+        # paired jobs), l + l/2 for a single real signal (outputs k <= l/2 only)
+        jl64 = jlen.astype(np.int64)
+        need = np.where(half | (e2 >= 0), 2 * jl64 - 1, jl64 + jl64 // 2)
+        for lm, sel in self._chunks_by_size(need):
             t1, t2, tf = self.long_tables(lm)
             j1, j2, jh, jl = e1[sel], e2[sel], half[sel], jlen[sel]
             bf, bidx = self._filters(jl, lm)
-            work = self.empty(int(sel.size) * (2 << lm), t.float64)
+            work = self.empty(int(sel.size) * 2 * lm, t.float64)
             paired = j2 >= 0
             two = paired | jh                                   # jobs that carry a second "signal"
             safe = np.maximum(j2, 0)
@@ -918,11 +951,11 @@ class Engine:
         if not rest.any():
             return
         rest_idx = np.nonzero(rest)[0]
-        for lm, sub in self._chunks_by_log2m(jl[rest_idx]):
+        for lm, sub in self._chunks_by_size(2 * jl[rest_idx].astype(np.int64) - 1):
             sel = rest_idx[sub]
             t1, t2, tf = self.long_tables(lm)
             bf, bidx = self._filters(jl[sel], lm)
-            work = self.empty(int(sel.size) * (2 << lm), t.float64)
+            work = self.empty(int(sel.size) * 2 * lm, t.float64)
             d_so, d_l = self.to_dev(spec_off[j1][sel]), self.to_dev(jl[sel])
             d_bp = self.to_dev(np.ascontiguousarray(el_par[sel]))
             d_fv = self.to_dev(np.ascontiguousarray(freq_val[j1][sel]))

@@ -33,7 +33,7 @@ extern "C" {
 #define IRA_E_FORMAT (-5)     /* a file is not RIFF/WAVE (host-side ingest entry points only) */
 #define IRA_E_HIP_BASE (-1000)
 
-#define IRA_ABI_VERSION 3   /* bumped whenever an exported signature or a scratch-size constant changes */
+#define IRA_ABI_VERSION 4   /* bumped whenever an exported signature or a scratch-size constant changes */
 
 int32_t ira_abi_version(void);
 const char* ira_error_string(int32_t code);
@@ -153,20 +153,23 @@ int32_t ira_stft_logbin(const float* x_dev, const int64_t* off_dev, const int32_
                         const int32_t* first_dev, const int32_t* count_dev, int32_t nbins, float* curves_dev,
                         const int64_t* curves_off_dev, void* stream);
 
-/* ---- a9/a17: arbitrary-length float64 DFTs (Bluestein over a four-step power-of-two FFT) ---------------
- * Common arguments: log2m with M = 2^log2m >= 2*max(L) - 1 (4 <= log2m <= 22); three caller-provided
- * complex-f64 tables for M = N1*N2 with the split ira_fft_split() reports (N1 = 2^log2n1, N2 = 2^log2n2):
+/* ---- a9/a17: arbitrary-length float64 DFTs (Bluestein over a four-step FFT of size M) -------------------
+ * Common arguments: the convolution size m = M, a power of two (16 <= M <= 2^22) or three times one
+ * (96 <= M <= 3*2^20), with M >= 2*max(L) - 1 -- or only M >= L + L/2 for ira_rfft_any elements that carry ONE real
+ * signal (no x2off / interleave): their L/2+1 bins do not see the wrap-around; three caller-provided
+ * complex-f64 tables for M = N1*N2 with the split ira_fft_split() reports (N2 a power of two, N1 one or 3x one):
  *   t1_dev[k] = exp(-2 pi i k/N1), k < N1;  t2_dev[k] = exp(-2 pi i k/N2), k < N2;
  *   tf_dev[k] = exp(-2 pi i k/M),  k < N2.
- * work_dev: nb * M complex f64 of scratch.  bfilt_dev: chirp-filter spectra built by ira_bluestein_filter,
- * M complex f64 each; bidx_dev[e] selects the filter (the one built for length L[e]) of element e. */
+ * work_dev: nb * M complex f64 of scratch.  bfilt_dev: chirp-filter spectra built by ira_bluestein_filter
+ * FOR THE SAME M, M complex f64 each; bidx_dev[e] selects the filter (the one built for length L[e]) of element e. */
 
-/* The four-step split the library uses for M = 2^log2m (host code sizes t1/t2/tf from it).  No reference
- * counterpart: numpy's pocketfft plans internally (reference analyse/frequency_response.py:204). */
-int32_t ira_fft_split(int32_t log2m, int32_t* log2n1, int32_t* log2n2);
+/* The four-step split the library uses for size m (host code sizes t1/t2/tf from it); IRA_E_SIZE if m is not a
+ * supported size.  No reference counterpart: numpy's pocketfft plans internally (reference
+ * analyse/frequency_response.py:204). */
+int32_t ira_fft_split(int32_t m, int32_t* n1, int32_t* n2);
 
 /* bfilt_dev[j] = FFT_M of the Bluestein chirp filter for length L_dev[j], j < nfilt. */
-int32_t ira_bluestein_filter(const int32_t* L_dev, int32_t nfilt, int32_t log2m, const void* t1_dev,
+int32_t ira_bluestein_filter(const int32_t* L_dev, int32_t nfilt, int32_t m, const void* t1_dev,
                              const void* t2_dev, const void* tf_dev, double* bfilt_dev, void* stream);
 
 /* spec_out[e][k] = sum_n x[xoff[e]+n] * (hanning(L[e])[n] | 1) * exp(-2 pi i n k / L[e]),  k = 0..L[e]/2,
@@ -187,7 +190,7 @@ int32_t ira_bluestein_filter(const int32_t* L_dev, int32_t nfilt, int32_t log2m,
  * transform size; its L[e]+1 spectrum bins go to spec_off_dev[e].  Window lengths then refer to the real signal
  * (win_len = 2*L[e]). */
 int32_t ira_rfft_any(const float* x_dev, const int64_t* xoff_dev, const int32_t* L_dev, int32_t nb,
-                     int32_t use_hann, int32_t log2m, const void* t1_dev, const void* t2_dev,
+                     int32_t use_hann, int32_t m, const void* t1_dev, const void* t2_dev,
                      const void* tf_dev, const double* bfilt_dev, const int32_t* bidx_dev,
                      double* work_dev, double* spec_out_dev, const int64_t* spec_off_dev,
                      const int64_t* x2off_dev, const int64_t* spec_off2_dev, double* zpair_dev,
@@ -207,7 +210,7 @@ int32_t ira_rfft_any(const float* x_dev, const int64_t* xoff_dev, const int32_t*
 #define IRA_BAND_DOUBLES 8
 int32_t ira_band_irfft(const double* spec_dev, const int64_t* spec_off_dev, const int32_t* L_dev,
                        int32_t nb, const double* band_params_dev, const double* freq_val_dev,
-                       int32_t log2m, const void* t1_dev, const void* t2_dev, const void* tf_dev,
+                       int32_t m, const void* t1_dev, const void* t2_dev, const void* tf_dev,
                        const double* bfilt_dev, const int32_t* bidx_dev, double* work_dev, float* y_dev,
                        const int64_t* y1_off_dev, const int64_t* y2_off_dev,
                        const int64_t* spec_off2_dev, void* stream);

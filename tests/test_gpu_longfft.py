@@ -111,6 +111,59 @@ def test_even_lengths_use_the_half_size_transform_and_match_unpacked():
             assert np.max(np.abs(g - g2)) / np.max(np.abs(ref)) < 1e-13
 
 
+def test_convolution_sizes_three_times_a_power_of_two():
+    """
+    Bluestein over M = 3 * 2^k (radix-3 column stage) and the reduced size rule for single real signals (M >= L + L/2: the
+    wrap-around never reaches bins k <= L/2): lengths sitting exactly on both sides of the size boundaries, against
+    numpy.fft.rfft and against the power-of-two sizes of round 2.
+    """
+    from audio_analysis_amd.engine import get_engine
+    eng = get_engine()
+    rng = np.random.default_rng(21)
+    n = 100000
+    x = (rng.standard_normal(n) * np.exp(-np.arange(n) / 12000.0)).astype(np.float32)
+    assert eng.three_pow2_sizes
+    # the rule itself
+    assert eng.conv_size_for(65535 + 65535 // 2) == 3 << 15          # odd single, tight: 98302 lags in M = 98304
+    assert eng.conv_size_for(65537 + 65537 // 2) == 1 << 17          # one sample more: next size
+    assert eng.conv_size_for(2 * 49151 - 1) == 3 << 15               # half-length job of L = 98302
+    assert eng.conv_size_for(2 * 239750 - 1) == 1 << 19 and eng.conv_size_for(479501 + 479501 // 2) == 3 << 18
+    assert eng.conv_size_for(97 + 48) == 192 and eng.conv_size_for(20) == 32
+    lengths = [65535, 65537, 98302, 97, 33, 4099, 23003, 69997, 2 * 37 * 311, 99991, 32771, 49153, 2 * 24571]
+    assert all(eng.smooth_split(int(v)) is None for v in lengths)
+    for hann in (False, True):
+        got = _spec(eng, x, lengths, hann)
+        try:
+            eng.three_pow2_sizes = False
+            old = _spec(eng, x, lengths, hann)
+        finally:
+            eng.three_pow2_sizes = True
+        for L, g, g2 in zip(lengths, got, old):
+            seg = x[:L].astype(np.float64)
+            if hann:
+                seg = seg * np.hanning(L)
+            ref = np.fft.rfft(seg)
+            scale = np.max(np.abs(ref))
+            err = np.max(np.abs(g[:, 0] + 1j * g[:, 1] - ref)) / scale
+            assert err < 5e-14, (L, hann, err)
+            assert g[0, 1] == 0.0 and (L % 2 == 1 or g[-1, 1] == 0.0)
+            assert np.max(np.abs(g - g2)) / scale < 1e-13, (L, hann)
+    # two signals per transform (all L outputs wanted): the full 2L - 1 rule, still on 3 * 2^k where it fits
+    chans = [x[:40000].copy(), x[30000:70000].copy()]
+    b = eng.upload(chans)
+    try:
+        eng.pair_across_channels = True
+        lens = np.array([24571, 24571], np.int32)                     # 2 L - 1 = 49141 -> M = 49152 = 3 * 2^14
+        spec, off = eng.rfft_any(b.x, b.off, lens, True)
+    finally:
+        eng.pair_across_channels = False
+    h = spec.cpu().numpy()
+    for c, o in zip(chans, off):
+        ref = np.fft.rfft(c[:24571].astype(np.float64) * np.hanning(24571))
+        g = h[2 * o : 2 * (o + 24571 // 2 + 1)].reshape(-1, 2)
+        assert np.max(np.abs(g[:, 0] + 1j * g[:, 1] - ref)) / np.max(np.abs(ref)) < 5e-14
+
+
 def test_smooth_lengths_take_the_direct_transform_and_match_numpy():
     """n = 2^a 3^b 5^c: two-pass mixed-radix four-step (ira_rfft_smooth) against numpy and against Bluestein."""
     from audio_analysis_amd.engine import get_engine
