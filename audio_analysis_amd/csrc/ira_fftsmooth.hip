@@ -47,6 +47,8 @@ struct SmoothPlan {
   const cd* t1;                     // exp(-2 pi i k / N1), k < N1
   const cd* t2;                     // exp(-2 pi i k / N2), k < N2
   const cd* tf;                     // exp(-2 pi i k / n),  k < N2
+  double hstep_c, hstep_s;          // half-size inverse: cos / sin of pi (256 / c1) / n1, the step of the W_2n^(-i) twiddle
+                                    // between a thread's consecutive pass-1 elements (valid when 256 % c1 == 0)
   int inplace;                      // 1: single LDS buffer, in-place passes (default); 0: ping-pong Stockham (A/B)
   int stamp;                        // diagnostics (IRA_SMOOTH_STAMP): per-phase cycle counts of one workgroup per kernel
 };
@@ -403,14 +405,14 @@ __device__ __forceinline__ void r_load2(const SJobs& J, const SCtx& c, long long
   r.a = xa.re; r.b = xa.im; r.c = xb.re; r.d = xb.im;
 }
 
-template <int MODE>
+template <int MODE, bool HALF>
 __device__ __forceinline__ RawIn smooth_fetch(const SmoothPlan& P, const SJobs& J, const SCtx& c, long long i) {
   RawIn r{0.0, 0.0, 0.0, 0.0, 0.0f, 0.0f};
   const long long n = P.n;
   if (MODE == SM_SIGNAL) {
     r.fa = *(i < c.nd1 ? J.x + c.o1 + c.st * i : J.x);
     r.fb = *((c.o2 >= 0 && i < c.nd2) ? J.x + c.o2 + c.st * i : J.x);       // no branch around it either (same reason)
-  } else if (J.half_out) {
+  } else if (HALF) {
     // half-size inverse of ONE band: element i needs the masked bins i and n - i of the (n + 1)-bin half spectrum
     const long long k2 = n - i;
     r_load2(J, c, i, k2, r);
@@ -433,8 +435,12 @@ __device__ __forceinline__ RawIn smooth_fetch(const SmoothPlan& P, const SJobs& 
   return r;
 }
 
-template <int MODE>
-__device__ __forceinline__ cd smooth_value(const SmoothPlan& P, const SJobs& J, const SCtx& c, long long i, const RawIn& r) {
+// (HALF: cs + i sn = W_2n^(-i) = exp(+i pi i / n), from the caller -- one sincospi per thread and a rotation per element
+// instead of a sincospi per element, which was most of the half-size pass-1 input stage: 256 half-size jobs took as long
+// as 256 full-size ones)
+template <int MODE, bool HALF>
+__device__ __forceinline__ cd smooth_value(const SmoothPlan& P, const SJobs& J, const SCtx& c, long long i, const RawIn& r,
+                                           double cs, double sn) {
   const long long n = P.n;
   if (MODE == SM_SIGNAL) {
     double v = i < c.nd1 ? (double)r.fa : 0.0, v2 = (c.o2 >= 0 && i < c.nd2) ? (double)r.fb : 0.0;
@@ -443,7 +449,7 @@ __device__ __forceinline__ cd smooth_value(const SmoothPlan& P, const SJobs& J, 
       if (c.o2 >= 0) v2 *= hann_s(c.st * i + (c.st - 1), c.lw2);
     }
     return {v, v2};
-  } else if (J.half_out) {
+  } else if (HALF) {
     // One band y of 2 n real samples from an n-point transform: with Xm = X * mask (n + 1 bins),
     //   E[i] = (Xm[i] + conj Xm[n-i]) / 2,  O[i] = W_2n^(-i) (Xm[i] - conj Xm[n-i]) / 2,  Z = E + i O,
     //   y[2 m] + i y[2 m + 1] = IDFT_n(Z)[m]        (inverse = conj(DFT(conj .)) / n: feed conj(Z))
@@ -452,9 +458,7 @@ __device__ __forceinline__ cd smooth_value(const SmoothPlan& P, const SJobs& J, 
     const cd xa = {r.a * ma, r.b * ma}, xb = {r.c * mb, -r.d * mb};            // Xm[i], conj Xm[n - i]
     const cd e = {0.5 * (xa.re + xb.re), 0.5 * (xa.im + xb.im)};
     const cd d = {0.5 * (xa.re - xb.re), 0.5 * (xa.im - xb.im)};
-    double sn, cs;
-    sincospi((double)i / (double)n, &sn, &cs);                                  // W_2n^(-i) = exp(+i pi i / n)
-    const cd o = {cs * d.re - sn * d.im, cs * d.im + sn * d.re};
+    const cd o = {cs * d.re - sn * d.im, cs * d.im + sn * d.re};                // W_2n^(-i) d
     const cd z = {e.re - o.im, e.im + o.re};                                     // E + i O
     return {z.re, -z.im};
   } else {
@@ -492,7 +496,7 @@ __device__ __forceinline__ void smooth_remap(unsigned& bx, unsigned& by) {
 #define SM_STAMP(var) do { if (P.stamp) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } } while (0)
 
 // ---- pass 1: columns.  grid (N2 / C, jobs) ------------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, bool HALF = false>
 __global__ __launch_bounds__(SM_THREADS, (MODE == SM_SIGNAL ? 6 : 5)) void smooth_cols_kernel(SmoothPlan P, SJobs J, cd* __restrict__ work) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cd* a = reinterpret_cast<cd*>(smem);
@@ -518,13 +522,24 @@ __global__ __launch_bounds__(SM_THREADS, (MODE == SM_SIGNAL ? 6 : 5)) void smoot
       return (long long)row * N2 + n2_0 + (i - row * C);
     };
 #pragma unroll
-    for (int u = 0; u < SM_UC; ++u) raw[u] = smooth_fetch<MODE>(P, J, ctx, index_of(u));
+    for (int u = 0; u < SM_UC; ++u) raw[u] = smooth_fetch<MODE, HALF>(P, J, ctx, index_of(u));
+    // half-size inverse: the twiddle exp(i pi idx / n) of the thread's first element of this batch (issued under the loads);
+    // with 256 % C == 0 a thread's elements are (256 / C) rows apart and the next ones follow by rotation
+    double cs = 1.0, sn = 0.0;
+    const bool rotate = HALF && (SM_THREADS % C) == 0;
+    if (HALF && rotate) sincospi((double)index_of(0) / (double)P.n, &sn, &cs);
 #pragma unroll
     for (int u = 0; u < SM_UC; ++u) {
       const int i = base + tid + SM_THREADS * u;
-      const cd v = smooth_value<MODE>(P, J, ctx, index_of(u), raw[u]);
+      if (HALF && !rotate) sincospi((double)index_of(u) / (double)P.n, &sn, &cs);
+      const cd v = smooth_value<MODE, HALF>(P, J, ctx, index_of(u), raw[u], cs, sn);
       const int row = (int)fdiv((unsigned)i, P.dc1);
       if (i < total1) a[(i - row * C) * LD + row] = v;
+      if (HALF && rotate) {
+        const double nc = cs * P.hstep_c - sn * P.hstep_s;
+        sn = sn * P.hstep_c + cs * P.hstep_s;
+        cs = nc;
+      }
     }
   }
   twiddle_lds_put(twl, twv, tid);
@@ -804,6 +819,11 @@ int32_t make_smooth_plan(int32_t n, const void* t1, const void* t2, const void* 
   for (int i = 0, span = n2; i < P->nr2; ++i) { span /= P->r2[i]; P->dr2[i] = fast_div_of((unsigned)P->r2[i]); P->span2[i] = span; }
   P->t1 = static_cast<const cd*>(t1); P->t2 = static_cast<const cd*>(t2); P->tf = static_cast<const cd*>(tf);
   P->stamp = ira_tune_flag("IRA_SMOOTH_STAMP");
+  {
+    const double step = 3.14159265358979323846 * (double)(SM_THREADS / P->c1) / (double)n1;
+    P->hstep_c = std::cos(step);
+    P->hstep_s = std::sin(step);
+  }
   return IRA_OK;
 }
 
@@ -891,10 +911,12 @@ extern "C" int32_t ira_band_irfft_smooth(const double* spec_dev, const int64_t* 
   hipStream_t st = (hipStream_t)stream;
   const size_t nbuf = P.inplace ? 1 : 2;
   const size_t l1 = (nbuf * P.c1 * P.ld1 + SM_TW) * sizeof(cd), l2 = (nbuf * P.c2 * P.ld2 + SM_TW) * sizeof(cd);
-  SM_TRY(allow(smooth_cols_kernel<SM_SPECTRUM>, l1));
+  SM_TRY(allow(smooth_cols_kernel<SM_SPECTRUM, false>, l1));
+  SM_TRY(allow(smooth_cols_kernel<SM_SPECTRUM, true>, l1));
   SM_TRY(allow(smooth_rows_kernel<SM_OUT_BANDS>, l2));
   cd* work = reinterpret_cast<cd*>(work_dev);
-  smooth_cols_kernel<SM_SPECTRUM><<<dim3(P.n2 / P.c1, nb), SM_THREADS, l1, st>>>(P, J, work);
+  if (half_out) smooth_cols_kernel<SM_SPECTRUM, true><<<dim3(P.n2 / P.c1, nb), SM_THREADS, l1, st>>>(P, J, work);
+  else smooth_cols_kernel<SM_SPECTRUM, false><<<dim3(P.n2 / P.c1, nb), SM_THREADS, l1, st>>>(P, J, work);
   smooth_rows_kernel<SM_OUT_BANDS><<<dim3(P.n1 / P.c2, nb), SM_THREADS, l2, st>>>(P, J, work);
   IRA_RETURN_LAUNCH();
 }
