@@ -38,6 +38,7 @@ __device__ __forceinline__ unsigned fdiv(unsigned x, FastDiv f) { return f.d <= 
 struct SmoothPlan {
   int n, n1, n2;
   FastDiv dc1, dc2, dn1, dn2;       // the same numbers as divisors
+  FastDiv dper1[12], dper2[12];     // butterflies per transform and pass (N / r_i) as divisors
   FastDiv dr1[12], dr2[12];         // radices as divisors, and the span N / (r_0 ... r_i) of digit i after lds_fft_dif_inplace
   int span1[12], span2[12];
   int c1, c2;                       // columns per workgroup in pass 1 / pass 2
@@ -222,15 +223,20 @@ __device__ cd* lds_fft_stockham(cd* a, cd* b, int N, const int* radices, int nra
 // digit-reversed slot k_0 (N / r_0) + k_1 (N / (r_0 r_1)) + ...; the consumers ask dif_slot() where a k lives.
 // Half the LDS per tile means twice the columns per workgroup at the same number of resident workgroups: the passes are a
 // closed queue of tiles cycling between a memory phase and an LDS phase, and what is in flight per CU is what LDS holds.
+// (The butterflies of ALL nbat transforms are dealt to the threads in one sweep: a transform has only N / R = 64 ... 100 of
+// them, and one transform after the other left three quarters of the 256 lanes idle in each of nbat dependent rounds.)
 template <int R>
-__device__ __forceinline__ void dif_pass(cd* x, int N, int ld, int len, const cd* __restrict__ tw, int tid, int nbat) {
-  const int per = N / R;                        // butterflies per transform
+__device__ __forceinline__ void dif_pass(cd* x, int N, int ld, int len, FastDiv dper, const cd* __restrict__ tw, int tid,
+                                         int nbat) {
+  const int per = (int)dper.d;                  // butterflies per transform (N / R)
   const int m = len / R;
   const int scale = N / len;                    // W_len^(p k) = W_N^(scale p k)
   const unsigned magic = (unsigned)(0x100000000ull / (unsigned)m) + 1u;      // bf / m for bf < 2^16
-  for (int t = 0; t < nbat; ++t) {
-    cd* xt = x + t * ld;
-    for (int bf = tid; bf < per; bf += SM_THREADS) {
+  {
+    for (int g = tid; g < per * nbat; g += SM_THREADS) {
+      const int t = (int)fdiv((unsigned)g, dper);
+      const int bf = g - t * per;
+      cd* xt = x + t * ld;
       const int blk = m == 1 ? bf : (int)__umulhi((unsigned)bf, magic);
       const int p = bf - blk * m;
       cd* base = xt + blk * len + p;
@@ -257,19 +263,20 @@ __device__ __forceinline__ void dif_pass(cd* x, int N, int ld, int len, const cd
   __syncthreads();
 }
 
-__device__ void lds_fft_dif_inplace(cd* a, int N, int ld, const int* radices, int nrad, const cd* __restrict__ tw, int tid,
-                                    int nbat) {
+__device__ void lds_fft_dif_inplace(cd* a, int N, int ld, const int* radices, const FastDiv* dper, int nrad,
+                                    const cd* __restrict__ tw, int tid, int nbat) {
   int len = N;
   for (int pass = 0; pass < nrad; ++pass) {
     const int r = radices[pass];
+    const FastDiv dp = dper[pass];
     switch (r) {
-      case 10: dif_pass<10>(a, N, ld, len, tw, tid, nbat); break;
-      case 8: dif_pass<8>(a, N, ld, len, tw, tid, nbat); break;
-      case 6: dif_pass<6>(a, N, ld, len, tw, tid, nbat); break;
-      case 5: dif_pass<5>(a, N, ld, len, tw, tid, nbat); break;
-      case 4: dif_pass<4>(a, N, ld, len, tw, tid, nbat); break;
-      case 3: dif_pass<3>(a, N, ld, len, tw, tid, nbat); break;
-      default: dif_pass<2>(a, N, ld, len, tw, tid, nbat); break;
+      case 10: dif_pass<10>(a, N, ld, len, dp, tw, tid, nbat); break;
+      case 8: dif_pass<8>(a, N, ld, len, dp, tw, tid, nbat); break;
+      case 6: dif_pass<6>(a, N, ld, len, dp, tw, tid, nbat); break;
+      case 5: dif_pass<5>(a, N, ld, len, dp, tw, tid, nbat); break;
+      case 4: dif_pass<4>(a, N, ld, len, dp, tw, tid, nbat); break;
+      case 3: dif_pass<3>(a, N, ld, len, dp, tw, tid, nbat); break;
+      default: dif_pass<2>(a, N, ld, len, dp, tw, tid, nbat); break;
     }
     len /= r;
   }
@@ -479,6 +486,18 @@ __device__ __forceinline__ cd smooth_value(const SmoothPlan& P, const SJobs& J, 
   }
 }
 
+// SM_SPECTRUM: can element i of the transform be non-zero at all (is one of the bins it reads inside a band's support)?
+template <bool HALF>
+__device__ __forceinline__ bool smooth_nonzero(const SmoothPlan& P, const SCtx& c, long long i) {
+  const long long n = P.n;
+  if (HALF) {
+    const long long k2 = n - i;
+    return (i >= c.s1_lo && i < c.s1_hi) || (k2 >= c.s1_lo && k2 < c.s1_hi);
+  }
+  const long long k = i > n / 2 ? n - i : i;
+  return (k >= c.s1_lo && k < c.s1_hi) || (k >= c.s2_lo && k < c.s2_hi);
+}
+
 constexpr int SM_U = 8;     // independent loads in flight per thread (pass 2)
 constexpr int SM_UC = 5;    // (pass 1: a fetch is up to four doubles; 640 x 2 columns = 5 x 256: ONE round of loads)
 
@@ -497,7 +516,7 @@ __device__ __forceinline__ void smooth_remap(unsigned& bx, unsigned& by) {
 
 // ---- pass 1: columns.  grid (N2 / C, jobs) ------------------------------------------------------------------------------
 template <int MODE, bool HALF = false>
-__global__ __launch_bounds__(SM_THREADS, (MODE == SM_SIGNAL ? 6 : 5)) void smooth_cols_kernel(SmoothPlan P, SJobs J, cd* __restrict__ work) {
+__global__ __launch_bounds__(SM_THREADS, ((MODE == SM_SIGNAL || !HALF) ? 6 : 5)) void smooth_cols_kernel(SmoothPlan P, SJobs J, cd* __restrict__ work) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cd* a = reinterpret_cast<cd*>(smem);
   const int C = P.c1, N1 = P.n1, N2 = P.n2;
@@ -532,7 +551,12 @@ __global__ __launch_bounds__(SM_THREADS, (MODE == SM_SIGNAL ? 6 : 5)) void smoot
     for (int u = 0; u < SM_UC; ++u) {
       const int i = base + tid + SM_THREADS * u;
       if (HALF && !rotate) sincospi((double)index_of(u) / (double)P.n, &sn, &cs);
-      const cd v = smooth_value<MODE, HALF>(P, J, ctx, index_of(u), raw[u], cs, sn);
+      // A third-octave band occupies a few per cent of the spectrum: when no lane of the wave holds a bin inside a band's
+      // support the masks, the Hermitian extension and the products (~80 of the ~280 instructions per element of this
+      // kernel) are skipped and the element is zero -- what the multiplication by the zero masks gives.
+      cd v = {0.0, 0.0};
+      if (MODE != SM_SPECTRUM || __builtin_amdgcn_ballot_w64(smooth_nonzero<HALF>(P, ctx, index_of(u))) != 0ull)
+        v = smooth_value<MODE, HALF>(P, J, ctx, index_of(u), raw[u], cs, sn);
       const int row = (int)fdiv((unsigned)i, P.dc1);
       if (i < total1) a[(i - row * C) * LD + row] = v;
       if (HALF && rotate) {
@@ -546,7 +570,7 @@ __global__ __launch_bounds__(SM_THREADS, (MODE == SM_SIGNAL ? 6 : 5)) void smoot
   __syncthreads();
   SM_STAMP(s1);
   const cd* r = a;
-  if (P.inplace) lds_fft_dif_inplace(a, N1, LD, P.r1, P.nr1, twl, tid, C);
+  if (P.inplace) lds_fft_dif_inplace(a, N1, LD, P.r1, P.dper1, P.nr1, twl, tid, C);
   else r = lds_fft_stockham(a, b, N1, P.r1, P.nr1, twl, tid, C);
   SM_STAMP(s2);
   cd* w = work + (long long)e * P.n;
@@ -634,7 +658,7 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_rows_kernel(SmoothPlan P, S
   __syncthreads();
   SM_STAMP(s1);
   const cd* r = a;
-  if (P.inplace) lds_fft_dif_inplace(a, N2, LD, P.r2, P.nr2, twl, tid, C);
+  if (P.inplace) lds_fft_dif_inplace(a, N2, LD, P.r2, P.dper2, P.nr2, twl, tid, C);
   else r = lds_fft_stockham(a, b, N2, P.r2, P.nr2, twl, tid, C);
   SM_STAMP(s2);
   const long long n = P.n;
@@ -815,8 +839,8 @@ int32_t make_smooth_plan(int32_t n, const void* t1, const void* t2, const void* 
   P->ld2 = P->inplace ? column_stride(n2, P->c2) : n2;
   P->dc1 = fast_div_of((unsigned)P->c1); P->dc2 = fast_div_of((unsigned)P->c2);
   P->dn1 = fast_div_of((unsigned)n1); P->dn2 = fast_div_of((unsigned)n2);
-  for (int i = 0, span = n1; i < P->nr1; ++i) { span /= P->r1[i]; P->dr1[i] = fast_div_of((unsigned)P->r1[i]); P->span1[i] = span; }
-  for (int i = 0, span = n2; i < P->nr2; ++i) { span /= P->r2[i]; P->dr2[i] = fast_div_of((unsigned)P->r2[i]); P->span2[i] = span; }
+  for (int i = 0, span = n1; i < P->nr1; ++i) { span /= P->r1[i]; P->dr1[i] = fast_div_of((unsigned)P->r1[i]); P->span1[i] = span; P->dper1[i] = fast_div_of((unsigned)(n1 / P->r1[i])); }
+  for (int i = 0, span = n2; i < P->nr2; ++i) { span /= P->r2[i]; P->dr2[i] = fast_div_of((unsigned)P->r2[i]); P->span2[i] = span; P->dper2[i] = fast_div_of((unsigned)(n2 / P->r2[i])); }
   P->t1 = static_cast<const cd*>(t1); P->t2 = static_cast<const cd*>(t2); P->tf = static_cast<const cd*>(tf);
   P->stamp = ira_tune_flag("IRA_SMOOTH_STAMP");
   {

@@ -402,29 +402,31 @@ __global__ __launch_bounds__(TL5) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   // ---- step 3: lane r = q holds Z[r + 256 k3] at v[brev(k3)] ----------------------------------------------------------
   dft_dif<double, 16>(v);
 
-  // ---- E3: real parts, then imaginary parts, natural order ------------------------------------------------------------
+  // ---- E3: the mirror partners only.  The post step pairs Z[k] with Z[M - k]; lane q keeps k = q + 256 i, i < 8, which it
+  // already holds (v[brev(i)]), and M - k = (256 - q) + 256 (15 - i) is entry k3 = 15 - i >= 8 of lane 256 - q: every lane
+  // publishes its upper eight values and reads eight of its partner's -- 256 bytes per lane through LDS and one barrier pair
+  // instead of the 512 bytes and two of the round-2 natural-order exchange (real parts, then imaginary parts, own values
+  // included).  Lane 0 pairs with itself: M - 256 i = 256 (16 - i), its own entry 16 - i; i = 0 pairs Z[0] with Z[0].
   double zkr[8], zpr[8], zki[8], zpi[8], midr, midi;
 #pragma unroll
-  for (int k3 = 0; k3 < 16; ++k3) exd[q + 256 * k3] = v[brev_bits(k3, 4)].re;
+  for (int j = 0; j < 8; ++j) ex[j * TL5 + q] = v[brev_bits(8 + j, 4)];       // k3 = 8 + j
   __syncthreads();
+  {
+    const int partner = (TL5 - q) & (TL5 - 1);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int k = q + TL5 * i;
-    zkr[i] = exd[k];
-    zpr[i] = exd[(M4 - k) & (M4 - 1)];
+    for (int i = 0; i < 8; ++i) {
+      // partner entry k3 = 15 - i (slot 7 - i); lane 0: k3 = 16 - i (slot 8 - i), i = 0 -> Z[0] itself
+      const int slot = q == 0 ? 8 - i : 7 - i;
+      cdd zp = v[0];                                                             // Z[0] (lane 0, i = 0)
+      if (!(q == 0 && i == 0)) zp = ex[slot * TL5 + partner];
+      zkr[i] = v[brev_bits(i, 4)].re; zki[i] = v[brev_bits(i, 4)].im;
+      zpr[i] = zp.re; zpi[i] = zp.im;
+    }
   }
-  midr = exd[M4 / 2];
-  __syncthreads();
-#pragma unroll
-  for (int k3 = 0; k3 < 16; ++k3) exd[q + 256 * k3] = v[brev_bits(k3, 4)].im;
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int k = q + TL5 * i;
-    zki[i] = exd[k];
-    zpi[i] = exd[(M4 - k) & (M4 - 1)];
+  {
+    const cdd mid = ex[0];                                                       // Z[2048]: lane 0, k3 = 8
+    midr = mid.re; midi = mid.im;
   }
-  midi = exd[M4 / 2];
   if (q == 0) frame_bad = !((zkr[0] - zkr[0]) + (zki[0] - zki[0]) == 0.0) ? 1 : 0;   // NaN / infinity in the frame (see v4)
   __syncthreads();                                            // E3 fully read; frame_bad, lb_range visible
   const bool bad_frame = frame_bad != 0;
@@ -496,7 +498,9 @@ __global__ __launch_bounds__(TL5) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int u = 0; u < 8; ++u)
           if (k0 + u < c) acc += v8[u];
       }
-      val = (float)(20.0 * log10(fmax(acc / (double)c, 1e-30)));
+      // 20 log10 m through the table log2 (series to r^6: a few 1e-16 relative, invisible after the float32 rounding) --
+      // the library log10 was ~130 of the ~1800 instructions of every wave although only 240 lanes of a frame use it
+      val = (float)(6.0205999132796239 * ira::log2_table<6>(fmax(acc / (double)c, 1e-30), ltab));
     }
     co[(int64_t)bb * T_out + col] = (bad_frame && c > 0) ? qnan32 : val;
   }
