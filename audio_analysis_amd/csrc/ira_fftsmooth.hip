@@ -52,6 +52,10 @@ struct SmoothPlan {
                                     // between a thread's consecutive pass-1 elements (valid when 256 % c1 == 0)
   int inplace;                      // 1: single LDS buffer, in-place passes (default); 0: ping-pong Stockham (A/B)
   int stamp;                        // diagnostics (IRA_SMOOTH_STAMP): per-phase cycle counts of one workgroup per kernel
+  int ablate;                       // diagnostics (IRA_SMOOTH_ABLATE, timing only -- results are wrong): 1 pass-2 band output
+                                    // written tile-major (contiguous per workgroup), 2 pass-1 output contiguous, 4 pass-1
+                                    // spectrum gather contiguous, 8 / 16 no transform in pass 1 / 2, 32 no input arithmetic
+                                    // in pass 1 (tools/smooth_ablate.sh, profiles/r03_smooth_ablation.txt)
 };
 
 // ---- radix butterflies, forward sign (W = exp(-2 pi i / r)), natural order in and out, registers only -------------------
@@ -537,6 +541,7 @@ __global__ __launch_bounds__(SM_THREADS, ((MODE == SM_SIGNAL || !HALF) ? 6 : 5))
     auto index_of = [&](int u) -> long long {               // recomputed, not kept: registers are what limits occupancy
       int i = base + tid + SM_THREADS * u;
       i = i < total1 ? i : total1 - 1;                      // clamp: every fetch is unconditional (stays in registers)
+      if (P.ablate & 4) return (long long)bx * total1 + i;
       const int row = (int)fdiv((unsigned)i, P.dc1);
       return (long long)row * N2 + n2_0 + (i - row * C);
     };
@@ -555,6 +560,7 @@ __global__ __launch_bounds__(SM_THREADS, ((MODE == SM_SIGNAL || !HALF) ? 6 : 5))
       // support the masks, the Hermitian extension and the products (~80 of the ~280 instructions per element of this
       // kernel) are skipped and the element is zero -- what the multiplication by the zero masks gives.
       cd v = {0.0, 0.0};
+      if (P.ablate & 32) v = {raw[u].a, raw[u].b}; else
       if (MODE != SM_SPECTRUM || __builtin_amdgcn_ballot_w64(smooth_nonzero<HALF>(P, ctx, index_of(u))) != 0ull)
         v = smooth_value<MODE, HALF>(P, J, ctx, index_of(u), raw[u], cs, sn);
       const int row = (int)fdiv((unsigned)i, P.dc1);
@@ -570,6 +576,7 @@ __global__ __launch_bounds__(SM_THREADS, ((MODE == SM_SIGNAL || !HALF) ? 6 : 5))
   __syncthreads();
   SM_STAMP(s1);
   const cd* r = a;
+  if (P.ablate & 8) {} else
   if (P.inplace) lds_fft_dif_inplace(a, N1, LD, P.r1, P.dper1, P.nr1, twl, tid, C);
   else r = lds_fft_stockham(a, b, N1, P.r1, P.nr1, twl, tid, C);
   SM_STAMP(s2);
@@ -594,7 +601,7 @@ __global__ __launch_bounds__(SM_THREADS, ((MODE == SM_SIGNAL || !HALF) ? 6 : 5))
       const int c = (int)fdiv((unsigned)i, P.dn1), k1 = i - c * N1;
       const int n2 = n2_0 + c;
       const int kt = (int)fdiv((unsigned)k1, P.dc2);                 // tile of k1 in pass 2
-      w[(long long)kt * ((long long)N2 * C2) + (long long)n2 * C2 + (k1 - kt * C2)] =
+      w[(P.ablate & 2) ? (long long)bx * total1 + i : (long long)kt * ((long long)N2 * C2) + (long long)n2 * C2 + (k1 - kt * C2)] =
           ira::cmul(r[c * LD + (P.inplace ? dif_slot(k1, P.dr1, P.span1, P.nr1) : k1)], ira::cmul(th[u], tl[u]));
     }
   }
@@ -658,6 +665,7 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_rows_kernel(SmoothPlan P, S
   __syncthreads();
   SM_STAMP(s1);
   const cd* r = a;
+  if (P.ablate & 16) {} else
   if (P.inplace) lds_fft_dif_inplace(a, N2, LD, P.r2, P.dper2, P.nr2, twl, tid, C);
   else r = lds_fft_stockham(a, b, N2, P.r2, P.nr2, twl, tid, C);
   SM_STAMP(s2);
@@ -679,8 +687,9 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_rows_kernel(SmoothPlan P, S
       J.y[out1 + 2 * k + 1] = (float)(-v.im * sc);
     } else {
       const double sc = 1.0 / (double)n;
-      J.y[out1 + k] = (float)(v.re * sc);
-      if (out2 >= 0) J.y[out2 + k] = (float)(-v.im * sc);
+      const long long ko = (P.ablate & 1) ? (long long)bx * total2 + i : k;
+      J.y[out1 + ko] = (float)(v.re * sc);
+      if (out2 >= 0) J.y[out2 + ko] = (float)(-v.im * sc);
     }
   }
   if (P.stamp) {
@@ -843,6 +852,7 @@ int32_t make_smooth_plan(int32_t n, const void* t1, const void* t2, const void* 
   for (int i = 0, span = n2; i < P->nr2; ++i) { span /= P->r2[i]; P->dr2[i] = fast_div_of((unsigned)P->r2[i]); P->span2[i] = span; P->dper2[i] = fast_div_of((unsigned)(n2 / P->r2[i])); }
   P->t1 = static_cast<const cd*>(t1); P->t2 = static_cast<const cd*>(t2); P->tf = static_cast<const cd*>(tf);
   P->stamp = ira_tune_flag("IRA_SMOOTH_STAMP");
+  P->ablate = ira_tune_int("IRA_SMOOTH_ABLATE", 0);
   {
     const double step = 3.14159265358979323846 * (double)(SM_THREADS / P->c1) / (double)n1;
     P->hstep_c = std::cos(step);
