@@ -119,6 +119,16 @@ def get_engine() -> "Engine":
     return _ENGINE
 
 
+def conv_size(need: int, three_pow2: bool = True) -> int:
+    """Smallest Bluestein convolution size the library takes (ira_fft_split: 2^k, or 3 * 2^k when allowed) that holds
+    `need` distinct lags; at least 16."""
+    need = max(int(need), 16)
+    m = 1 << int(need - 1).bit_length()
+    if three_pow2 and m >= 128 and 3 * (m >> 2) >= need:
+        m = 3 * (m >> 2)
+    return m
+
+
 class Engine:
     def __init__(self, device: Optional[str] = None):
         import torch
@@ -591,11 +601,7 @@ class Engine:
 
     def conv_size_for(self, need: int) -> int:
         """Smallest supported convolution size M >= need (a linear convolution of `need` distinct lags)."""
-        need = max(int(need), 16)
-        m = 1 << int(need - 1).bit_length()
-        if self.three_pow2_sizes and m >= 128 and 3 * (m >> 2) >= need:
-            m = 3 * (m >> 2)
-        return m
+        return conv_size(need, self.three_pow2_sizes)
 
     def long_tables(self, m: int):
         key = ("long", int(m))

@@ -322,7 +322,7 @@ def load_traffic(cfg: str):
 
 
 # ABI calls that are ONE kernel launch: their live per-call time is that kernel's own duration
-SINGLE_KERNEL_CALLS = {"ira_stft_logbin": "stft5_kernel", "ira_stft_mag_db_tf": "stft3_kernel", "ira_ar_gram": "ar_lag_kernel",
+SINGLE_KERNEL_CALLS = {"ira_stft_logbin": "stft5_kernel", "ira_stft_mag_db_tf": "stft6_kernel", "ira_ar_gram": "ar_lag_kernel",
                        "ira_spectrum_mag_phase": "mag_phase_kernel", "ira_phase_unwrap": "unwrap_kernel",
                        "ira_spectrum_stats": "stats_kernel", "ira_poly_roots": "poly_roots_kernel"}
 

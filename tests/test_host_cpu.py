@@ -54,6 +54,31 @@ def test_argument_validation_without_gpu():
     assert lib.ira_ar_gram(1, 0, 1, 1, 0, 1, 100, 2000, 1, 0, 0) == -2
 
 
+def test_bluestein_convolution_sizes_and_their_four_step_split():
+    """The sizes the host picks (2^k or 3 * 2^k) are sizes the library splits (n1 * n2 = M, n2 a power of two, n1 one or
+    three times one); everything else is refused.  ira_fft_split is host-only code: no GPU needed."""
+    import ctypes
+    from audio_analysis_amd import _lib
+    from audio_analysis_amd.engine import conv_size
+    lib = _lib.load()
+    a, b = ctypes.c_int32(0), ctypes.c_int32(0)
+    for need in [1, 16, 17, 97 + 48, 1000, 4099 * 3 // 2, 65535 + 32767, 65537 + 32768, 2 * 49151 - 1, 2 * 239750 - 1,
+                 479501 + 239750, 959999, (1 << 22) - 5]:
+        for three in (True, False):
+            m = conv_size(need, three)
+            assert m >= max(need, 16)
+            assert m & (m - 1) == 0 or (three and m % 3 == 0 and (m // 3) & (m // 3 - 1) == 0)
+            if three and m & (m - 1) == 0 and m >= 128:
+                assert 3 * (m >> 2) < need                     # the smaller 3 * 2^k really was too small
+            assert lib.ira_fft_split(m, ctypes.byref(a), ctypes.byref(b)) == 0
+            assert a.value * b.value == m and b.value & (b.value - 1) == 0 and b.value <= 8192
+            q = a.value // 3 if a.value % 3 == 0 else a.value
+            assert q & (q - 1) == 0
+    assert conv_size(479501 + 239750) == 3 << 18 and conv_size(479501 + 239750, False) == 1 << 20
+    for bad in (0, 15, 48, 5 << 10, 7 << 12, (1 << 22) + 1, 3 << 21, 100000):
+        assert lib.ira_fft_split(bad, ctypes.byref(a), ctypes.byref(b)) == -2, bad     # IRA_E_SIZE
+
+
 def test_product_path_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
