@@ -244,7 +244,7 @@ def make_roof(ev, roof_steps, settings, L, n, nchan, traffic_tab):
             what = "per channel: 4L + 16(L/2+1) bytes (fr/filter spectrum of arbitrary length)"
         elif name.startswith("ira_rfft_smooth"):
             b = float(nchan) * (4.0 * n + 16.0 * (n // 2 + 1))
-            what = "per channel: 4n + 16(n/2+1) bytes (RT60 full-file forward transform, direct mixed radix, paired)"
+            what = "per channel: 4n + 16(n/2+1) bytes (RT60 full-file forward transform, direct mixed radix, half-length complex)"
         elif name.startswith("ira_band_irfft") and nb:
             b = float(nchan) * (16.0 * (n // 2 + 1) + nb * 4.0 * n)
             what = f"per channel: 16(n/2+1) spectrum in + {nb} band signals x 4n out bytes"
@@ -274,16 +274,24 @@ def make_roof(ev, roof_steps, settings, L, n, nchan, traffic_tab):
         # compulsory bytes (every pass reads and writes its n complex values once), and they are vector-float64 work.
         stream_b = flops = None
         if name.startswith("ira_band_irfft_smooth") and nb:
-            jobs = nchan * nb / 2.0                                      # two bands ride one complex inverse
-            stream_b = jobs * (2 * 16.0 * n + 16.0 * n + 16.0 * n + 2 * 4.0 * n)
-            flops = jobs * 5.0 * n * np.log2(n)
+            # a channel's transforms are its own (round 3): two of its bands ride one full-length complex inverse, a band
+            # left over takes a half-length one
+            full, half, h = nchan * (nb // 2), nchan * (nb % 2), n // 2
+            stream_b = full * (16.0 * (n // 2 + 1) + 16.0 * n + 16.0 * n + 2 * 4.0 * n) + \
+                       half * (16.0 * (n // 2 + 1) + 16.0 * h + 16.0 * h + 4.0 * n)
+            flops = full * 5.0 * n * np.log2(n) + half * 5.0 * h * np.log2(h)
         elif name.startswith("ira_rfft_smooth"):
-            jobs = nchan / 2.0                                           # two channels ride one complex transform
-            stream_b = jobs * (2 * 4.0 * n + 16.0 * n + 16.0 * n + 16.0 * n + 16.0 * n + 2 * 16.0 * (n // 2 + 1))
-            flops = jobs * 5.0 * n * np.log2(n)
+            # one real signal of even length = ONE half-length complex transform (x[2m] + i x[2m+1]) + the untangling pass
+            h = n // 2
+            stream_b = nchan * (4.0 * n + 16.0 * h + 16.0 * h + 16.0 * h + 16.0 * h + 16.0 * (h + 1))
+            flops = nchan * 5.0 * h * np.log2(h)
         elif name.startswith("ira_rfft_any"):
-            tlen = np.where(L % 2 == 0, L / 2, L)
-            M = 2.0 ** np.ceil(np.log2(2 * tlen - 1))
+            # Bluestein: an even length rides a half-length transform (2 l - 1 lags), an odd one a full-length transform of a
+            # single real signal (l + l/2 lags); M = the smallest of 2^k, 3 * 2^k (engine.conv_size)
+            from audio_analysis_amd.engine import conv_size
+            tlen = np.where(L % 2 == 0, L // 2, L)
+            need = np.where(L % 2 == 0, 2 * tlen - 1, tlen + tlen // 2)
+            M = np.array([conv_size(int(v)) for v in need], dtype=np.float64)
             stream_b = float(np.sum(4.0 * L + 16.0 * M * 5 + 16.0 * (L // 2 + 1)))
             flops = float(np.sum(2 * 5.0 * M * np.log2(M) + 6.0 * M))
         if name.startswith("ira_stft_logbin") or (name.startswith("ira_stft_mag_db") and "[f64" in name and ",sel]" not in name):

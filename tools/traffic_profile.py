@@ -21,8 +21,8 @@ CALLS = [   # (substring of the kernel name, ABI call)
     ("smooth_half_split", "ira_rfft_smooth"), ("rows3_kernel", "ira_rfft_any"), ("edc_moments", "ira_edc_fits"),
     ("edc_line", "ira_edc_fits"), ("pcm16_jobs", "ira_pcm16_to_channels"),
     ("stft2_kernel<double, 1", "ira_stft_mag_db[f64,n4096,sel]"), ("stft2_kernel", "ira_stft_mag_db"),
-    ("smooth_cols_kernel<0>", "ira_rfft_smooth"), ("smooth_rows_kernel<0>", "ira_rfft_smooth"), ("smooth_pair_split", "ira_rfft_smooth"),
-    ("smooth_cols_kernel<1>", "ira_band_irfft_smooth"), ("smooth_rows_kernel<1>", "ira_band_irfft_smooth"),
+    ("smooth_cols_kernel<0", "ira_rfft_smooth"), ("smooth_rows_kernel<0>", "ira_rfft_smooth"), ("smooth_pair_split", "ira_rfft_smooth"),
+    ("smooth_cols_kernel<1", "ira_band_irfft_smooth"), ("smooth_rows_kernel<1>", "ira_band_irfft_smooth"),
     ("cols_fwd_kernel<0>", "ira_rfft_any"), ("rows_kernel<1>", "ira_rfft_any"), ("cols_inv_kernel<0>", "ira_rfft_any"),
     ("pair_split_kernel", "ira_rfft_any"), ("half_split_kernel", "ira_rfft_any"),
     ("cols_fwd_kernel<1>", "ira_bluestein_filter"), ("rows_kernel<0>", "ira_bluestein_filter"),
