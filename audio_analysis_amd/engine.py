@@ -268,7 +268,11 @@ class Engine:
         return self._side
 
     _lanes = None
-    num_lanes = max(1, min(4, int(os.environ.get("IRA_STREAMS", "3"))))
+    num_lanes = max(1, min(4, int(os.environ.get("IRA_STREAMS", "2"))))
+    # which report blocks go to which lane (pipeline.FullReport.submit; None = its measured default).  IRA_LANE_DEAL, e.g.
+    # "0,1|4,3,5,2", is the A/B switch of tools: 0 bands, 1 spectrum, 2 zplane, 3 decay, 4 modal, 5 stft
+    lane_deal = ([[int(v) for v in part.split(",")] for part in os.environ["IRA_LANE_DEAL"].split("|")]
+                 if os.environ.get("IRA_LANE_DEAL") else None)
 
     def block_streams(self):
         """
@@ -276,8 +280,9 @@ class Engine:
         latency-bound kernels of one lane (curve fits, Cholesky solves, root finders, unwrap scans) run beside another
         lane's wide kernels instead of leaving most CUs idle, and the launch gaps of one lane are covered by the others.
         Every lane has its own chirp-filter plan pool (_filters); tables are uploaded synchronously (_table_to_dev).
-        IRA_STREAMS=1 keeps everything on the caller's stream (A/B switch); default 3 (measured on MI355X, 64 x 10 s
-        full report: 1 lane 7182, 2 lanes 8305, 3 lanes 8823, 4 lanes 8711 IRs/s).
+        IRA_STREAMS=1 keeps everything on the caller's stream (A/B switch); default 2 (round 3, 256 x 10 s per step: 1 lane
+        12.4 k, 2 lanes 13.4 k, 3 lanes 11.6-12.3 k IRs/s; round 1 measured 3 lanes best at 64 per step, when the small
+        latency-bound kernels were a fifth of the step).
         """
         if self.num_lanes <= 1:
             return None

@@ -311,9 +311,14 @@ class FullReport:
             ev.record(main)
             done.append(ev)
         else:
-            # Measured (64 x 10 s): once two or more lanes are busy the GPU is saturated -- 2, 3 and 4 lanes and several
-            # ways of dealing the groups all land within 2 % (7.2-7.4 ms per step); this deal was the best of them.
-            deal = {2: [[0, 1], [4, 3, 5, 2]], 3: [[0], [1], [4, 3, 5, 2]], 4: [[0], [1], [4, 3], [5, 2]]}[len(lanes)]
+            # Round 3, measured at 256 x 10 s per step (each deal three times, alternating, one box): two lanes -- the long
+            # transforms and the Schroeder fits (memory-side work) on one, the float64 / float32 STFTs and the AR fit
+            # (arithmetic) on the other -- 13.4-13.5 k IRs/s; [[0, 1], [4, 3, 5, 2]] 12.3-13.1 k; [[0, 1, 2], [4, 3, 5]]
+            # 13.1-13.2 k; three lanes (round 2's default, bands | spectrum | rest: two families of long transforms side by
+            # side evict each other's work arrays) 11.6-12.3 k; one lane 12.4 k.
+            deal = {2: [[0, 1, 3], [4, 5, 2]], 3: [[0], [1], [4, 3, 5, 2]], 4: [[0], [1], [4, 3], [5, 2]]}[len(lanes)]
+            if eng.lane_deal is not None and len(eng.lane_deal) == len(lanes):      # A/B (tools only)
+                deal = eng.lane_deal
             # A lane waits for THIS batch's upload only (not for another lane's previous step: steps overlap across
             # lanes) and is ordered behind its own earlier work by being a stream.  The batch's arrays were allocated
             # on the caller's stream: record_stream keeps the allocator from recycling them while a lane may read them.
