@@ -140,6 +140,15 @@ def test_pipeline_records_are_shard_invariant():
         perm = [4, 0, 9, 3, 7, 1, 8, 2, 6, 5]
         shuffled = P.FullReport(eng).run(eng.upload([chans[i] for i in perm]))
         assert shuffled.tobytes() == full[perm].tobytes()
+        # the number of HIP streams the report blocks are dealt onto (one, the default two, round 2's three) is scheduling
+        # only: the same bytes
+        saved = eng.num_lanes
+        try:
+            for lanes in (1, 2, 3):
+                eng.num_lanes = lanes
+                assert P.FullReport(eng).run(eng.upload(chans)).tobytes() == full.tobytes(), lanes
+        finally:
+            eng.num_lanes = saved
     parts = []
     for r in range(2):
         lo, hi = shard_files(len(chans), r, 2)
