@@ -35,22 +35,34 @@ __host__ __device__ inline FastDiv fast_div_of(unsigned d) {
 }
 __device__ __forceinline__ unsigned fdiv(unsigned x, FastDiv f) { return f.d <= 1u ? x : __umulhi(x, f.magic); }
 
+// The radix passes of one in-LDS transform.  Every field is read with COMPILE-TIME indices (pick(), dif_slot()): the plan is
+// a kernel argument, and an entry indexed by the pass counter is a scalar load from the kernel-argument segment followed by
+// s_waitcnt lgkmcnt(0) every time the source mentions it -- round 2's kernels issued ~41 of them per wave (SQ_INSTS_SMEM,
+// profiles/r02_smooth_fft_counters.txt), three to four per ELEMENT in the output stages (dif_slot), each a serial ~200-cycle
+// stall on the critical path of a tile.  With constant indices the loads are loop-invariant and leave the loops.
+constexpr int SM_MAXP = 6;          // passes per transform: 729 = 3^6 is the longest chain for lengths <= 1024
+struct PassTab {
+  int nr;
+  int r[SM_MAXP];                   // radix of pass i
+  int len[SM_MAXP];                 // sub-transform length entering pass i: N / (r_0 ... r_{i-1})
+  int scale[SM_MAXP];               // N / len[i]
+  int span[SM_MAXP];                // N / (r_0 ... r_i): weight of digit i in the slot of X[k] after the passes
+  unsigned per[SM_MAXP], per_magic[SM_MAXP];     // butterflies per transform in pass i (N / r_i) as a divisor
+  unsigned m_magic[SM_MAXP];        // floor(2^32 / (len[i] / r_i)) + 1
+  unsigned r_magic[SM_MAXP];        // floor(2^32 / r_i) + 1
+};
+
 struct SmoothPlan {
   int n, n1, n2;
   FastDiv dc1, dc2, dn1, dn2;       // the same numbers as divisors
-  FastDiv dper1[12], dper2[12];     // butterflies per transform and pass (N / r_i) as divisors
-  FastDiv dr1[12], dr2[12];         // radices as divisors, and the span N / (r_0 ... r_i) of digit i after lds_fft_dif_inplace
-  int span1[12], span2[12];
+  PassTab p1, p2;                   // radix passes of the N1- and N2-point transforms
   int c1, c2;                       // columns per workgroup in pass 1 / pass 2
-  int ld1, ld2;                     // LDS column strides (n1 / n2 plus a bank-conflict pad, see column_stride)
-  int r1[SM_MAX_RADICES], nr1;      // radices of the N1-point transform
-  int r2[SM_MAX_RADICES], nr2;
+  int ld1, ld2;                     // LDS column strides (= n1 / n2, see column_stride)
   const cd* t1;                     // exp(-2 pi i k / N1), k < N1
   const cd* t2;                     // exp(-2 pi i k / N2), k < N2
   const cd* tf;                     // exp(-2 pi i k / n),  k < N2
   double hstep_c, hstep_s;          // half-size inverse: cos / sin of pi (256 / c1) / n1, the step of the W_2n^(-i) twiddle
                                     // between a thread's consecutive pass-1 elements (valid when 256 % c1 == 0)
-  int inplace;                      // 1: single LDS buffer, in-place passes (default); 0: ping-pong Stockham (A/B)
   int stamp;                        // diagnostics (IRA_SMOOTH_STAMP): per-phase cycle counts of one workgroup per kernel
   int ablate;                       // diagnostics (IRA_SMOOTH_ABLATE, timing only -- results are wrong): 1 pass-2 band output
                                     // written tile-major (contiguous per workgroup), 2 pass-1 output contiguous, 4 pass-1
@@ -143,10 +155,6 @@ __device__ __forceinline__ void bfly<8>(cd (&a)[8]) {
   t = a[1]; a[1] = a[4]; a[4] = t;
   t = a[3]; a[3] = a[6]; a[6] = t;
 }
-// One Stockham pass of radix R on sub-length m*R with stride s (= product of the previous radices), nbat transforms:
-//   y[q + s (R p + k)] = W_N^(s p k) * sum_j x[q + s (p + m j)] W_R^(j k),   p < m, q < s.
-// p = bf / s by a multiply-high with magic = floor(2^32 / s) + 1 (exact for bf < 2^16); the R-1 twiddles of a butterfly
-// are powers of ONE table value.
 // Sub-FFT twiddles W_N^t, t < N <= 1024, from two 32+33-entry LDS tables: coarse[t >> 5] = W_N^(32 (t >> 5)),
 // fine[t & 31] = W_N^(t & 31): two LDS reads and one complex multiply (a dependent GLOBAL load per butterfly was the
 // critical path of every pass, an in-kernel sincospi costs ~100 instructions).
@@ -160,68 +168,8 @@ __device__ __forceinline__ void twiddle_lds_put(cd* tab, cd v, int tid) {
   if (tid < 66) tab[tid] = v;
 }
 
-template <int R>
-__device__ __forceinline__ void stockham_pass(const cd* x, cd* y, int N, int m, int s, unsigned magic,
-                                              const cd* __restrict__ tw, int tid, int nbat) {
-  const int per = N / R;
-  for (int t = 0; t < nbat; ++t) {
-    const cd* xt = x + t * N;
-    cd* yt = y + t * N;
-    for (int bf = tid; bf < per; bf += SM_THREADS) {
-      const int p = s == 1 ? bf : (int)__umulhi((unsigned)bf, magic);
-      const int q = bf - p * s;
-      cd v[R];
-#pragma unroll
-      for (int j = 0; j < R; ++j) v[j] = xt[bf + s * m * j];           // q + s p = bf
-      bfly<R>(v);
-      cd* yo = yt + q + s * R * p;
-      yo[0] = v[0];
-      if (p == 0) {
-#pragma unroll
-        for (int k = 1; k < R; ++k) yo[s * k] = v[k];
-      } else {
-        const int t = s * p;                                             // W_N^(s p), s p < N / R; tw = LDS tables
-        const cd w1 = ira::cmul(tw[t >> 5], tw[33 + (t & 31)]);
-        cd w = w1;
-#pragma unroll
-        for (int k = 1; k < R; ++k) {
-          yo[s * k] = ira::cmul(v[k], w);
-          if (k + 1 < R) w = ira::cmul(w, w1);
-        }
-      }
-    }
-  }
-  __syncthreads();
-}
-
-// Stockham autosort FFT of `nbat` transforms of N points each (buffers a/b, transform t at offset t*N), natural order in,
-// natural order out.  Returns the buffer holding the result.  All threads call.
-__device__ cd* lds_fft_stockham(cd* a, cd* b, int N, const int* radices, int nrad, const cd* __restrict__ tw, int tid,
-                                int nbat) {
-  int s = 1, len = N;
-  cd* x = a;
-  cd* y = b;
-  for (int pass = 0; pass < nrad; ++pass) {
-    const int r = radices[pass];
-    const int m = len / r;
-    const unsigned magic = (unsigned)(0x100000000ull / (unsigned)s) + 1u;
-    switch (r) {
-      case 10: stockham_pass<10>(x, y, N, m, s, magic, tw, tid, nbat); break;
-      case 8: stockham_pass<8>(x, y, N, m, s, magic, tw, tid, nbat); break;
-      case 6: stockham_pass<6>(x, y, N, m, s, magic, tw, tid, nbat); break;
-      case 5: stockham_pass<5>(x, y, N, m, s, magic, tw, tid, nbat); break;
-      case 4: stockham_pass<4>(x, y, N, m, s, magic, tw, tid, nbat); break;
-      case 3: stockham_pass<3>(x, y, N, m, s, magic, tw, tid, nbat); break;
-      default: stockham_pass<2>(x, y, N, m, s, magic, tw, tid, nbat); break;
-    }
-    cd* tmp = x; x = y; y = tmp;
-    s *= r;
-    len = m;
-  }
-  return x;
-}
-
-// ---- the same transform IN PLACE (one LDS buffer) ---------------------------------------------------------------------
+// ---- the transform IN PLACE (one LDS buffer) ------------------------------------------------------------------------------
+// (Round 1's ping-pong Stockham variant, kept as an A/B until round 3, is gone: it needed twice the LDS per tile.)
 // Decimation in frequency with every butterfly writing back to the R slots it read: no second buffer, no staging, one
 // barrier per pass.  The price is the output order: X[k], k = k_0 + r_0 k_1 + r_0 r_1 k_2 ..., ends up at the
 // digit-reversed slot k_0 (N / r_0) + k_1 (N / (r_0 r_1)) + ...; the consumers ask dif_slot() where a k lives.
@@ -230,18 +178,15 @@ __device__ cd* lds_fft_stockham(cd* a, cd* b, int N, const int* radices, int nra
 // (The butterflies of ALL nbat transforms are dealt to the threads in one sweep: a transform has only N / R = 64 ... 100 of
 // them, and one transform after the other left three quarters of the 256 lanes idle in each of nbat dependent rounds.)
 template <int R>
-__device__ __forceinline__ void dif_pass(cd* x, int N, int ld, int len, FastDiv dper, const cd* __restrict__ tw, int tid,
-                                         int nbat) {
-  const int per = (int)dper.d;                  // butterflies per transform (N / R)
-  const int m = len / R;
-  const int scale = N / len;                    // W_len^(p k) = W_N^(scale p k)
-  const unsigned magic = (unsigned)(0x100000000ull / (unsigned)m) + 1u;      // bf / m for bf < 2^16
+__device__ __forceinline__ void dif_pass(cd* x, int ld, int len, int scale, unsigned per, unsigned per_magic,
+                                         unsigned m_magic, const cd* __restrict__ tw, int tid, int nbat) {
+  const int m = len / R;                        // (R is a compile-time constant)
   {
-    for (int g = tid; g < per * nbat; g += SM_THREADS) {
-      const int t = (int)fdiv((unsigned)g, dper);
-      const int bf = g - t * per;
+    for (int g = tid; g < (int)per * nbat; g += SM_THREADS) {
+      const int t = per == 1u ? g : (int)__umulhi((unsigned)g, per_magic);                // g / per
+      const int bf = g - t * (int)per;
       cd* xt = x + t * ld;
-      const int blk = m == 1 ? bf : (int)__umulhi((unsigned)bf, magic);
+      const int blk = m == 1 ? bf : (int)__umulhi((unsigned)bf, m_magic);
       const int p = bf - blk * m;
       cd* base = xt + blk * len + p;
       cd v[R];
@@ -253,7 +198,7 @@ __device__ __forceinline__ void dif_pass(cd* x, int N, int ld, int len, FastDiv 
 #pragma unroll
         for (int k = 1; k < R; ++k) base[m * k] = v[k];
       } else {
-        const int tt = scale * p;                                          // < N / R
+        const int tt = scale * p;                                          // W_len^(p k) = W_N^(scale p k), scale p < N / R
         const cd w1 = ira::cmul(tw[tt >> 5], tw[33 + (tt & 31)]);
         cd w = w1;
 #pragma unroll
@@ -267,33 +212,42 @@ __device__ __forceinline__ void dif_pass(cd* x, int N, int ld, int len, FastDiv 
   __syncthreads();
 }
 
-__device__ void lds_fft_dif_inplace(cd* a, int N, int ld, const int* radices, const FastDiv* dper, int nrad,
-                                    const cd* __restrict__ tw, int tid, int nbat) {
-  int len = N;
-  for (int pass = 0; pass < nrad; ++pass) {
-    const int r = radices[pass];
-    const FastDiv dp = dper[pass];
+// entry `i` of a per-pass array by a chain of scalar selects over compile-time indices (see PassTab)
+template <typename T>
+__device__ __forceinline__ T pick(int i, const T (&a)[SM_MAXP]) {
+  T v = a[0];
+#pragma unroll
+  for (int j = 1; j < SM_MAXP; ++j) v = (i == j) ? a[j] : v;
+  return v;
+}
+
+__device__ __forceinline__ void lds_fft_dif_inplace(cd* a, int ld, const PassTab& T, const cd* __restrict__ tw, int tid,
+                                                    int nbat) {
+  for (int pass = 0; pass < T.nr; ++pass) {
+    const int r = pick(pass, T.r), len = pick(pass, T.len), scale = pick(pass, T.scale);
+    const unsigned per = pick(pass, T.per), pm = pick(pass, T.per_magic), mm = pick(pass, T.m_magic);
     switch (r) {
-      case 10: dif_pass<10>(a, N, ld, len, dp, tw, tid, nbat); break;
-      case 8: dif_pass<8>(a, N, ld, len, dp, tw, tid, nbat); break;
-      case 6: dif_pass<6>(a, N, ld, len, dp, tw, tid, nbat); break;
-      case 5: dif_pass<5>(a, N, ld, len, dp, tw, tid, nbat); break;
-      case 4: dif_pass<4>(a, N, ld, len, dp, tw, tid, nbat); break;
-      case 3: dif_pass<3>(a, N, ld, len, dp, tw, tid, nbat); break;
-      default: dif_pass<2>(a, N, ld, len, dp, tw, tid, nbat); break;
+      case 10: dif_pass<10>(a, ld, len, scale, per, pm, mm, tw, tid, nbat); break;
+      case 8: dif_pass<8>(a, ld, len, scale, per, pm, mm, tw, tid, nbat); break;
+      case 6: dif_pass<6>(a, ld, len, scale, per, pm, mm, tw, tid, nbat); break;
+      case 5: dif_pass<5>(a, ld, len, scale, per, pm, mm, tw, tid, nbat); break;
+      case 4: dif_pass<4>(a, ld, len, scale, per, pm, mm, tw, tid, nbat); break;
+      case 3: dif_pass<3>(a, ld, len, scale, per, pm, mm, tw, tid, nbat); break;
+      default: dif_pass<2>(a, ld, len, scale, per, pm, mm, tw, tid, nbat); break;
     }
-    len /= r;
   }
 }
 
 // slot of X[k] after lds_fft_dif_inplace: digit i of k (mixed radix r_0, r_1, ...) times span_i = N / (r_0 ... r_i)
-__device__ __forceinline__ int dif_slot(int k, const FastDiv* radices, const int* span, int nrad) {
+__device__ __forceinline__ int dif_slot(int k, const PassTab& T) {
   int slot = 0;
-#pragma unroll 1
-  for (int i = 0; i < nrad; ++i) {
-    const int q = (int)fdiv((unsigned)k, radices[i]);
-    slot += (k - q * (int)radices[i].d) * span[i];
-    k = q;
+#pragma unroll
+  for (int i = 0; i < SM_MAXP; ++i) {
+    if (i < T.nr) {
+      const int q = (int)__umulhi((unsigned)k, T.r_magic[i]);             // k / r_i   (r_i >= 2)
+      slot += (k - q * T.r[i]) * T.span[i];
+      k = q;
+    }
   }
   return slot;
 }
@@ -524,9 +478,8 @@ __global__ __launch_bounds__(SM_THREADS, ((MODE == SM_SIGNAL || !HALF) ? 6 : 5))
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cd* a = reinterpret_cast<cd*>(smem);
   const int C = P.c1, N1 = P.n1, N2 = P.n2;
-  const int LD = P.ld1;                                    // column stride in LDS (N1 for the ping-pong plan)
-  cd* b = a + (size_t)C * LD;                              // second buffer (ping-pong plan only)
-  cd* twl = P.inplace ? b : b + (size_t)C * N1;            // SM_TW entries
+  const int LD = P.ld1;                                    // column stride in LDS
+  cd* twl = a + (size_t)C * LD;                            // SM_TW entries
   unsigned bx, by;
   smooth_remap(bx, by);
   const int e = (int)by, tid = threadIdx.x;
@@ -576,9 +529,7 @@ __global__ __launch_bounds__(SM_THREADS, ((MODE == SM_SIGNAL || !HALF) ? 6 : 5))
   __syncthreads();
   SM_STAMP(s1);
   const cd* r = a;
-  if (P.ablate & 8) {} else
-  if (P.inplace) lds_fft_dif_inplace(a, N1, LD, P.r1, P.dper1, P.nr1, twl, tid, C);
-  else r = lds_fft_stockham(a, b, N1, P.r1, P.nr1, twl, tid, C);
+  if (!(P.ablate & 8)) lds_fft_dif_inplace(a, LD, P.p1, twl, tid, C);
   SM_STAMP(s2);
   cd* w = work + (long long)e * P.n;
   const int C2 = P.c2;
@@ -602,7 +553,7 @@ __global__ __launch_bounds__(SM_THREADS, ((MODE == SM_SIGNAL || !HALF) ? 6 : 5))
       const int n2 = n2_0 + c;
       const int kt = (int)fdiv((unsigned)k1, P.dc2);                 // tile of k1 in pass 2
       w[(P.ablate & 2) ? (long long)bx * total1 + i : (long long)kt * ((long long)N2 * C2) + (long long)n2 * C2 + (k1 - kt * C2)] =
-          ira::cmul(r[c * LD + (P.inplace ? dif_slot(k1, P.dr1, P.span1, P.nr1) : k1)], ira::cmul(th[u], tl[u]));
+          ira::cmul(r[c * LD + dif_slot(k1, P.p1)], ira::cmul(th[u], tl[u]));
     }
   }
   if (P.stamp) {
@@ -618,9 +569,8 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_rows_kernel(SmoothPlan P, S
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cd* a = reinterpret_cast<cd*>(smem);
   const int C = P.c2, N1 = P.n1, N2 = P.n2;
-  const int LD = P.ld2;                                    // column stride in LDS (N2 for the ping-pong plan)
-  cd* b = a + (size_t)C * LD;                              // second buffer (ping-pong plan only)
-  cd* twl = P.inplace ? b : b + (size_t)C * N2;
+  const int LD = P.ld2;                                    // column stride in LDS
+  cd* twl = a + (size_t)C * LD;
   unsigned bx, by;
   smooth_remap(bx, by);
   const int e = (int)by, tid = threadIdx.x;
@@ -665,15 +615,13 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_rows_kernel(SmoothPlan P, S
   __syncthreads();
   SM_STAMP(s1);
   const cd* r = a;
-  if (P.ablate & 16) {} else
-  if (P.inplace) lds_fft_dif_inplace(a, N2, LD, P.r2, P.dper2, P.nr2, twl, tid, C);
-  else r = lds_fft_stockham(a, b, N2, P.r2, P.nr2, twl, tid, C);
+  if (!(P.ablate & 16)) lds_fft_dif_inplace(a, LD, P.p2, twl, tid, C);
   SM_STAMP(s2);
   const long long n = P.n;
   for (int i = tid; i < N2 * C; i += SM_THREADS) {
     const int k2 = (int)fdiv((unsigned)i, P.dc2), c = i - k2 * C;
     const long long k = (long long)(k1_0 + c) + (long long)N1 * k2;        // natural output index
-    cd v = r[c * LD + (P.inplace ? dif_slot(k2, P.dr2, P.span2, P.nr2) : k2)];
+    cd v = r[c * LD + dif_slot(k2, P.p2)];
     if (OUT == SM_OUT_SPEC) {
       if (paired) {
         J.zpair[out1 + k] = v;
@@ -759,16 +707,10 @@ int factor_radices(int n, int* out) {
 }
 
 // columns per workgroup for a sub-transform of `len` points (other dimension `other`), dividing the other dimension.
-// Ping-pong plan: as many as keep both LDS buffers within 64 KB.  In-place plan: as many as keep the one buffer within
-// 26 KB -- the registers allow four workgroups per CU and LDS must not be what stops the fourth; measured for
+// As many as keep the tile within 26 KB -- the registers allow four workgroups per CU and LDS must not be what stops the fourth; measured for
 // 480000 = 640 x 750 (band inverses / forward, ms): columns 2/2 1.48 / 0.61, 3/4 1.50 / 0.63, 5/4 1.61 / 0.67,
 // 6/5 2.03 / 0.82 (ping-pong 2/2: 1.62 / 0.64).
-int pick_columns(int len, int other, bool inplace) {
-  if (!inplace) {
-    int c = 8;
-    while (c > 1 && (((size_t)2 * c * len + SM_TW) * sizeof(cd) > 64 * 1024 || other % c != 0)) c >>= 1;
-    return c;
-  }
+int pick_columns(int len, int other) {
   int best = 1;
   for (int c = 1; c <= 8; ++c)
     if (other % c == 0 && ((size_t)c * len + SM_TW) * sizeof(cd) <= 26 * 1024) best = c;
@@ -813,13 +755,35 @@ bool smooth_split(long long n, int* n1_out, int* n2_out) {
   return true;
 }
 
+// radix passes of an N-point transform (radices from factor_radices or a tuning override); false if they do not fit PassTab
+bool fill_passes(int N, const int* radices, int count, PassTab* T) {
+  if (count < 1 || count > SM_MAXP) return false;
+  *T = PassTab{};
+  T->nr = count;
+  int len = N;
+  for (int i = 0; i < SM_MAXP; ++i) {
+    const int r = i < count ? radices[i] : 2;                              // unused entries: harmless constants
+    const int m = i < count ? len / r : 1;
+    T->r[i] = r;
+    T->len[i] = i < count ? len : 2;
+    T->scale[i] = i < count ? N / len : 1;
+    T->span[i] = i < count ? len / r : 0;
+    T->per[i] = (unsigned)(N / r);
+    T->per_magic[i] = fast_div_of((unsigned)(N / r)).magic;
+    T->m_magic[i] = fast_div_of((unsigned)m).magic;
+    T->r_magic[i] = fast_div_of((unsigned)r).magic;
+    if (i < count) len /= r;
+  }
+  return len == 1;
+}
+
 int32_t make_smooth_plan(int32_t n, const void* t1, const void* t2, const void* tf, SmoothPlan* P) {
   int n1, n2;
   if (!smooth_split(n, &n1, &n2)) return IRA_E_UNSUPPORTED;
   P->n = n; P->n1 = n1; P->n2 = n2;
-  P->nr1 = factor_radices(n1, P->r1);
-  P->nr2 = factor_radices(n2, P->r2);
-  if (P->nr1 < 0 || P->nr2 < 0) return IRA_E_UNSUPPORTED;
+  int r1[SM_MAX_RADICES], r2[SM_MAX_RADICES];
+  int nr1 = factor_radices(n1, r1), nr2 = factor_radices(n2, r2);
+  if (nr1 < 0 || nr2 < 0) return IRA_E_UNSUPPORTED;
   // tuning: IRA_SMOOTH_R1 / IRA_SMOOTH_R2 = comma-separated radix order for the n1- / n2-point transforms (product checked)
   auto override_radices = [](const char* name, int len, int* out, int* cnt) {
     const char* ev = ira_tune_str(name);
@@ -837,19 +801,17 @@ int32_t make_smooth_plan(int32_t n, const void* t1, const void* t2, const void* 
     for (int i = 0; i < k; ++i) out[i] = tmp[i];
     *cnt = k;
   };
-  override_radices("IRA_SMOOTH_R1", n1, P->r1, &P->nr1);
-  override_radices("IRA_SMOOTH_R2", n2, P->r2, &P->nr2);
-  P->inplace = !ira_tune_flag("IRA_SMOOTH_PINGPONG");
-  P->c1 = pick_columns(n1, n2, P->inplace != 0);
-  P->c2 = pick_columns(n2, n1, P->inplace != 0);
+  override_radices("IRA_SMOOTH_R1", n1, r1, &nr1);
+  override_radices("IRA_SMOOTH_R2", n2, r2, &nr2);
+  if (!fill_passes(n1, r1, nr1, &P->p1) || !fill_passes(n2, r2, nr2, &P->p2)) return IRA_E_UNSUPPORTED;
+  P->c1 = pick_columns(n1, n2);
+  P->c2 = pick_columns(n2, n1);
   { const int v = ira_tune_int("IRA_SMOOTH_C1", 0); if (v >= 1 && n2 % v == 0) P->c1 = v; }
   { const int v = ira_tune_int("IRA_SMOOTH_C2", 0); if (v >= 1 && n1 % v == 0) P->c2 = v; }
-  P->ld1 = P->inplace ? column_stride(n1, P->c1) : n1;
-  P->ld2 = P->inplace ? column_stride(n2, P->c2) : n2;
+  P->ld1 = column_stride(n1, P->c1);
+  P->ld2 = column_stride(n2, P->c2);
   P->dc1 = fast_div_of((unsigned)P->c1); P->dc2 = fast_div_of((unsigned)P->c2);
   P->dn1 = fast_div_of((unsigned)n1); P->dn2 = fast_div_of((unsigned)n2);
-  for (int i = 0, span = n1; i < P->nr1; ++i) { span /= P->r1[i]; P->dr1[i] = fast_div_of((unsigned)P->r1[i]); P->span1[i] = span; P->dper1[i] = fast_div_of((unsigned)(n1 / P->r1[i])); }
-  for (int i = 0, span = n2; i < P->nr2; ++i) { span /= P->r2[i]; P->dr2[i] = fast_div_of((unsigned)P->r2[i]); P->span2[i] = span; P->dper2[i] = fast_div_of((unsigned)(n2 / P->r2[i])); }
   P->t1 = static_cast<const cd*>(t1); P->t2 = static_cast<const cd*>(t2); P->tf = static_cast<const cd*>(tf);
   P->stamp = ira_tune_flag("IRA_SMOOTH_STAMP");
   P->ablate = ira_tune_int("IRA_SMOOTH_ABLATE", 0);
@@ -878,7 +840,8 @@ extern "C" int32_t ira_fft_smooth_split(int32_t n, int32_t* n1, int32_t* n2) {
   int a, b;
   if (!smooth_split(n, &a, &b)) return IRA_E_UNSUPPORTED;
   int r[SM_MAX_RADICES];
-  if (factor_radices(a, r) < 0 || factor_radices(b, r) < 0) return IRA_E_UNSUPPORTED;
+  const int ca = factor_radices(a, r), cb = factor_radices(b, r);
+  if (ca < 1 || cb < 1 || ca > SM_MAXP || cb > SM_MAXP) return IRA_E_UNSUPPORTED;
   *n1 = a; *n2 = b;
   return IRA_OK;
 }
@@ -908,8 +871,7 @@ extern "C" int32_t ira_rfft_smooth(const float* x_dev, const int64_t* xoff_dev, 
     J.zpair = reinterpret_cast<cd*>(zpair_dev); J.zpair_off = zpair_off_dev;
   }
   hipStream_t st = (hipStream_t)stream;
-  const size_t nbuf = P.inplace ? 1 : 2;
-  const size_t l1 = (nbuf * P.c1 * P.ld1 + SM_TW) * sizeof(cd), l2 = (nbuf * P.c2 * P.ld2 + SM_TW) * sizeof(cd);
+  const size_t l1 = ((size_t)P.c1 * P.ld1 + SM_TW) * sizeof(cd), l2 = ((size_t)P.c2 * P.ld2 + SM_TW) * sizeof(cd);
   SM_TRY(allow(smooth_cols_kernel<SM_SIGNAL>, l1));
   SM_TRY(allow(smooth_rows_kernel<SM_OUT_SPEC>, l2));
   cd* work = reinterpret_cast<cd*>(work_dev);
@@ -943,8 +905,7 @@ extern "C" int32_t ira_band_irfft_smooth(const double* spec_dev, const int64_t* 
   J.half_out = half_out ? 1 : 0;
   if (half_out && spec_off2_dev != nullptr) return IRA_E_UNSUPPORTED;       // one band of one spectrum per job
   hipStream_t st = (hipStream_t)stream;
-  const size_t nbuf = P.inplace ? 1 : 2;
-  const size_t l1 = (nbuf * P.c1 * P.ld1 + SM_TW) * sizeof(cd), l2 = (nbuf * P.c2 * P.ld2 + SM_TW) * sizeof(cd);
+  const size_t l1 = ((size_t)P.c1 * P.ld1 + SM_TW) * sizeof(cd), l2 = ((size_t)P.c2 * P.ld2 + SM_TW) * sizeof(cd);
   SM_TRY(allow(smooth_cols_kernel<SM_SPECTRUM, false>, l1));
   SM_TRY(allow(smooth_cols_kernel<SM_SPECTRUM, true>, l1));
   SM_TRY(allow(smooth_rows_kernel<SM_OUT_BANDS>, l2));
