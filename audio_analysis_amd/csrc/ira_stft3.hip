@@ -411,6 +411,12 @@ __global__ __launch_bounds__(64 * NT) void stft6_kernel(
   float xa0[16], xb0[16];                                  // half 0 of the frame about to be transformed (PF)
   if (PF && have) load_half(fx, q0, 0, xa0, xb0);
 
+  // The sixteen wave-uniform factors W_N^(64 i) of the post step live in scalar registers for the whole walk: inside the loop
+  // they were sixteen scalar loads per frame in four to eight serial round trips (s_waitcnt lgkmcnt(0)).
+  cf wuni[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) wuni[i] = tw[64 * i];
+
   while (have) {
     unsigned tn = t + t_step;
     const float* fxn = fx;
@@ -567,7 +573,7 @@ __global__ __launch_bounds__(64 * NT) void stft6_kernel(
       const cf e = {0.5f * (zkr[i] + zpr[i]), 0.5f * (zki[i] - zpi[i])};
       const cf d = {0.5f * (zkr[i] - zpr[i]), 0.5f * (zki[i] + zpi[i])};
       const cf o = {d.im, -d.re};
-      const cf wk = ira::cmul(wlane, (AB & 8) ? cf{wlane.im * (float)(i + 1), wlane.re} : tw[64 * i]);
+      const cf wk = ira::cmul(wlane, (AB & 8) ? cf{wlane.im * (float)(i + 1), wlane.re} : wuni[i]);
       const cf pp = ira::cmul(wk, o);
       const float lo = bad ? qn : db_of(e.re + pp.re, e.im + pp.im, floor_pow, floor_db);
       const float hi = bad ? qn : db_of(e.re - pp.re, e.im - pp.im, floor_pow, floor_db);

@@ -341,6 +341,12 @@ __global__ __launch_bounds__(TL5) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const float* fx = x + off[seg] + frame * hop;
   const int k1l = q & 15, n3l = q >> 4;            // step-2 role: (k1, n3)
   const bool lower = q < TL4;                      // lanes whose step-1 / step-2 results go through the buffer first
+  // The eight wave-uniform factors W_N^(256 i) of the post step, requested HERE: they compile to scalar loads, and placed
+  // at their use each one stalled its wave for a scalar-cache round trip (s_waitcnt lgkmcnt(0), which also drains the LDS
+  // queue) in the middle of the conversion loop -- eight serial stalls per frame and wave.
+  cdd wuni[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) wuni[i] = tw[TL5 * i];
 
   // ---- step 1 -------------------------------------------------------------------------------------------------
   cdd v[16];
@@ -443,7 +449,7 @@ __global__ __launch_bounds__(TL5) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       const cdd e = {0.5 * (zkr[i] + zpr[i]), 0.5 * (zki[i] - zpi[i])};
       const cdd d = {0.5 * (zkr[i] - zpr[i]), 0.5 * (zki[i] + zpi[i])};
       const cdd o = {d.im, -d.re};
-      const cdd wk = ira::cmul(wlane, tw[TL5 * i]);          // W_N^k = W_N^q W_N^(256 i); second factor wave-uniform
+      const cdd wk = ira::cmul(wlane, wuni[i]);              // W_N^k = W_N^q W_N^(256 i); second factor wave-uniform
       const cdd pp = ira::cmul(wk, o);
       fo[k] = bad_frame ? qnan32 : db_of4(e.re + pp.re, e.im + pp.im, floor_pow, floor_db, ltab);
       fo[M4 - k] = bad_frame ? qnan32 : db_of4(e.re - pp.re, e.im - pp.im, floor_pow, floor_db, ltab);   // k = 0 -> bin M
@@ -476,7 +482,7 @@ __global__ __launch_bounds__(TL5) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const cdd e = {0.5 * (zkr[i] + zpr[i]), 0.5 * (zki[i] - zpi[i])};
     const cdd d = {0.5 * (zkr[i] - zpr[i]), 0.5 * (zki[i] + zpi[i])};
     const cdd o = {d.im, -d.re};
-    const cdd wk = ira::cmul(wlane, tw[TL5 * i]);
+    const cdd wk = ira::cmul(wlane, wuni[i]);
     const cdd pp = ira::cmul(wk, o);
     if (need_a) exd[k] = lin_of4(e.re + pp.re, e.im + pp.im, floor_pow, floor_db, floor_lin32, ltab);
     if (need_b) exd[M4 - k] = lin_of4(e.re - pp.re, e.im - pp.im, floor_pow, floor_db, floor_lin32, ltab);
