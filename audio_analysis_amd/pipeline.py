@@ -129,6 +129,27 @@ def _same_spectrum(a, b) -> bool:
     return all(getattr(a, k) == getattr(b, k) for k in keys)
 
 
+def _row_median_p90_max(a: np.ndarray):
+    """numpy.nanmedian / numpy.nanpercentile(90) / numpy.nanmax along the rows of `a` (every row holds at least one number),
+    the same values bit for bit: the mean of the two middle order statistics, and numpy's linear interpolation between
+    neighbouring order statistics with its own `_lerp` (a + (b - a) t, or b - (b - a)(1 - t) for t >= 0.5).  Vectorised:
+    numpy's nan-functions go row by row through apply_along_axis (9 ms per 256 channels x 240 points, more than the rest
+    of a step's host work together)."""
+    srt = np.sort(a, axis=1)                                   # NaNs last
+    cnt = np.sum(~np.isnan(a), axis=1)
+    rows = np.arange(a.shape[0])
+    lo, hi = srt[rows, (cnt - 1) // 2], srt[rows, cnt // 2]
+    med = np.where(cnt % 2 == 1, lo, (lo + hi) / 2.0)          # numpy: mean of the two middle values = their sum / 2
+    virt = (cnt - 1) * np.true_divide(90, 100)
+    prev = np.floor(virt)
+    t = virt - prev
+    ip = prev.astype(np.int64)
+    va, vb = srt[rows, ip], srt[rows, np.minimum(ip + 1, cnt - 1)]
+    d = vb - va
+    p90 = np.where(t >= 0.5, vb - d * (1.0 - t), va + d * t)
+    return med, p90, srt[rows, cnt - 1]
+
+
 class FullReport:
     """Runs the metrics-only report over a ChannelBatch; keeps the big arrays of the last step on the device."""
 
@@ -407,12 +428,8 @@ class FullReport:
             rt = np.where(valid, rec[:, :, 6], np.nan)
             some = valid.any(axis=1)
             if some.any():
-                import warnings
-                with warnings.catch_warnings():
-                    warnings.simplefilter("ignore", category=RuntimeWarning)      # all-NaN rows stay NaN
-                    m[some, M_MODAL_MEDIAN] = np.nanmedian(rt[some], axis=1)
-                    m[some, M_MODAL_P90] = np.nanpercentile(rt[some], 90, axis=1)
-                    m[some, M_MODAL_MAX] = np.nanmax(rt[some], axis=1)
+                med, p90, mx = _row_median_p90_max(rt[some])
+                m[some, M_MODAL_MEDIAN], m[some, M_MODAL_P90], m[some, M_MODAL_MAX] = med, p90, mx
         if s.run_group_delay:
             vals, gam, cnt = fut["gd_stats"]
             m[:, M_GD_MEDIAN : M_GD_P90 + 1] = _gd.finish_summary_statistics(vals.get(), gam, cnt)

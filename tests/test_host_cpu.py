@@ -341,6 +341,26 @@ def test_bench_starts_its_own_ranks():
 
 
 # ---------------------------------------------------------------------------------------- report host helpers
+def test_vectorised_row_quantiles_equal_numpys_nan_functions():
+    """pipeline._row_median_p90_max replaces numpy.nanmedian / nanpercentile(90) / nanmax along rows (they go row by row
+    through apply_along_axis): the same float64 values bit for bit, NaN holes, ties and single-value rows included."""
+    from audio_analysis_amd.pipeline import _row_median_p90_max
+    rng = np.random.default_rng(0)
+    for trial in range(200):
+        n, k = int(rng.integers(1, 40)), int(rng.integers(1, 241))
+        a = rng.standard_normal((n, k)) * rng.choice([1.0, 1e-3, 1e3])
+        if k > 3:
+            a[:, 1] = a[:, 0]                                     # ties
+        a[rng.random((n, k)) < rng.random()] = np.nan
+        for i in range(n):
+            if np.all(np.isnan(a[i])):
+                a[i, rng.integers(0, k)] = rng.standard_normal()
+        med, p90, mx = _row_median_p90_max(a)
+        assert np.array_equal(med, np.nanmedian(a, axis=1)), trial
+        assert np.array_equal(p90, np.nanpercentile(a, 90, axis=1)), trial
+        assert np.array_equal(mx, np.nanmax(a, axis=1)), trial
+
+
 def test_report_grouping_helpers_and_group_delay_quantiles():
     """Host-side pieces of the batched / text-only report path: per-file grouping of per-channel items, the group-delay
     summary joiner, and the order-statistic ranks that reproduce numpy.median / numpy.percentile."""
