@@ -5,9 +5,12 @@
 //                                        conversion (x / 32768, clip to [-1, 1]; reference analyse/io.py:46-64, :98-113)
 //                                        and, for stereo, the optional mono downmix 0.5 * (L + R) in float32
 //                                        (analyse/io.py:85-91).  The H2D copy carries 2 bytes per sample instead of 4.
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 #include "ira_common.h"
 
@@ -217,6 +220,56 @@ extern "C" int32_t ira_wav_read_pcm16(const char* path, int64_t data_offset, int
   if (rc == IRA_OK && std::fread(dst_host, sizeof(int16_t), want, f) != want) rc = IRA_E_IO;
   std::fclose(f);
   return rc;
+}
+
+// ---- a whole group of taps in ONE call: a Python caller's interpreter lock is released once, for the whole group, instead of
+// being taken and dropped around every file by sixteen pool threads (which starved the thread that drives the GPU: at 128
+// taps per step the analysis thread spent more time waiting for the lock than enqueueing work).  The threads live inside the
+// call (created and joined here: the library keeps no state).
+namespace {
+template <typename F>
+void for_each_file(int32_t n, int32_t threads, F work) {
+  if (threads < 1) threads = 1;
+  if (threads > n) threads = n;
+  if (threads > 64) threads = 64;
+  if (threads <= 1) {
+    for (int32_t i = 0; i < n; ++i) work(i);
+    return;
+  }
+  std::atomic<int32_t> next{0};
+  std::vector<std::thread> pool;
+  pool.reserve((size_t)threads);
+  for (int32_t t = 0; t < threads; ++t)
+    pool.emplace_back([&]() {
+      for (int32_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) work(i);
+    });
+  for (auto& th : pool) th.join();
+}
+}  // namespace
+
+extern "C" int32_t ira_wav_probe_batch(const char* const* paths, int32_t n, int32_t threads, int32_t* status,
+                                       int32_t* sample_rate, int32_t* channels, int64_t* frames, int64_t* data_offset) {
+  IRA_CHECK_PTR(paths); IRA_CHECK_PTR(status); IRA_CHECK_PTR(sample_rate); IRA_CHECK_PTR(channels); IRA_CHECK_PTR(frames);
+  IRA_CHECK_PTR(data_offset);
+  if (n < 0) return IRA_E_SIZE;
+  for_each_file(n, threads, [&](int32_t i) {
+    status[i] = paths[i] ? ira_wav_probe(paths[i], sample_rate + i, channels + i, frames + i, data_offset + i) : IRA_E_NULL;
+  });
+  return IRA_OK;
+}
+
+extern "C" int32_t ira_wav_read_pcm16_batch(const char* const* paths, const int64_t* data_offset, const int64_t* frames,
+                                            const int32_t* channels, const int64_t* dst_off, int16_t* dst_host, int32_t n,
+                                            int32_t threads, int32_t* status) {
+  IRA_CHECK_PTR(paths); IRA_CHECK_PTR(data_offset); IRA_CHECK_PTR(frames); IRA_CHECK_PTR(channels); IRA_CHECK_PTR(dst_off);
+  IRA_CHECK_PTR(dst_host); IRA_CHECK_PTR(status);
+  if (n < 0) return IRA_E_SIZE;
+  for_each_file(n, threads, [&](int32_t i) {
+    status[i] = (paths[i] && dst_off[i] >= 0)
+                    ? ira_wav_read_pcm16(paths[i], data_offset[i], frames[i], channels[i], dst_host + dst_off[i])
+                    : IRA_E_NULL;
+  });
+  return IRA_OK;
 }
 
 extern "C" int32_t ira_pcm16_to_channels(const int16_t* pcm_dev, int64_t frames, int32_t channels, int32_t mono_downmix,

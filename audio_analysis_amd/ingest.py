@@ -91,6 +91,72 @@ def read_tap_pcm16(info: TapInfo, dst: Optional[np.ndarray] = None) -> np.ndarra
     return dst
 
 
+def _io_threads() -> int:
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 2)
+    return max(2, min(16, n))
+
+
+def _path_array(paths: Sequence[Path]):
+    enc = [str(p).encode() for p in paths]
+    return (C.c_char_p * len(enc))(*enc), enc          # (the byte strings must outlive the call)
+
+
+def probe_taps(paths: Sequence[str | Path]) -> List[TapInfo]:
+    """probe_tap for a whole group in ONE library call (ira_wav_probe_batch: the readers run on threads inside the call,
+    the interpreter lock is released once).  Errors are raised for the first offending file in group order, with the
+    types of the per-file path."""
+    ps = [Path(p) for p in paths]
+    n = len(ps)
+    if n == 0:
+        return []
+    lib = _lib.load()
+    arr, keep = _path_array(ps)
+    status = np.zeros(n, dtype=np.int32); rate = np.zeros(n, dtype=np.int32); ch = np.zeros(n, dtype=np.int32)
+    frames = np.zeros(n, dtype=np.int64); off = np.zeros(n, dtype=np.int64)
+    check(lib.ira_wav_probe_batch(C.addressof(arr), n, _io_threads(), status.ctypes.data, rate.ctypes.data, ch.ctypes.data,
+                                  frames.ctypes.data, off.ctypes.data), "ira_wav_probe_batch")
+    del keep
+    out = []
+    for i, p in enumerate(ps):
+        rc = int(status[i])
+        if rc == IRA_E_UNSUPPORTED:
+            out.append(TapInfo(p, int(rate[i]), int(ch[i]), int(frames[i]), int(off[i]), False))
+            continue
+        _raise_like_scipy(rc, p)
+        check(rc, f"ira_wav_probe({p})")
+        out.append(TapInfo(p, int(rate[i]), int(ch[i]), int(frames[i]), int(off[i]), True))
+    return out
+
+
+def read_taps_pcm16(infos: Sequence[TapInfo], dst: np.ndarray, dst_off: Sequence[int]) -> None:
+    """Payloads of a group of native taps into ONE int16 buffer (file i at dst[dst_off[i]:]) in one library call."""
+    n = len(infos)
+    if n == 0:
+        return
+    if dst.dtype != np.int16 or not dst.flags.c_contiguous:
+        raise ValueError("dst must be a C-contiguous int16 array")
+    for info, o in zip(infos, dst_off):
+        if not info.native:
+            raise ValueError(f"{info.path} is not 16-bit PCM")
+        if o < 0 or o + info.frames * info.channels > dst.size:
+            raise ValueError("dst is too small for the payloads")
+    lib = _lib.load()
+    arr, keep = _path_array([i.path for i in infos])
+    d_off = np.array([i.data_offset for i in infos], dtype=np.int64)
+    fr = np.array([i.frames for i in infos], dtype=np.int64)
+    ch = np.array([i.channels for i in infos], dtype=np.int32)
+    do = np.array(list(dst_off), dtype=np.int64)
+    status = np.zeros(n, dtype=np.int32)
+    check(lib.ira_wav_read_pcm16_batch(C.addressof(arr), d_off.ctypes.data, fr.ctypes.data, ch.ctypes.data, do.ctypes.data,
+                                       dst.ctypes.data, n, _io_threads(), status.ctypes.data), "ira_wav_read_pcm16_batch")
+    del keep
+    for i, info in enumerate(infos):
+        rc = int(status[i])
+        _raise_like_scipy(rc, info.path)
+        check(rc, f"ira_wav_read_pcm16({info.path})")
+
+
 def _validate(info: TapInfo, expected_rate: int) -> None:
     # messages of the reference's validate_audio_format (analyse/io.py:161-178), channel mode "mono_or_stereo"
     if info.sample_rate_hz != expected_rate:
@@ -106,20 +172,6 @@ def channel_names(channels: int, mono_downmix: bool) -> List[str]:
     if channels == 1 or mono_downmix:
         return ["mono"]
     return ["left", "right"]
-
-
-_POOL = None
-
-
-def _io_pool():
-    """Threads for header probes and payload reads (file I/O + memcpy inside libira, GIL released by ctypes)."""
-    global _POOL
-    if _POOL is None:
-        import os
-        from concurrent.futures import ThreadPoolExecutor
-        n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 2)
-        _POOL = ThreadPoolExecutor(max_workers=max(2, min(16, n)), thread_name_prefix="ira-ingest")
-    return _POOL
 
 
 class TapSet:
@@ -139,8 +191,7 @@ class TapSet:
         caller's thread before the first view()."""
         t = eng.torch
         self.eng = eng
-        pool = _io_pool()
-        self.infos = list(pool.map(probe_tap, paths)) if len(paths) > 1 else [probe_tap(p) for p in paths]
+        self.infos = probe_taps(paths)
         self.expected_sample_rate_hz = int(expected_sample_rate_hz)
         for info in self.infos:
             _validate(info, self.expected_sample_rate_hz)
@@ -154,18 +205,9 @@ class TapSet:
         self._pcm_dev = None
         if total:
             # pinned staging straight from torch's caching host allocator (a block of an earlier step is reused, nothing
-            # is pinned anew); the files are read concurrently -- libira's reader runs outside the GIL
+            # is pinned anew); the files are read concurrently inside ONE library call (ira_wav_read_pcm16_batch)
             stage = t.empty(total, dtype=t.int16, pin_memory=True)
-            stage_np = stage.numpy()
-
-            def read(i):
-                n = self.infos[i].frames * self.infos[i].channels
-                read_tap_pcm16(self.infos[i], stage_np[self._pcm_off[i] : self._pcm_off[i] + n])
-
-            if len(self._native) > 1:
-                list(pool.map(read, self._native))
-            else:
-                read(self._native[0])
+            read_taps_pcm16([self.infos[i] for i in self._native], stage.numpy(), [self._pcm_off[i] for i in self._native])
             self._stage = stage
             if upload:
                 self.upload()

@@ -33,7 +33,7 @@ extern "C" {
 #define IRA_E_FORMAT (-5)     /* a file is not RIFF/WAVE (host-side ingest entry points only) */
 #define IRA_E_HIP_BASE (-1000)
 
-#define IRA_ABI_VERSION 4   /* bumped whenever an exported signature or a scratch-size constant changes */
+#define IRA_ABI_VERSION 5   /* bumped whenever an exported signature or a scratch-size constant changes */
 
 int32_t ira_abi_version(void);
 const char* ira_error_string(int32_t code);
@@ -435,6 +435,17 @@ int32_t ira_wav_probe(const char* path, int32_t* sample_rate, int32_t* channels,
                       int64_t* data_offset);
 int32_t ira_wav_read_pcm16(const char* path, int64_t data_offset, int64_t frames, int32_t channels,
                            int16_t* dst_host);
+
+/* The same for a whole group of files in ONE call, on `threads` host threads created and joined inside the call (a caller
+ * with an interpreter lock releases it once per group instead of once per file).  status[i] = what ira_wav_probe /
+ * ira_wav_read_pcm16 returns for file i; the return value is IRA_OK unless an argument is NULL / n < 0.  File i's payload
+ * goes to dst_host + dst_off[i] (int16 elements).  Replaces the per-file loop around scipy.io.wavfile.read of reference
+ * analyse/bundle.py:56-67 -> report.py -> io.py:200. */
+int32_t ira_wav_probe_batch(const char* const* paths, int32_t n, int32_t threads, int32_t* status, int32_t* sample_rate,
+                            int32_t* channels, int64_t* frames, int64_t* data_offset);
+int32_t ira_wav_read_pcm16_batch(const char* const* paths, const int64_t* data_offset, const int64_t* frames,
+                                 const int32_t* channels, const int64_t* dst_off, int16_t* dst_host, int32_t n,
+                                 int32_t threads, int32_t* status);
 int32_t ira_pcm16_to_channels(const int16_t* pcm_dev, int64_t frames, int32_t channels, int32_t mono_downmix,
                               float* out_dev, void* stream);
 /* The same conversion for a GROUP of tap files in one launch (a bundle step holds 32 taps; one launch per tap was 27 % of a

@@ -144,3 +144,47 @@ def test_ingest_validation_messages(tmp_path):
         ingest._validate(ingest.probe_tap(p), 48000)
     assert ingest.channel_names(2, False) == ["left", "right"] and ingest.channel_names(2, True) == ["mono"]
     assert ingest.channel_names(1, False) == ["mono"] and ingest.channel_names(1, True) == ["mono"]
+
+
+def test_group_calls_equal_the_per_file_calls(tmp_path):
+    """ira_wav_probe_batch / ira_wav_read_pcm16_batch (a whole group of taps per library call, threads inside the call):
+    the same infos and payload bytes as the per-file entry points, for more files than threads, in group order; the first
+    offending file of a group raises what it raises on its own (a missing tap FileNotFoundError, a non-RIFF file
+    ValueError); an int32 file comes back as not native."""
+    from audio_analysis_amd import ingest
+    rng = np.random.default_rng(3)
+    paths, payloads = [], []
+    for i in range(37):
+        frames, ch = int(rng.integers(1, 3000)), int(rng.integers(1, 3))
+        pcm = rng.integers(-32768, 32768, size=(frames, ch), dtype=np.int16)
+        p = tmp_path / f"t{i:02d}.wav"
+        p.write_bytes(_wav16(pcm))
+        paths.append(p); payloads.append(pcm)
+    infos = ingest.probe_taps(paths)
+    assert [i.path for i in infos] == paths
+    for info, p, pcm in zip(infos, paths, payloads):
+        assert info == ingest.probe_tap(p) and info.native and (info.frames, info.channels) == pcm.shape
+    sizes = [(i.frames * i.channels + 1) & ~1 for i in infos]
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+    buf = np.full(int(sum(sizes)), 12345, dtype=np.int16)
+    ingest.read_taps_pcm16(infos, buf, offs.tolist())
+    for info, o, pcm in zip(infos, offs, payloads):
+        assert np.array_equal(buf[o : o + pcm.size].reshape(pcm.shape), pcm)
+        assert np.array_equal(ingest.read_tap_pcm16(info), pcm)
+    # errors: per-file types, first offender in group order
+    bad = tmp_path / "notwav.wav"
+    bad.write_bytes(b"this is not a RIFF file at all")
+    with pytest.raises(FileNotFoundError):
+        ingest.probe_taps(paths[:3] + [tmp_path / "missing.wav", bad])
+    with pytest.raises(ValueError):
+        ingest.probe_taps(paths[:3] + [bad, tmp_path / "missing.wav"])
+    with pytest.raises(ValueError):
+        ingest.read_taps_pcm16(infos[:2], np.zeros(4, dtype=np.int16), [0, 2])      # too small
+    assert ingest.probe_taps([]) == []
+
+
+def _wav16(pcm: np.ndarray) -> bytes:
+    data = pcm.astype("<i2").tobytes()
+    ch = pcm.shape[1]
+    return (b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, ch, 48000, 48000 * 2 * ch, 2 * ch, 16)
+            + b"data" + struct.pack("<I", len(data)) + data)
