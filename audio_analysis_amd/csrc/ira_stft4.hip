@@ -319,7 +319,8 @@ __global__ __launch_bounds__(TL5) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const double* __restrict__ window, const cdd* __restrict__ tw, double floor_lin, float floor_db,
     float* __restrict__ out, const int64_t* __restrict__ out_off, const int32_t* __restrict__ frame_sel,
     const int64_t* __restrict__ sel_off, int lb_nbins, int lb_kbase, const int32_t* __restrict__ lb_first,
-    const int32_t* __restrict__ lb_count) {
+    const int32_t* __restrict__ lb_count, int ablate) {
+  // ablate (IRA_STFT5_ABLATE, tuning build, timing only): 1 no window loads, 2 no sample loads, 4 no dB -> linear conversion
   __shared__ __attribute__((aligned(16))) cdd ex[EXC4];
   __shared__ ira::LogTabEntry ltab[ira::LOGTAB_N];
   __shared__ int lb_range[2];
@@ -356,8 +357,10 @@ __global__ __launch_bounds__(TL5) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) {
       const int n = n1 * 256 + q;
-      xa[n1] = fx[2 * n]; xb[n1] = fx[2 * n + 1];
-      wa[n1] = window[2 * n]; wb[n1] = window[2 * n + 1];
+      if (ablate & 2) { xa[n1] = (float)(n & 7) * 0.125f; xb[n1] = (float)(q & 3); }
+      else { xa[n1] = fx[2 * n]; xb[n1] = fx[2 * n + 1]; }
+      if (ablate & 1) { wa[n1] = 0.5 + 1e-4 * n1; wb[n1] = 0.25; }
+      else { wa[n1] = window[2 * n]; wb[n1] = window[2 * n + 1]; }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -484,6 +487,11 @@ __global__ __launch_bounds__(TL5) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const cdd o = {d.im, -d.re};
     const cdd wk = ira::cmul(wlane, wuni[i]);
     const cdd pp = ira::cmul(wk, o);
+    if (ablate & 4) {
+      if (need_a) exd[k] = e.re + pp.re;
+      if (need_b) exd[M4 - k] = e.im - pp.im;
+      continue;
+    }
     if (need_a) exd[k] = lin_of4(e.re + pp.re, e.im + pp.im, floor_pow, floor_db, floor_lin32, ltab);
     if (need_b) exd[M4 - k] = lin_of4(e.re - pp.re, e.im - pp.im, floor_pow, floor_db, floor_lin32, ltab);
   }
@@ -529,7 +537,7 @@ int32_t ira_stft4_dispatch_tf(const float* x, const int64_t* off, const int32_t*
   else
     stft5_kernel<<<grid, TL5, 0, st>>>(x, off, nframes, hop, static_cast<const double*>(window),
                                        static_cast<const cdd*>(tw), floor_lin, (float)floor_db, out, out_off, frame_sel,
-                                       sel_off, 0, 0, nullptr, nullptr);
+                                       sel_off, 0, 0, nullptr, nullptr, ira_tune_int("IRA_STFT5_ABLATE", 0));
   IRA_RETURN_LAUNCH();
 }
 
@@ -549,6 +557,6 @@ int32_t ira_stft4_dispatch_logbin(const float* x, const int64_t* off, const int3
   else
     stft5_kernel<<<grid, TL5, 0, st>>>(x, off, nframes, hop, static_cast<const double*>(window),
                                        static_cast<const cdd*>(tw), floor_lin, (float)floor_db, curves, curves_off,
-                                       nullptr, nullptr, nbins, k_base, first, count);
+                                       nullptr, nullptr, nbins, k_base, first, count, ira_tune_int("IRA_STFT5_ABLATE", 0));
   IRA_RETURN_LAUNCH();
 }
