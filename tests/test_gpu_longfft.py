@@ -164,6 +164,40 @@ def test_convolution_sizes_three_times_a_power_of_two():
         assert np.max(np.abs(g[:, 0] + 1j * g[:, 1] - ref)) / np.max(np.abs(ref)) < 5e-14
 
 
+def test_chirp_filter_pools_grow_evict_and_fall_back():
+    """Engine._filter_pool: pools per (M, stream) under one budget.  With a budget of a few filters the same spectra come
+    out whether the filters are cached, rebuilt after an eviction, built into a pool that had to grow, or built into a
+    private array because the call does not fit the budget at all."""
+    from audio_analysis_amd.engine import get_engine
+    eng = get_engine()
+    rng = np.random.default_rng(31)
+    x = (rng.standard_normal(40000) * np.exp(-np.arange(40000) / 6000.0)).astype(np.float32)
+    b = eng.upload([x])
+    sets = [[20011, 20013, 20017, 20021], [30011, 30013, 30029], [20011, 20023, 20029, 20047, 20051, 20063],
+            [9001, 9007, 9011, 9013, 9029, 9041, 9043, 9049, 9059, 9067, 9091, 9103]]
+    saved_budget, saved_pools = eng.filter_cache_bytes, dict(eng._filter_pools)
+    try:
+        ref = {}
+        for lens in sets:
+            for L, g in zip(lens, _spec(eng, x, lens, True)):
+                ref[L] = g.copy()
+                want = np.fft.rfft(x[:L].astype(np.float64) * np.hanning(L))
+                assert np.max(np.abs(g[:, 0] + 1j * g[:, 1] - want)) / np.max(np.abs(want)) < 5e-14
+        for budget in (6 << 20, 3 << 20, 1 << 20, 0):        # a handful of filters ... nothing: pool, eviction, private array
+            eng._filter_pools.clear()
+            eng.filter_cache_bytes = budget
+            for rep in range(2):
+                for lens in sets + sets[::-1]:
+                    for L, g in zip(lens, _spec(eng, x, lens, True)):
+                        assert np.array_equal(g, ref[L]), (budget, L)
+            total = sum(q["cap"] * 16 * k[0] for k, q in eng._filter_pools.items())
+            assert total <= max(budget, 0), (budget, total)
+    finally:
+        eng.filter_cache_bytes = saved_budget
+        eng._filter_pools.clear()
+        eng._filter_pools.update(saved_pools)
+
+
 def test_smooth_lengths_take_the_direct_transform_and_match_numpy():
     """n = 2^a 3^b 5^c: two-pass mixed-radix four-step (ira_rfft_smooth) against numpy and against Bluestein."""
     from audio_analysis_amd.engine import get_engine
