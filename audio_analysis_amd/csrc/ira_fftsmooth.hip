@@ -57,6 +57,7 @@ struct SmoothPlan {
   FastDiv dc1, dc2, dn1, dn2;       // the same numbers as divisors
   PassTab p1, p2;                   // radix passes of the N1- and N2-point transforms
   int c1, c2;                       // columns per workgroup in pass 1 / pass 2
+  unsigned c2_one;                  // 1 if c2 == 1 (branch-free i / c2 in pass 2's tile load, see there)
   int ld1, ld2;                     // LDS column strides (= n1 / n2, see column_stride)
   const cd* t1;                     // exp(-2 pi i k / N1), k < N1
   const cd* t2;                     // exp(-2 pi i k / N2), k < N2
@@ -603,11 +604,21 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_rows_kernel(SmoothPlan P, S
       i = i < total2 ? i : total2 - 1;
       raw[u] = w[(long long)bx * total2 + i];               // this tile: n2 * C + c, contiguous
     }
+    // (nothing may be scheduled across this line: left alone, hipcc 7.2 sinks every load to its LDS store to save
+    // registers -- load, s_waitcnt vmcnt(0), ds_write, eight times in a row: eight serial memory round trips per tile,
+    // tools/isa_serial_loads.py)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < SM_U; ++u) {
       int i = base + tid + SM_THREADS * u;
       i = i < total2 ? i : total2 - 1;
-      const int row = (int)fdiv((unsigned)i, P.dc2);
+      // i / C BRANCH-FREE (C = 1: magic 0, c2_one 1).  fdiv()'s `d <= 1 ? x : umulhi(x, magic)` is a uniform BRANCH here, and
+      // hipcc sinks each tile load into the block of its LDS store across it: load, s_waitcnt vmcnt(0), ds_write, eight times
+      // in a row -- eight serial memory round trips per tile (ISA dump, round 3; the sched_barrier above cannot help, the
+      // sinking happens before scheduling).  Same family as the `if (i < total)` guards of round 2, DESIGN.md section 4.3.
+      // Worth 1.6 % here (0.976 -> 0.960 ms per 64 channels): the tile's loads are not what its workgroup waits for.  (The
+      // same rewrite of fdiv() itself costs the pass-1 kernels 10-17 more spilled registers and loses 3 %.)
+      const int row = (int)(__umulhi((unsigned)i, P.dc2.magic) + (unsigned)i * P.c2_one);
       a[(i - row * C) * LD + row] = raw[u];
     }
   }
@@ -811,6 +822,7 @@ int32_t make_smooth_plan(int32_t n, const void* t1, const void* t2, const void* 
   P->ld1 = column_stride(n1, P->c1);
   P->ld2 = column_stride(n2, P->c2);
   P->dc1 = fast_div_of((unsigned)P->c1); P->dc2 = fast_div_of((unsigned)P->c2);
+  P->c2_one = P->c2 <= 1 ? 1u : 0u;
   P->dn1 = fast_div_of((unsigned)n1); P->dn2 = fast_div_of((unsigned)n2);
   P->t1 = static_cast<const cd*>(t1); P->t2 = static_cast<const cd*>(t2); P->tf = static_cast<const cd*>(tf);
   P->stamp = ira_tune_flag("IRA_SMOOTH_STAMP");
