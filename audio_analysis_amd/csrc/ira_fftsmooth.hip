@@ -68,7 +68,8 @@ struct SmoothPlan {
   int ablate;                       // diagnostics (IRA_SMOOTH_ABLATE, timing only -- results are wrong): 1 pass-2 band output
                                     // written tile-major (contiguous per workgroup), 2 pass-1 output contiguous, 4 pass-1
                                     // spectrum gather contiguous, 8 / 16 no transform in pass 1 / 2, 32 no input arithmetic
-                                    // in pass 1 (tools/smooth_ablate.sh, profiles/r03_smooth_ablation.txt)
+                                    // in pass 1, 64 no output-twiddle loads in pass 1, 128 no digit-reversed slot lookups
+                                    // (tools/smooth_ablate.sh, profiles/r03_smooth_ablation.txt)
 };
 
 // ---- radix butterflies, forward sign (W = exp(-2 pi i / r)), natural order in and out, registers only -------------------
@@ -543,6 +544,7 @@ __global__ __launch_bounds__(SM_THREADS, ((MODE == SM_SIGNAL || !HALF) ? 6 : 5))
       const int c = (int)fdiv((unsigned)i, P.dn1), k1 = i - c * N1;
       const unsigned p = (unsigned)k1 * (unsigned)(n2_0 + c);
       const unsigned hi = fdiv(p, P.dn2);
+      if (P.ablate & 64) { th[u] = {1.0, 0.0}; tl[u] = {0.0, 1.0}; continue; }
       th[u] = P.t1[hi];
       tl[u] = P.tf[p - hi * (unsigned)N2];
     }
@@ -554,7 +556,7 @@ __global__ __launch_bounds__(SM_THREADS, ((MODE == SM_SIGNAL || !HALF) ? 6 : 5))
       const int n2 = n2_0 + c;
       const int kt = (int)fdiv((unsigned)k1, P.dc2);                 // tile of k1 in pass 2
       w[(P.ablate & 2) ? (long long)bx * total1 + i : (long long)kt * ((long long)N2 * C2) + (long long)n2 * C2 + (k1 - kt * C2)] =
-          ira::cmul(r[c * LD + dif_slot(k1, P.p1)], ira::cmul(th[u], tl[u]));
+          ira::cmul(r[c * LD + ((P.ablate & 128) ? k1 : dif_slot(k1, P.p1))], ira::cmul(th[u], tl[u]));
     }
   }
   if (P.stamp) {
@@ -632,7 +634,7 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_rows_kernel(SmoothPlan P, S
   for (int i = tid; i < N2 * C; i += SM_THREADS) {
     const int k2 = (int)fdiv((unsigned)i, P.dc2), c = i - k2 * C;
     const long long k = (long long)(k1_0 + c) + (long long)N1 * k2;        // natural output index
-    cd v = r[c * LD + dif_slot(k2, P.p2)];
+    cd v = r[c * LD + ((P.ablate & 128) ? k2 : dif_slot(k2, P.p2))];
     if (OUT == SM_OUT_SPEC) {
       if (paired) {
         J.zpair[out1 + k] = v;
