@@ -237,12 +237,16 @@ void for_each_file(int32_t n, int32_t threads, F work) {
     return;
   }
   std::atomic<int32_t> next{0};
+  auto drain = [&]() {
+    for (int32_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) work(i);
+  };
   std::vector<std::thread> pool;
-  pool.reserve((size_t)threads);
-  for (int32_t t = 0; t < threads; ++t)
-    pool.emplace_back([&]() {
-      for (int32_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) work(i);
-    });
+  try {                                     // no exception may cross the C boundary: a thread that cannot be started
+    pool.reserve((size_t)threads);          // (resource limits) just means fewer readers -- the caller's thread drains too
+    for (int32_t t = 1; t < threads; ++t) pool.emplace_back(drain);
+  } catch (...) {
+  }
+  drain();
   for (auto& th : pool) th.join();
 }
 }  // namespace

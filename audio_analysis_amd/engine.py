@@ -142,7 +142,8 @@ class Engine:
         self.torch = torch
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self._tables: Dict[Tuple, object] = {}
-        self._filter_pools: Dict[int, dict] = {}
+        self._filter_pools: Dict[tuple, dict] = {}      # (M, stream) -> pool, see _filter_pool
+        self._filter_tick = 0
         self._ring = None
         if os.environ.get("IRA_WORKSPACE_MB"):            # tuning knob: long-FFT jobs per launch (see workspace_budget_bytes)
             self.workspace_budget_bytes = int(float(os.environ["IRA_WORKSPACE_MB"]) * (1 << 20))
@@ -679,7 +680,7 @@ class Engine:
         if limit < need_slots:
             return None
         key = (int(m), int(self.stream))
-        self._filter_tick = getattr(self, "_filter_tick", 0) + 1
+        self._filter_tick += 1
         pool = self._filter_pools.get(key)
         if pool is not None and pool["cap"] >= need_slots:
             pool["last"] = self._filter_tick
