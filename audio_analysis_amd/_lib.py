@@ -107,14 +107,25 @@ def load():
     import torch  # noqa: F401
 
     lib = C.CDLL(str(path))
+    rebuild = "rebuild it with `python -m audio_analysis_amd.build`" + (" --tuning" if tuning else "")
+    # The version FIRST: a stale library from an older ABI lacks the newer symbols, and binding them before this check would
+    # end in a bare AttributeError instead of the message a stale library is the case for.
+    try:
+        version = lib.ira_abi_version
+    except AttributeError:
+        raise IraError(f"{path} exports no ira_abi_version (not a libira build, or one older than the versioned ABI): "
+                       f"{rebuild}") from None
+    version.restype, version.argtypes = PROTOTYPES["ira_abi_version"]
+    have = int(version())
+    if have != ABI_VERSION:
+        raise IraError(f"{path} has ABI version {have}, this package binds version {ABI_VERSION}: {rebuild}")
     for name, (res, args) in PROTOTYPES.items():
-        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise IraError(f"{path} (ABI version {have}) does not export {name}: {rebuild}") from None
         fn.restype = res
         fn.argtypes = args
-    have = int(lib.ira_abi_version())
-    if have != ABI_VERSION:
-        raise IraError(f"{path} has ABI version {have}, this package binds version {ABI_VERSION}: rebuild it with "
-                       "`python -m audio_analysis_amd.build`" + (" --tuning" if tuning else ""))
     _lib = lib
     return lib
 

@@ -591,8 +591,8 @@ __global__ __launch_bounds__(SV_THREADS) void ar_solve_kernel(const double* __re
 //   ar_lag_dd_kernel    grid (chunks of LAG_CHUNK rows, 1, nb): p+1 lag sums of the chunk, one or more lags per thread
 //   ar_solve_dd_kernel  one workgroup per element: G from the lag sums by the same diagonal walk as ar_solve_kernel (exact
 //                       products of head / tail samples), Cholesky + solves in global scratch (p^2 double-doubles).
-// A pivot that is not positive RELATIVE to the trace (1e-26) means G is singular to working precision -- the element keeps
-// status 1 and ira_ar_minnorm returns lstsq's minimum-norm solution as before.
+// A pivot that is not positive RELATIVE to the trace (1e-26) means G is singular to working precision -- the element is
+// given status 1 (whatever brought it here) and ira_ar_minnorm returns lstsq's minimum-norm solution as before.
 // ------------------------------------------------------------------------------------------------------------
 struct dd { double hi, lo; };
 // `#pragma clang fp contract(off)` in every routine: this file is compiled with fused multiply-add contraction on, and a
@@ -757,7 +757,14 @@ __global__ __launch_bounds__(SV_THREADS) void ar_solve_dd_kernel(const double* _
     }
     __syncthreads();
   }
-  if (fail) return;                                     // singular to ~1e-26: status stays 1 -> ira_ar_minnorm
+  if (fail) {
+    // Singular to ~1e-26 of the trace even in double-double arithmetic.  The status is WRITTEN, not left as it was: an
+    // element that came here on its condition estimate alone still carries status 0 (its float64 pivots stayed positive by
+    // rounding noise) and would otherwise be refined from a meaningless float64 factor and reported as solved.  Status 1
+    // hands it to ira_ar_minnorm, which returns lstsq's minimum-norm solution (status 4 + rank).
+    if (tid == 0) info[IRA_AR_INFO_DOUBLES * e + 0] = 1.0;
+    return;
+  }
   for (int k = 0; k < p; ++k) {                         // L y = r
     if (tid == 0) vec[k] = dd_div(vec[k], G[(long long)k * p + k]);
     __syncthreads();

@@ -32,7 +32,12 @@ static inline int ira_tune_int(const char* name, int dflt) {
 }
 static inline const char* ira_tune_str(const char* name) { return std::getenv(name); }
 static inline bool ira_tune_flag(const char* name) { return std::getenv(name) != nullptr; }
+// timing-only ablation tests inside kernels ("results are wrong by construction"): IRA_ABL(mask & bit) is the test in the
+// tuning build and the constant 0 in the product library, which therefore carries no ablation path and pays no
+// per-element test for one
+#define IRA_ABL(expr) (expr)
 #else
+#define IRA_ABL(expr) 0
 static inline constexpr int ira_tune_int(const char*, int dflt) { return dflt; }
 static inline constexpr const char* ira_tune_str(const char*) { return nullptr; }
 static inline constexpr bool ira_tune_flag(const char*) { return false; }

@@ -425,7 +425,7 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
           const long long n = n0 + (long long)j * dn;
           const double h = (lw1 > 1) ? 0.5 + 0.5 * hc : 1.0;
           const double h2 = (lw2 > 1) ? 0.5 + 0.5 * hc2 : 1.0;
-          lds[c * stride + col_slot(g, n1)] = (g.ablate & 1) ? cd{(double)n, 1.0} : value_input<MODE>(J, ctx, n, M, w, h, h2, raw[u]);
+          lds[c * stride + col_slot(g, n1)] = (IRA_ABL(g.ablate & 1)) ? cd{(double)n, 1.0} : value_input<MODE>(J, ctx, n, M, w, h, h2, raw[u]);
           w = ira::cmul(w, d);
           d = ira::cmul(d, e2);
           const double nc = hc * rc - hs * rs;
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   }
   ira::tw_split_put(twl, twv, tid);
   __syncthreads();
-  if (!(g.ablate & 2)) {
+  if (!(IRA_ABL(g.ablate & 2))) {
     if (g.rad == 3) radix3_stage<false>(g, lds, twl, C, stride, tid);
     ira::lds_fft_dif<double, FL_LR, true>(lds, g.log2q, twl, (unsigned)g.rad, tid, FL_THREADS, C * g.rad, (1u << g.log2q) + 1u);
   }
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
       if (i >= total_o) continue;
       const unsigned c = i & cm, r = i >> lc;
       const cd v = ira::cmul(lds[c * stride + col_slot(g, r)], ira::cmul(th[u], tl[u]));
-      if ((g.ablate & 4) && v.re != 12345.678) continue;
+      if ((IRA_ABL(g.ablate & 4)) && v.re != 12345.678) continue;
       w[(long long)r * N2 + n2_0 + c] = v;
     }
   }
@@ -507,10 +507,10 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   }
   ira::tw_split_put(twl, twv, tid);
   __syncthreads();
-  if (!(g.ablate & 8)) ira::lds_fft_dif<double, FL_LR, true>(lds, g.log2n2, twl, 1u, tid, FL_THREADS, R, N2);
+  if (!(IRA_ABL(g.ablate & 8))) ira::lds_fft_dif<double, FL_LR, true>(lds, g.log2n2, twl, 1u, tid, FL_THREADS, R, N2);
   if (MODE == ROW_CONV) {
     const cd* b = J.bfilt + (long long)filt * M + (long long)r0 * N2;
-    if (!(g.ablate & 16))
+    if (!(IRA_ABL(g.ablate & 16)))
       for (unsigned base = 0; base < total; base += FL_THREADS * FL_U) {
         cd fb[FL_U];
 #pragma unroll
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         }
       }
     __syncthreads();
-    if (!(g.ablate & 8)) ira::lds_fft_dit<double, FL_LR, true>(lds, g.log2n2, twl, 1u, true, tid, FL_THREADS, R, N2);
+    if (!(IRA_ABL(g.ablate & 8))) ira::lds_fft_dit<double, FL_LR, true>(lds, g.log2n2, twl, 1u, true, tid, FL_THREADS, R, N2);
     for (unsigned base = 0; base < total; base += FL_THREADS * FL_UI) {
       cd th[FL_UI], tl[FL_UI];
 #pragma unroll
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         cd t = ira::cmul(th[u], tl[u]);
         t.im = -t.im;
         const cd v = ira::cmul(lds[i], t);
-        if ((g.ablate & 128) && v.re != 12345.678) continue;
+        if ((IRA_ABL(g.ablate & 128)) && v.re != 12345.678) continue;
         w[i] = v;
       }
     }
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     for (int u = 0; u < FL_U; ++u) {
       unsigned i = base + tid + FL_THREADS * u;
       i = i < total ? i : total - 1;
-      raw[u] = (g.ablate & 256) ? cd{(double)i, 1.0} : w[(long long)(i >> lc) * N2 + n2_0 + (i & cm)];
+      raw[u] = (IRA_ABL(g.ablate & 256)) ? cd{(double)i, 1.0} : w[(long long)(i >> lc) * N2 + n2_0 + (i & cm)];
     }
 #pragma unroll
     for (int u = 0; u < FL_U; ++u) {
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   }
   ira::tw_split_put(twl, twv, tid);
   __syncthreads();
-  if (!(g.ablate & 32)) {
+  if (!(IRA_ABL(g.ablate & 32))) {
     ira::lds_fft_dit<double, FL_LR, true>(lds, g.log2q, twl, (unsigned)g.rad, true, tid, FL_THREADS, C * g.rad, (1u << g.log2q) + 1u);
     if (g.rad == 3) radix3_stage<true>(g, lds, twl, C, stride, tid);
   }
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     cdl = ira::cmul(cdl, ce2);
     if (n >= n_need) continue;
     cd v = lds[c * stride + col_slot(g, n1)];
-    if (!(g.ablate & 64)) v = ira::cmul(v, wn);
+    if (!(IRA_ABL(g.ablate & 64))) v = ira::cmul(v, wn);
     if (MODE == OUT_SPECTRUM) {
       v.re *= inv_m; v.im *= inv_m;
       if (paired) {

@@ -496,7 +496,7 @@ __global__ __launch_bounds__(SM_THREADS, ((MODE == SM_SIGNAL || !HALF) ? 6 : 5))
     auto index_of = [&](int u) -> long long {               // recomputed, not kept: registers are what limits occupancy
       int i = base + tid + SM_THREADS * u;
       i = i < total1 ? i : total1 - 1;                      // clamp: every fetch is unconditional (stays in registers)
-      if (P.ablate & 4) return (long long)bx * total1 + i;
+      if (IRA_ABL(P.ablate & 4)) return (long long)bx * total1 + i;
       const int row = (int)fdiv((unsigned)i, P.dc1);
       return (long long)row * N2 + n2_0 + (i - row * C);
     };
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(SM_THREADS, ((MODE == SM_SIGNAL || !HALF) ? 6 : 5))
       // support the masks, the Hermitian extension and the products (~80 of the ~280 instructions per element of this
       // kernel) are skipped and the element is zero -- what the multiplication by the zero masks gives.
       cd v = {0.0, 0.0};
-      if (P.ablate & 32) v = {raw[u].a, raw[u].b}; else
+      if (IRA_ABL(P.ablate & 32)) v = {raw[u].a, raw[u].b}; else
       if (MODE != SM_SPECTRUM || __builtin_amdgcn_ballot_w64(smooth_nonzero<HALF>(P, ctx, index_of(u))) != 0ull)
         v = smooth_value<MODE, HALF>(P, J, ctx, index_of(u), raw[u], cs, sn);
       const int row = (int)fdiv((unsigned)i, P.dc1);
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(SM_THREADS, ((MODE == SM_SIGNAL || !HALF) ? 6 : 5))
   __syncthreads();
   SM_STAMP(s1);
   const cd* r = a;
-  if (!(P.ablate & 8)) lds_fft_dif_inplace(a, LD, P.p1, twl, tid, C);
+  if (!(IRA_ABL(P.ablate & 8))) lds_fft_dif_inplace(a, LD, P.p1, twl, tid, C);
   SM_STAMP(s2);
   cd* w = work + (long long)e * P.n;
   const int C2 = P.c2;
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(SM_THREADS, ((MODE == SM_SIGNAL || !HALF) ? 6 : 5))
       const int c = (int)fdiv((unsigned)i, P.dn1), k1 = i - c * N1;
       const unsigned p = (unsigned)k1 * (unsigned)(n2_0 + c);
       const unsigned hi = fdiv(p, P.dn2);
-      if (P.ablate & 64) { th[u] = {1.0, 0.0}; tl[u] = {0.0, 1.0}; continue; }
+      if (IRA_ABL(P.ablate & 64)) { th[u] = {1.0, 0.0}; tl[u] = {0.0, 1.0}; continue; }
       th[u] = P.t1[hi];
       tl[u] = P.tf[p - hi * (unsigned)N2];
     }
@@ -555,8 +555,8 @@ __global__ __launch_bounds__(SM_THREADS, ((MODE == SM_SIGNAL || !HALF) ? 6 : 5))
       const int c = (int)fdiv((unsigned)i, P.dn1), k1 = i - c * N1;
       const int n2 = n2_0 + c;
       const int kt = (int)fdiv((unsigned)k1, P.dc2);                 // tile of k1 in pass 2
-      w[(P.ablate & 2) ? (long long)bx * total1 + i : (long long)kt * ((long long)N2 * C2) + (long long)n2 * C2 + (k1 - kt * C2)] =
-          ira::cmul(r[c * LD + ((P.ablate & 128) ? k1 : dif_slot(k1, P.p1))], ira::cmul(th[u], tl[u]));
+      w[(IRA_ABL(P.ablate & 2)) ? (long long)bx * total1 + i : (long long)kt * ((long long)N2 * C2) + (long long)n2 * C2 + (k1 - kt * C2)] =
+          ira::cmul(r[c * LD + ((IRA_ABL(P.ablate & 128)) ? k1 : dif_slot(k1, P.p1))], ira::cmul(th[u], tl[u]));
     }
   }
   if (P.stamp) {
@@ -628,13 +628,13 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_rows_kernel(SmoothPlan P, S
   __syncthreads();
   SM_STAMP(s1);
   const cd* r = a;
-  if (!(P.ablate & 16)) lds_fft_dif_inplace(a, LD, P.p2, twl, tid, C);
+  if (!(IRA_ABL(P.ablate & 16))) lds_fft_dif_inplace(a, LD, P.p2, twl, tid, C);
   SM_STAMP(s2);
   const long long n = P.n;
   for (int i = tid; i < N2 * C; i += SM_THREADS) {
     const int k2 = (int)fdiv((unsigned)i, P.dc2), c = i - k2 * C;
     const long long k = (long long)(k1_0 + c) + (long long)N1 * k2;        // natural output index
-    cd v = r[c * LD + ((P.ablate & 128) ? k2 : dif_slot(k2, P.p2))];
+    cd v = r[c * LD + ((IRA_ABL(P.ablate & 128)) ? k2 : dif_slot(k2, P.p2))];
     if (OUT == SM_OUT_SPEC) {
       if (paired) {
         J.zpair[out1 + k] = v;
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_rows_kernel(SmoothPlan P, S
       J.y[out1 + 2 * k + 1] = (float)(-v.im * sc);
     } else {
       const double sc = 1.0 / (double)n;
-      const long long ko = (P.ablate & 1) ? (long long)bx * total2 + i : k;
+      const long long ko = (IRA_ABL(P.ablate & 1)) ? (long long)bx * total2 + i : k;
       J.y[out1 + ko] = (float)(v.re * sc);
       if (out2 >= 0) J.y[out2 + ko] = (float)(-v.im * sc);
     }

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64 * TW * NT) void stft2_kernel(
 
   // diagnostic (ablate bit 256): per-phase cycle stamps of wave 0 of workgroup (0,0), written over out[0..7]
   unsigned long long st[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define IRA_STAMP(i) do { if (ablate & 256) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); st[i] = t_; } } while (0)
+#define IRA_STAMP(i) do { if (IRA_ABL(ablate & 256)) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); st[i] = t_; } } while (0)
   static_assert(FS == 1 || FS == 2, "FS == 2 holds frame 0's outputs in registers while frame 1 runs");
   float keep_lo[FS == 2 ? C::NPAIR : 1], keep_hi[FS == 2 ? C::NPAIR : 1], keep_mid = 0.f;
   float lo[C::NPAIR], hi[C::NPAIR], mid = 0.f;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64 * TW * NT) void stft2_kernel(
         if (c4 + c < ncol) gp[c] = tp[c];
     }
   }
-  if ((ablate & 256) && wg == 1 && tid == 0) {
+  if ((IRA_ABL(ablate & 256)) && wg == 1 && tid == 0) {
     IRA_STAMP(7);
     printf("STAMPS step1 %llu step2 %llu step3 %llu post %llu keep %llu barrier %llu tile+store %llu | step2(h=1): reads %llu dft16 %llu tw+writes %llu\n",
            st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6] - st[5], st[7] - st[6],

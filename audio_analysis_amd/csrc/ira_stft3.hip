@@ -68,11 +68,11 @@ __global__ __launch_bounds__(64 * NT3) void stft3_kernel(
   const unsigned orig = blockIdx.y * gx + blockIdx.x;
   const unsigned xq = nwg / 8, xr = nwg % 8, xcd = orig % 8;
   const unsigned wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + orig / 8;
-  if ((ablate & 48) && orig < 256u * (16 / NT3) * 1u) {
+  if ((IRA_ABL(ablate & 48)) && orig < 256u * (16 / NT3) * 1u) {
     // diagnostic: stagger the first round of workgroups so that co-resident ones are out of phase
-    const unsigned slot = (NT3 == 16) ? ((ablate & 16) ? ((orig >> 3) & 1u) : ((orig >> 3) & 3u))
-                                      : ((ablate & 16) ? (orig / 256u) % (16 / NT3) : orig % (16 / NT3));
-    for (unsigned i = 0; i < slot * (unsigned)(ablate >> 8); ++i) __builtin_amdgcn_s_sleep(100);
+    const unsigned slot = (NT3 == 16) ? ((IRA_ABL(ablate & 16)) ? ((orig >> 3) & 1u) : ((orig >> 3) & 3u))
+                                      : ((IRA_ABL(ablate & 16)) ? (orig / 256u) % (16 / NT3) : orig % (16 / NT3));
+    for (unsigned i = 0; i < slot * (unsigned)IRA_ABL(ablate >> 8); ++i) __builtin_amdgcn_s_sleep(100);
   }
   const int seg = (int)(wg / gx);
   const int T_out = nframes[seg];
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(64 * NT3) void stft3_kernel(
   const int team = __builtin_amdgcn_readfirstlane(tid >> 6), q = tid & 63;
   cf* ex = reinterpret_cast<cf*>(smem_raw) + (size_t)team * EXC;
   unsigned long long st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define IRA_STAMP(i) do { if (ablate & 128) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); st[i] = t_; } } while (0)
+#define IRA_STAMP(i) do { if (IRA_ABL(ablate & 128)) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); st[i] = t_; } } while (0)
   IRA_STAMP(0);
   float* exf = reinterpret_cast<float*>(ex);
   // The Hann window (16 KB) is the same for every frame: one copy in LDS per workgroup instead of 16 KB of L1 traffic
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64 * NT3) void stft3_kernel(
   // around every load).
   const int64_t frame = (col < T_out) ? (frame_sel ? (int64_t)frame_sel[sel_off[seg] + col] : (int64_t)col) : 0;
   const float* fx = x + off[seg] + frame * hop;
-  if (ablate & 64) fx = x + ((size_t)(wg * TB3 + team) * 4096u) % (size_t)(30720000u - 8192u);   // diagnostic: disjoint frames
+  if (IRA_ABL(ablate & 64)) fx = x + ((size_t)(wg * TB3 + team) * 4096u) % (size_t)(30720000u - 8192u);   // diagnostic: disjoint frames
   const int k1l = q & 15, n3a = q >> 4;
 
   // ---- step 1 -------------------------------------------------------------------------------------------------
@@ -109,8 +109,8 @@ __global__ __launch_bounds__(64 * NT3) void stft3_kernel(
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) {
       const int n = n1 * 128 + m;
-      if (ablate & 1) { xa[n1] = (float)n; xb[n1] = (float)(n + 1); } else { xa[n1] = fx[2 * n]; xb[n1] = fx[2 * n + 1]; }
-      if (ablate & 2) { wa[n1] = 0.5f; wb[n1] = 0.25f; } else { wa[n1] = winl[2 * n]; wb[n1] = winl[2 * n + 1]; }
+      if (IRA_ABL(ablate & 1)) { xa[n1] = (float)n; xb[n1] = (float)(n + 1); } else { xa[n1] = fx[2 * n]; xb[n1] = fx[2 * n + 1]; }
+      if (IRA_ABL(ablate & 2)) { wa[n1] = 0.5f; wb[n1] = 0.25f; } else { wa[n1] = winl[2 * n]; wb[n1] = winl[2 * n + 1]; }
     }
     __builtin_amdgcn_sched_barrier(0);
     cf v[16];
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(64 * NT3) void stft3_kernel(
     const cf o = {d.im, -d.re};
     const cf wk = ira::cmul(wlane, tw[64 * i]);          // W_N^k = W_N^q W_N^(64 i); second factor wave-uniform
     const cf pp = ira::cmul(wk, o);
-    if (ablate & 8) { lo[i] = e.re + pp.re; hi[i] = e.im - pp.im; continue; }
+    if (IRA_ABL(ablate & 8)) { lo[i] = e.re + pp.re; hi[i] = e.im - pp.im; continue; }
     lo[i] = db_of(e.re + pp.re, e.im + pp.im, floor_pow, floor_db);
     hi[i] = db_of(e.re - pp.re, e.im - pp.im, floor_pow, floor_db);
   }
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(64 * NT3) void stft3_kernel(
   // aligned (T is arbitrary); global dwordx4 stores accept that.
   typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
   constexpr int QR = TB3 / 4;
-  for (int idx = tid; idx < ((ablate & 4) ? 1 : F3 * QR); idx += 64 * NT3) {
+  for (int idx = tid; idx < ((IRA_ABL(ablate & 4)) ? 1 : F3 * QR); idx += 64 * NT3) {
     const int k = idx / QR, c4 = (idx % QR) * 4;
     const float* tp = tile + k * (TB3 + 1) + c4;
     float* gp = o + (int64_t)k * T_out + col0 + c4;
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(64 * NT3) void stft3_kernel(
         if (c4 + c < ncol) gp[c] = tp[c];
     }
   }
-  if (ablate & 128) {
+  if (IRA_ABL(ablate & 128)) {
     unsigned long long t5, t6;
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t5) :: "memory");          // stores issued, not yet acknowledged

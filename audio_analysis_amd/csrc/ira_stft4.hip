@@ -357,9 +357,9 @@ __global__ __launch_bounds__(TL5) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) {
       const int n = n1 * 256 + q;
-      if (ablate & 2) { xa[n1] = (float)(n & 7) * 0.125f; xb[n1] = (float)(q & 3); }
+      if (IRA_ABL(ablate & 2)) { xa[n1] = (float)(n & 7) * 0.125f; xb[n1] = (float)(q & 3); }
       else { xa[n1] = fx[2 * n]; xb[n1] = fx[2 * n + 1]; }
-      if (ablate & 1) { wa[n1] = 0.5 + 1e-4 * n1; wb[n1] = 0.25; }
+      if (IRA_ABL(ablate & 1)) { wa[n1] = 0.5 + 1e-4 * n1; wb[n1] = 0.25; }
       else { wa[n1] = window[2 * n]; wb[n1] = window[2 * n + 1]; }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(TL5) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const cdd o = {d.im, -d.re};
     const cdd wk = ira::cmul(wlane, wuni[i]);
     const cdd pp = ira::cmul(wk, o);
-    if (ablate & 4) {
+    if (IRA_ABL(ablate & 4)) {
       if (need_a) exd[k] = e.re + pp.re;
       if (need_b) exd[M4 - k] = e.im - pp.im;
       continue;

@@ -236,6 +236,42 @@ def test_rank_deficient_fits_return_the_minimum_norm_solution():
         zplane._fit_ar_least_squares(bad.astype(np.float64), 16)
 
 
+def test_singular_gram_flagged_by_its_condition_estimate_gets_the_minimum_norm_solution():
+    """exactly periodic segments make the Gram matrix exactly singular (columns of the Hankel matrix
+    repeat), but the float64 Cholesky pivots of such a matrix can stay positive by rounding noise: the element then reaches
+    the double-double solver with status 0, on its condition estimate alone.  When the double-double factorisation finds it
+    singular it must SAY so (status 1 -> ira_ar_minnorm -> status 4 + rank), not leave a status 0 behind that sends the
+    element through refinement of a meaningless float64 factor and reports noise coefficients as a solved fit."""
+    from audio_analysis_amd.engine import get_engine
+    from audio_analysis_amd.synth import synth_ir
+    eng = get_engine()
+    n = 6000
+    rng = np.random.default_rng(77)
+    chans, periods = [], (3, 4, 8, 12, 20)
+    for per in periods:
+        chans.append(np.tile(rng.standard_normal(per).astype(np.float32), n // per + 1)[:n].copy())
+    good = synth_ir(32, 0, n, rt60_seconds=0.05, pre_delay=0)
+    chans.append(good)
+    b = eng.upload(chans)
+    for order in (32, 64):
+        co, info = eng.ar_fit(b.x, b.off, b.length.astype(np.int32), None, order)
+        co, info = co.cpu().numpy(), info.cpu().numpy()
+        assert list(info[:-1, 0]) == [4.0] * len(periods), (order, info[:, 0])
+        assert info[-1, 0] in (0.0, 2.0)
+        for i, per in enumerate(periods):
+            assert 1 <= info[i, 3] <= per, (order, per, info[i])                # the rank lstsq sees: at most the period
+            ref = O.fit_ar(chans[i].astype(np.float64), order)
+            scale = max(1.0, float(np.abs(ref).max()))
+            assert np.abs(co[i] - ref).max() <= 1e-8 * scale, (order, per, np.abs(co[i] - ref).max())
+    # the same through the float64 sample path (deconvolved responses are float64 on the device)
+    x64 = np.concatenate([c.astype(np.float64) for c in chans[:3]])
+    d64 = eng.to_dev(x64)
+    off = np.arange(3, dtype=np.int64) * n
+    co, info = eng.ar_fit(d64, off, np.full(3, n, np.int32), None, 64, x_is_f64=True)
+    info = info.cpu().numpy()
+    assert list(info[:, 0]) == [4.0, 4.0, 4.0], info[:, 0]
+
+
 def _match_poles(got, ref):
     """Greedy nearest-neighbour matching of two pole sets (numpy.roots' order is unspecified): max |got - ref| over pairs."""
     got = list(got)

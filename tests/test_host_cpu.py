@@ -43,6 +43,29 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert lib.ira_ar_partial_doubles(64, 10) == 0
 
 
+def test_stale_library_is_named_as_such(tmp_path):
+    """a libira.so left over from an older ABI lacks the newer symbols.  The loader checks the version BEFORE it
+    binds the prototypes, so the failure is the "rebuild it" message and not a bare AttributeError; the same for a library
+    of the right version that lacks a symbol."""
+    src = tmp_path / "stale.c"
+    for tag, body in (("old", "int ira_abi_version(void) { return 1; }"),
+                      ("holes", "int ira_abi_version(void) { return %d; }" % __import__("audio_analysis_amd._lib", fromlist=["x"]).ABI_VERSION),
+                      ("none", "int unrelated(void) { return 0; }")):
+        src.write_text(body + "\n")
+        so = tmp_path / f"libira_{tag}.so"
+        subprocess.run(["gcc", "-shared", "-fPIC", str(src), "-o", str(so)], check=True)
+        code = ("from audio_analysis_amd import _lib\n"
+                "try:\n    _lib.load()\nexcept _lib.IraError as e:\n    print('IraError:', e)\n")
+        env = dict(os.environ, IRA_TUNING="1", IRA_LIBRARY=str(so), PYTHONPATH=str(REPO))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=str(REPO))
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "IraError:" in r.stdout and "audio_analysis_amd.build" in r.stdout, (tag, r.stdout, r.stderr[-500:])
+        if tag == "old":
+            assert "ABI version 1" in r.stdout
+        if tag == "holes":
+            assert "does not export" in r.stdout
+
+
 def test_argument_validation_without_gpu():
     """Entry points reject bad arguments before touching the device (no compute calls here)."""
     from audio_analysis_amd import _lib
