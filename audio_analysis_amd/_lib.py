@@ -13,7 +13,7 @@ _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libira.so"
 _lib = None
 # must equal IRA_ABI_VERSION of include/ira.h: a stale .so called with this file's prototypes would read shifted
 # arguments or undersized scratch (memory corruption on the GPU instead of a clean error)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_f32p = C.c_void_p
 c_i64p = C.c_void_p
@@ -41,9 +41,9 @@ PROTOTYPES = {
     "ira_fft_split": (i32, [i32, vp, vp]),
     "ira_bluestein_filter": (i32, [vp, i32, i32, vp, vp, vp, vp, vp]),
     "ira_rfft_any": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp,
-                           vp, vp]),
+                           vp, i32, vp]),
     "ira_band_irfft": (i32, [vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
-    "ira_spectrum_mag_phase": (i32, [vp, vp, vp, i32, i32, f64, vp, vp, vp, vp, vp]),
+    "ira_spectrum_mag_phase": (i32, [vp, vp, vp, i32, i32, f64, vp, vp, vp, vp, vp, vp]),
     "ira_phase_unwrap": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "ira_log_smooth_db": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "ira_group_delay": (i32, [vp, vp, vp, i32, i32, vp, f64, vp, vp, vp]),

@@ -127,8 +127,10 @@ def spectrum_device(eng, batch, sample_rate_hz: int, settings, what: str, want_p
     (unwrapped) phase and the (n, 8) statistics records of ira_spectrum_stats, all left in HBM.
     """
     starts, lens = spectrum_segments(eng, batch, sample_rate_hz, settings, what)
-    spec, off = eng.rfft_any(batch.x, batch.off + starts, lens, bool(settings.use_hann_window))
-    mag, ph = eng.spectrum_mag_phase(spec, off, lens, float(settings.magnitude_floor_db), want_phase=want_phase)
+    # nothing but the dB / phase kernel reads these spectra: even-length Bluestein elements stay packed (engine.rfft_any)
+    spec, off, packed = eng.rfft_any(batch.x, batch.off + starts, lens, bool(settings.use_hann_window), packed_ok=True)
+    mag, ph = eng.spectrum_mag_phase(spec, off, lens, float(settings.magnitude_floor_db), want_phase=want_phase,
+                                     packed=packed)
     phase = eng.phase_unwrap(ph, off, lens, unwrap, degrees) if want_phase else None
     nyq = 0.5 * float(sample_rate_hz)
     f_lo = float(np.clip(settings.f_min_hz, 0.0, nyq))
@@ -149,8 +151,8 @@ def spectrum_device(eng, batch, sample_rate_hz: int, settings, what: str, want_p
             smoothed = eng.log_smooth(mag, off, np.ones(len(rng), np.int32), k_lo, nsel, steps, bins_w,
                                       int(getattr(settings, "log_bins_per_octave", 96)), through_float32=False)
     stats = eng.spectrum_stats(mag, off, lens, steps, f_lo, f_hi, 1000.0)
-    return dict(spec=spec, off=off, starts=starts, lens=lens, mag=mag, phase=phase, stats=stats, f_lo=f_lo, f_hi=f_hi,
-                smoothed=smoothed)
+    return dict(spec=spec, off=off, packed=packed, starts=starts, lens=lens, mag=mag, phase=phase, stats=stats, f_lo=f_lo,
+                f_hi=f_hi, smoothed=smoothed)
 
 
 def analyse_frequency_response_batch(

@@ -97,12 +97,16 @@ def group_delay_device(eng, batch, sample_rate_hz: int, settings: GroupDelayAnal
     n_fft = np.array([fft_size_for(int(v), settings) for v in lens], dtype=np.int64)
     if np.any(n_fft < 2) or np.any(n_fft > (1 << 21)):
         raise ValueError("group delay needs 2 <= fft_size <= 2097152.")
-    spec, off = eng.rfft_any(batch.x, batch.off + starts, n_fft.astype(np.int32), bool(settings.use_hann_window),
-                             data_len=np.minimum(lens, n_fft).astype(np.int32), win_len=lens.astype(np.int32))
-    _, ph = eng.spectrum_mag_phase(spec, off, n_fft.astype(np.int32), -400.0, want_phase=True)
-    ph64 = eng.phase_unwrap(ph, off, n_fft.astype(np.int32), bool(settings.unwrap_phase), False, as_float64=True)
-    steps = np.array([rfft_bin_step(int(v), sample_rate_hz) for v in n_fft], dtype=np.float64)
-    gd = eng.group_delay(ph64, off, n_fft, steps, float(sample_rate_hz))
+    tag, eng.event_tag = eng.event_tag, "[gd]"             # per-call device times of this block (bench.py) under their own names
+    try:
+        spec, off = eng.rfft_any(batch.x, batch.off + starts, n_fft.astype(np.int32), bool(settings.use_hann_window),
+                                 data_len=np.minimum(lens, n_fft).astype(np.int32), win_len=lens.astype(np.int32))
+        _, ph = eng.spectrum_mag_phase(spec, off, n_fft.astype(np.int32), -400.0, want_phase=True)
+        ph64 = eng.phase_unwrap(ph, off, n_fft.astype(np.int32), bool(settings.unwrap_phase), False, as_float64=True)
+        steps = np.array([rfft_bin_step(int(v), sample_rate_hz) for v in n_fft], dtype=np.float64)
+        gd = eng.group_delay(ph64, off, n_fft, steps, float(sample_rate_hz))
+    finally:
+        eng.event_tag = tag
     return dict(gd=gd, off=off, n_fft=n_fft, starts=starts, lens=lens)
 
 

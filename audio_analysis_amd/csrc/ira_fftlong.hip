@@ -801,7 +801,8 @@ extern "C" int32_t ira_rfft_any(const float* x_dev, const int64_t* xoff_dev, con
                                 const int64_t* x2off_dev, const int64_t* spec_off2_dev, double* zpair_dev,
                                 const int64_t* zpair_off_dev, int32_t max_len, const int32_t* data_len_dev,
                                 const int32_t* win_len_dev, const int32_t* data_len2_dev,
-                                const int32_t* win_len2_dev, const int32_t* interleave_dev, void* stream) {
+                                const int32_t* win_len2_dev, const int32_t* interleave_dev, int32_t keep_packed,
+                                void* stream) {
   IRA_CHECK_PTR(x_dev); IRA_CHECK_PTR(xoff_dev); IRA_CHECK_PTR(L_dev); IRA_CHECK_PTR(t1_dev); IRA_CHECK_PTR(t2_dev);
   IRA_CHECK_PTR(tf_dev); IRA_CHECK_PTR(bfilt_dev); IRA_CHECK_PTR(bidx_dev); IRA_CHECK_PTR(work_dev);
   IRA_CHECK_PTR(spec_out_dev); IRA_CHECK_PTR(spec_off_dev);
@@ -825,7 +826,9 @@ extern "C" int32_t ira_rfft_any(const float* x_dev, const int64_t* xoff_dev, con
   rc = run_convolution<IN_SIGNAL, OUT_SPECTRUM>(p, J, reinterpret_cast<cd*>(work_dev), nb, (hipStream_t)stream);
   if (rc != IRA_OK || x2off_dev == nullptr) return rc;
   pair_split_kernel<<<dim3((max_len / 2 + 1 + 255) / 256, nb), 256, 0, (hipStream_t)stream>>>(J);
-  if (interleave_dev != nullptr)
+  // keep_packed: the half-length transforms Z of interleaved elements stay as the column pass wrote them (zpair); the
+  // consumer untangles them on the fly (ira_spectrum_mag_phase with packed_dev) -- no read-modify-write pass over Z
+  if (interleave_dev != nullptr && !keep_packed)
     half_split_kernel<<<dim3((max_len + 1 + 255) / 256, nb), 256, 0, (hipStream_t)stream>>>(J);
   IRA_RETURN_LAUNCH();
 }

@@ -64,6 +64,11 @@ struct SmoothPlan {
   const cd* tf;                     // exp(-2 pi i k / n),  k < N2
   double hstep_c, hstep_s;          // half-size inverse: cos / sin of pi (256 / c1) / n1, the step of the W_2n^(-i) twiddle
                                     // between a thread's consecutive pass-1 elements (valid when 256 % c1 == 0)
+  int pairs;                        // forward transform of an interleaved real signal with the untangling FUSED into pass 2:
+                                    // the intermediate is stored in MIRROR-PAIR tiles -- tile 0 = rows {0, n1/2}, tile p =
+                                    // rows {p, n1 - p} (n1 even, c2 = 2) -- so that Z[k] and Z[n - k] meet in one workgroup
+  double pstep_c, pstep_s;          // pairs: cos / sin of -pi (256 / 2) / n2, the step of W_2n^k between a thread's
+                                    // consecutive pass-2 elements (k advances by 128 n1)
   int stamp;                        // diagnostics (IRA_SMOOTH_STAMP): per-phase cycle counts of one workgroup per kernel
   int ablate;                       // diagnostics (IRA_SMOOTH_ABLATE, timing only -- results are wrong): 1 pass-2 band output
                                     // written tile-major (contiguous per workgroup), 2 pass-1 output contiguous, 4 pass-1
@@ -284,7 +289,7 @@ struct SJobs {
 };
 
 enum { SM_SIGNAL = 0, SM_SPECTRUM = 1 };
-enum { SM_OUT_SPEC = 0, SM_OUT_BANDS = 1 };
+enum { SM_OUT_SPEC = 0, SM_OUT_BANDS = 1, SM_OUT_SPEC_PAIRS = 2 };
 
 __device__ __forceinline__ double hann_s(long long i, long long L) {
   if (L <= 1) return 1.0;
@@ -535,13 +540,22 @@ __global__ __launch_bounds__(SM_THREADS, ((MODE == SM_SIGNAL || !HALF) ? 6 : 5))
   SM_STAMP(s2);
   cd* w = work + (long long)e * P.n;
   const int C2 = P.c2;
+  // SM_SIGNAL with HALF = the MIRROR-PAIR layout of the intermediate (SmoothPlan::pairs): position j of a column stands for
+  // row k1 = j/2 (even j; tile j/2, member 0) or its mirror n1 - j/2 (odd j; member 1) -- j = 0 / 1 are the two rows that
+  // mirror themselves, 0 and n1/2 -- so that neighbouring lanes write the two members of one tile: 32 contiguous bytes.
+  constexpr bool PAIRS = MODE == SM_SIGNAL && HALF;
+  auto row_of = [&](int j) -> int {
+    if (!PAIRS) return j;
+    const int q = j >> 1;
+    return (j & 1) ? (q == 0 ? (N1 >> 1) : N1 - q) : q;
+  };
   for (int base = 0; base < total1; base += SM_THREADS * SM_UC) {
     cd th[SM_UC], tl[SM_UC];                               // the twiddle factors W_n^(k1 n2) of the batch: loads first
 #pragma unroll
     for (int u = 0; u < SM_UC; ++u) {
       int i = base + tid + SM_THREADS * u;
       i = i < total1 ? i : total1 - 1;
-      const int c = (int)fdiv((unsigned)i, P.dn1), k1 = i - c * N1;
+      const int c = (int)fdiv((unsigned)i, P.dn1), k1 = row_of(i - c * N1);
       const unsigned p = (unsigned)k1 * (unsigned)(n2_0 + c);
       const unsigned hi = fdiv(p, P.dn2);
       if (IRA_ABL(P.ablate & 64)) { th[u] = {1.0, 0.0}; tl[u] = {0.0, 1.0}; continue; }
@@ -552,10 +566,11 @@ __global__ __launch_bounds__(SM_THREADS, ((MODE == SM_SIGNAL || !HALF) ? 6 : 5))
     for (int u = 0; u < SM_UC; ++u) {
       const int i = base + tid + SM_THREADS * u;
       if (i >= total1) continue;
-      const int c = (int)fdiv((unsigned)i, P.dn1), k1 = i - c * N1;
+      const int c = (int)fdiv((unsigned)i, P.dn1), j = i - c * N1, k1 = row_of(j);
       const int n2 = n2_0 + c;
-      const int kt = (int)fdiv((unsigned)k1, P.dc2);                 // tile of k1 in pass 2
-      w[(IRA_ABL(P.ablate & 2)) ? (long long)bx * total1 + i : (long long)kt * ((long long)N2 * C2) + (long long)n2 * C2 + (k1 - kt * C2)] =
+      const int kt = PAIRS ? (j >> 1) : (int)fdiv((unsigned)k1, P.dc2);                 // tile of k1 in pass 2
+      const int km = PAIRS ? (j & 1) : k1 - kt * C2;                                     // and its place in the tile
+      w[(IRA_ABL(P.ablate & 2)) ? (long long)bx * total1 + i : (long long)kt * ((long long)N2 * C2) + (long long)n2 * C2 + km] =
           ira::cmul(r[c * LD + ((IRA_ABL(P.ablate & 128)) ? k1 : dif_slot(k1, P.p1))], ira::cmul(th[u], tl[u]));
     }
   }
@@ -584,7 +599,10 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_rows_kernel(SmoothPlan P, S
   // the job's output offsets, once (scalar registers; see SCtx)
   bool paired = false;
   long long out1 = 0, out2 = -1;
-  if (OUT == SM_OUT_SPEC) {
+  if (OUT == SM_OUT_SPEC_PAIRS) {
+    const long long so = J.spec_off[e];
+    out1 = ira::uniform(so);
+  } else if (OUT == SM_OUT_SPEC) {
     const long long x2 = J.x2off ? (long long)J.x2off[e] : -1ll, zo = J.x2off ? (long long)J.zpair_off[e] : 0ll;
     const long long so = J.spec_off[e];
     paired = ira::uniform(x2) >= 0;
@@ -631,11 +649,46 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_rows_kernel(SmoothPlan P, S
   if (!(IRA_ABL(P.ablate & 16))) lds_fft_dif_inplace(a, LD, P.p2, twl, tid, C);
   SM_STAMP(s2);
   const long long n = P.n;
+  if (OUT == SM_OUT_SPEC_PAIRS) {
+    // The tile holds Z = DFT_n(x[2m] + i x[2m+1]) on rows a and b = the mirror of a (tile 0: rows 0 and n1/2, each its own
+    // mirror): Z[k] and Z[n - k] are both here, and the real signal's spectrum of length 2n leaves this kernel directly,
+    //   X[k] = E[k] + W_2n^k O[k],  E = (Z[k] + conj Z[n-k]) / 2,  O = (Z[k] - conj Z[n-k]) / (2i),   k = 0 .. n
+    // (round 3 wrote Z out and read it back twice in a separate pass, smooth_half_split_kernel: 11.5 MB per 10 s channel).
+    // W_2n^k = exp(-i pi k / n) along a thread's elements (k2 advances by 128: k by 128 n1) by rotation from an exactly
+    // reduced start value; a handful of steps.
+    const int p = (int)bx;
+    const int ra = p, rb = p == 0 ? (N1 >> 1) : N1 - p;
+    double cs = 1.0, sn = 0.0;
+    {
+      const int k2 = tid >> 1;
+      const long long k0 = (long long)((tid & 1) ? rb : ra) + (long long)N1 * k2;
+      sincospi(-(double)k0 / (double)n, &sn, &cs);
+    }
+    for (int i = tid; i < N2 * 2; i += SM_THREADS) {
+      const int k2 = i >> 1, c = i & 1;
+      const long long k = (long long)(c ? rb : ra) + (long long)N1 * k2;
+      // the mirror n - k: row 0 pairs k2 with (n2 - k2) mod n2 in the same row; every other row pairs k2 with n2 - 1 - k2 of
+      // its mirror row (row n1/2 is its own mirror row)
+      const bool self0 = p == 0 && c == 0;
+      const int k2m = self0 ? (k2 == 0 ? 0 : N2 - k2) : N2 - 1 - k2;
+      const int cm = p == 0 ? c : 1 - c;
+      const cd zk = r[c * LD + dif_slot(k2, P.p2)], zl = r[cm * LD + dif_slot(k2m, P.p2)];
+      const cd ev = {0.5 * (zk.re + zl.re), 0.5 * (zk.im - zl.im)};
+      const cd od = {0.5 * (zk.im + zl.im), 0.5 * (zl.re - zk.re)};
+      cd x = {ev.re + (cs * od.re - sn * od.im), ev.im + (cs * od.im + sn * od.re)};
+      if (k == 0) x.im = 0.0;                                              // DC of a real signal
+      J.spec_out[out1 + k] = x;
+      if (k == 0) J.spec_out[out1 + n] = cd{zk.re - zk.im, 0.0};           // Nyquist bin k = n: E[0] - O[0]
+      const double nc = cs * P.pstep_c - sn * P.pstep_s;
+      sn = sn * P.pstep_c + cs * P.pstep_s;
+      cs = nc;
+    }
+  } else
   for (int i = tid; i < N2 * C; i += SM_THREADS) {
     const int k2 = (int)fdiv((unsigned)i, P.dc2), c = i - k2 * C;
     const long long k = (long long)(k1_0 + c) + (long long)N1 * k2;        // natural output index
     cd v = r[c * LD + ((IRA_ABL(P.ablate & 128)) ? k2 : dif_slot(k2, P.p2))];
-    if (OUT == SM_OUT_SPEC) {
+    if (OUT == SM_OUT_SPEC || OUT == SM_OUT_SPEC_PAIRS) {
       if (paired) {
         J.zpair[out1 + k] = v;
       } else if (k <= n / 2) {
@@ -790,9 +843,10 @@ bool fill_passes(int N, const int* radices, int count, PassTab* T) {
   return len == 1;
 }
 
-int32_t make_smooth_plan(int32_t n, const void* t1, const void* t2, const void* tf, SmoothPlan* P) {
+int32_t make_smooth_plan(int32_t n, const void* t1, const void* t2, const void* tf, SmoothPlan* P, bool pairs = false) {
   int n1, n2;
   if (!smooth_split(n, &n1, &n2)) return IRA_E_UNSUPPORTED;
+  if (pairs && (n1 % 2 != 0 || n1 < 4)) return IRA_E_UNSUPPORTED;
   P->n = n; P->n1 = n1; P->n2 = n2;
   int r1[SM_MAX_RADICES], r2[SM_MAX_RADICES];
   int nr1 = factor_radices(n1, r1), nr2 = factor_radices(n2, r2);
@@ -821,6 +875,13 @@ int32_t make_smooth_plan(int32_t n, const void* t1, const void* t2, const void* 
   P->c2 = pick_columns(n2, n1);
   { const int v = ira_tune_int("IRA_SMOOTH_C1", 0); if (v >= 1 && n2 % v == 0) P->c1 = v; }
   { const int v = ira_tune_int("IRA_SMOOTH_C2", 0); if (v >= 1 && n1 % v == 0) P->c2 = v; }
+  P->pairs = pairs ? 1 : 0;
+  if (pairs) P->c2 = 2;                                  // a tile = a row and its mirror row
+  {
+    const double step = -3.14159265358979323846 * (double)(SM_THREADS / 2) / (double)n2;
+    P->pstep_c = std::cos(step);
+    P->pstep_s = std::sin(step);
+  }
   P->ld1 = column_stride(n1, P->c1);
   P->ld2 = column_stride(n2, P->c2);
   P->dc1 = fast_div_of((unsigned)P->c1); P->dc2 = fast_div_of((unsigned)P->c2);
@@ -871,24 +932,35 @@ extern "C" int32_t ira_rfft_smooth(const float* x_dev, const int64_t* xoff_dev, 
   IRA_CHECK_PTR(work_dev); IRA_CHECK_PTR(spec_out_dev); IRA_CHECK_PTR(spec_off_dev);
   if (nb <= 0) return nb == 0 ? IRA_OK : IRA_E_SIZE;
   if (nb > 65535) return IRA_E_SIZE;
-  if (interleave && (x2off_dev == nullptr || data_len2_dev != nullptr || win_len2_dev != nullptr)) return IRA_E_NULL;
+  if (interleave && (data_len2_dev != nullptr || win_len2_dev != nullptr)) return IRA_E_NULL;
+  // interleave without zpair scratch: the untangling is fused into pass 2 (mirror-pair tiles; needs an even n1 -- callers
+  // ask ira_fft_smooth_split); with zpair: round 3's separate split pass (any n1)
+  const bool pairs = interleave && zpair_dev == nullptr;
+  if (interleave && !pairs && x2off_dev == nullptr) return IRA_E_NULL;
   SmoothPlan P;
-  const int32_t rc = make_smooth_plan(n, t1_dev, t2_dev, tf_dev, &P);
+  const int32_t rc = make_smooth_plan(n, t1_dev, t2_dev, tf_dev, &P, pairs);
   if (rc != IRA_OK) return rc;
   SJobs J{};
   J.x = x_dev; J.xoff = xoff_dev; J.use_hann = use_hann; J.interleave = interleave ? 1 : 0;
   J.data_len = data_len_dev; J.win_len = win_len_dev; J.data_len2 = data_len2_dev; J.win_len2 = win_len2_dev;
   J.spec_out = reinterpret_cast<cd*>(spec_out_dev); J.spec_off = spec_off_dev;
-  if (x2off_dev != nullptr) {
+  if (x2off_dev != nullptr && !pairs) {
     if (spec_off2_dev == nullptr || zpair_dev == nullptr || zpair_off_dev == nullptr) return IRA_E_NULL;
     J.x2off = x2off_dev; J.spec_off2 = spec_off2_dev;
     J.zpair = reinterpret_cast<cd*>(zpair_dev); J.zpair_off = zpair_off_dev;
   }
   hipStream_t st = (hipStream_t)stream;
   const size_t l1 = ((size_t)P.c1 * P.ld1 + SM_TW) * sizeof(cd), l2 = ((size_t)P.c2 * P.ld2 + SM_TW) * sizeof(cd);
+  cd* work = reinterpret_cast<cd*>(work_dev);
+  if (pairs) {
+    SM_TRY(allow(smooth_cols_kernel<SM_SIGNAL, true>, l1));
+    SM_TRY(allow(smooth_rows_kernel<SM_OUT_SPEC_PAIRS>, l2));
+    smooth_cols_kernel<SM_SIGNAL, true><<<dim3(P.n2 / P.c1, nb), SM_THREADS, l1, st>>>(P, J, work);
+    smooth_rows_kernel<SM_OUT_SPEC_PAIRS><<<dim3(P.n1 / 2, nb), SM_THREADS, l2, st>>>(P, J, work);
+    IRA_RETURN_LAUNCH();
+  }
   SM_TRY(allow(smooth_cols_kernel<SM_SIGNAL>, l1));
   SM_TRY(allow(smooth_rows_kernel<SM_OUT_SPEC>, l2));
-  cd* work = reinterpret_cast<cd*>(work_dev);
   smooth_cols_kernel<SM_SIGNAL><<<dim3(P.n2 / P.c1, nb), SM_THREADS, l1, st>>>(P, J, work);
   smooth_rows_kernel<SM_OUT_SPEC><<<dim3(P.n1 / P.c2, nb), SM_THREADS, l2, st>>>(P, J, work);
   if (interleave)

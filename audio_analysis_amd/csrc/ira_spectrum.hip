@@ -47,7 +47,7 @@ __device__ __forceinline__ double atan2_table(double y, double x, const double* 
 __global__ __launch_bounds__(256) void mag_phase_kernel(const cd* __restrict__ spec, const int64_t* __restrict__ spec_off,
                                  const int32_t* __restrict__ L, double floor_lin, float* __restrict__ mag_db,
                                  const int64_t* __restrict__ mag_off, double* __restrict__ phase,
-                                 const int64_t* __restrict__ phase_off) {
+                                 const int64_t* __restrict__ phase_off, const int32_t* __restrict__ packed) {
   __shared__ ira::LogTabEntry ltab[ira::LOGTAB_N];
   __shared__ double atab[ATAN_TAB + 1];
   ira::build_log_table(ltab, threadIdx.x);
@@ -60,8 +60,33 @@ __global__ __launch_bounds__(256) void mag_phase_kernel(const cd* __restrict__ s
   double* po = phase ? phase + phase_off[e] : nullptr;
   const double floor_p = floor_lin * floor_lin;
   const float floor_db32 = (float)(20.0 * log10(floor_lin));
-  for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nb; k += (long long)gridDim.x * blockDim.x) {
-    const cd v = s[k];
+  // packed element: s holds Z = DFT_l(x[2m] + i x[2m+1]), l = L/2 values (ira_rfft_any, keep_packed), and bin k of the real
+  // signal's spectrum is formed here, where Z[k] and Z[l - k] are two contiguous streams -- the formulas of
+  // half_split_kernel (ira_fftlong.hip) without its pass over memory
+  const bool pk = packed != nullptr && ira::uniform(packed[e]) != 0;
+  const long long l = (long long)L[e] / 2;
+  // W_2l^k = exp(-i pi k / l) along a thread's bins (a grid stride apart) by rotation from an exactly reduced start value: two
+  // sincospi per thread instead of one per bin (16 bins per thread; per bin it cost as much as the dB and the angle together)
+  const long long k_first = (long long)blockIdx.x * blockDim.x + threadIdx.x, k_step = (long long)gridDim.x * blockDim.x;
+  double cs = 1.0, sn = 0.0, rc = 1.0, rs = 0.0;
+  if (pk) {
+    sincospi(-(double)(k_first < nb ? k_first : 0) / (double)l, &sn, &cs);
+    sincospi(-(double)(k_step % (2 * l)) / (double)l, &rs, &rc);
+  }
+  for (long long k = k_first; k < nb; k += k_step) {
+    cd v;
+    if (pk) {
+      const cd zk = s[k == l ? 0 : k], zl = s[(k == 0 || k == l) ? 0 : l - k];
+      const cd ev = {0.5 * (zk.re + zl.re), 0.5 * (zk.im - zl.im)};
+      const cd od = {0.5 * (zk.im + zl.im), 0.5 * (zl.re - zk.re)};
+      v = {ev.re + (cs * od.re - sn * od.im), ev.im + (cs * od.im + sn * od.re)};
+      if (k == 0 || k == l) v.im = 0.0;                            // DC / Nyquist of a real signal
+      const double nc = cs * rc - sn * rs;
+      sn = sn * rc + cs * rs;
+      cs = nc;
+    } else {
+      v = s[k];
+    }
     const double p = v.re * v.re + v.im * v.im;
     float db;
     if (p > 1.0e-280 && p < 1.0e280 && floor_lin > 1.0e-140) {
@@ -513,7 +538,7 @@ __global__ __launch_bounds__(LS_THREADS) void log_smooth_kernel(float* __restric
 extern "C" int32_t ira_spectrum_mag_phase(const double* spec_dev, const int64_t* spec_off_dev, const int32_t* L_dev,
                                           int32_t nb, int32_t max_len, double floor_db, float* mag_db_dev,
                                           const int64_t* mag_off_dev, double* phase_dev,
-                                          const int64_t* phase_off_dev, void* stream) {
+                                          const int64_t* phase_off_dev, const int32_t* packed_dev, void* stream) {
   IRA_CHECK_PTR(spec_dev); IRA_CHECK_PTR(spec_off_dev); IRA_CHECK_PTR(L_dev); IRA_CHECK_PTR(mag_db_dev);
   IRA_CHECK_PTR(mag_off_dev);
   if (phase_dev != nullptr && phase_off_dev == nullptr) return IRA_E_NULL;
@@ -524,7 +549,7 @@ extern "C" int32_t ira_spectrum_mag_phase(const double* spec_dev, const int64_t*
   if (blocks < 1) blocks = 1;
   mag_phase_kernel<<<dim3(blocks, nb), 256, 0, (hipStream_t)stream>>>(
       reinterpret_cast<const cd*>(spec_dev), spec_off_dev, L_dev, floor_lin, mag_db_dev, mag_off_dev, phase_dev,
-      phase_off_dev);
+      phase_off_dev, packed_dev);
   IRA_RETURN_LAUNCH();
 }
 

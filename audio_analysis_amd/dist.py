@@ -41,6 +41,91 @@ def init_process_group(backend: Optional[str] = None):
     return rank, local_rank, world
 
 
+def _parse_cpulist(text: str):
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def _core_order(cpus, sys_root: str = "/sys"):
+    """The CPUs ordered so that the hardware threads of one core are neighbours (a slice then holds whole cores: two ranks
+    never share a physical core through its SMT siblings)."""
+    def first_sibling(c):
+        try:
+            return min(_parse_cpulist(open(os.path.join(sys_root, "devices", "system", "cpu", f"cpu{c}", "topology",
+                                                         "thread_siblings_list")).read()))
+        except (OSError, ValueError):
+            return c
+    return sorted(cpus, key=lambda c: (first_sibling(c), c))
+
+
+def gpu_numa_cpus(sys_root: str = "/sys"):
+    """[(pci address, numa node, [cpus])] for every AMD GPU of the host, in PCI bus order (the order HIP enumerates them in
+    by default), read from sysfs: /sys/class/drm/card*/device/{vendor, numa_node, local_cpulist}.  Empty when the host
+    shows none (containers without /sys/class/drm)."""
+    import glob
+    seen = {}
+    for dev in glob.glob(os.path.join(sys_root, "class", "drm", "card[0-9]*", "device")):
+        try:
+            if open(os.path.join(dev, "vendor")).read().strip().lower() != "0x1002":
+                continue
+            addr = os.path.basename(os.path.realpath(dev))
+            node = int(open(os.path.join(dev, "numa_node")).read().strip())
+            cpus = _parse_cpulist(open(os.path.join(dev, "local_cpulist")).read())
+        except (OSError, ValueError):
+            continue
+        if cpus:
+            seen[addr] = (addr, node, cpus)
+    return [seen[k] for k in sorted(seen)]
+
+
+def rank_cpu_affinity(local_rank: int, local_world: int, allowed=None, gpus=None):
+    """
+    The CPUs rank `local_rank` of `local_world` ranks on this host should run on (one process per
+    GPU; eight ranks on one host share its PCIe root complexes and memory controllers): the cores of ITS GPU's NUMA node
+    (sysfs), cut into disjoint, equal slices among the ranks whose GPUs sit on that node -- so that the pinned host
+    batches a rank allocates are node-local and no two ranks' worker threads compete for a core.  When sysfs shows no
+    GPU topology (or fewer GPUs than ranks) the allowed CPUs are dealt evenly in order.  Returns (cpus, how) with `how` a
+    short description for the bench line; single rank: (allowed, "unrestricted").
+    """
+    if allowed is None:
+        try:
+            allowed = sorted(os.sched_getaffinity(0))
+        except AttributeError:
+            allowed = list(range(os.cpu_count() or 1))
+    allowed = sorted(allowed)
+    if local_world <= 1:
+        return allowed, "unrestricted (one rank)"
+    gpus = gpu_numa_cpus() if gpus is None else gpus
+    if len(gpus) >= local_world:
+        # several ranks may rehearse on fewer GPUs (IRA_DIST_BACKEND=gloo): rank r uses GPU r mod #GPUs there too
+        mine = gpus[local_rank % len(gpus)]
+        peers = [r for r in range(local_world) if gpus[r % len(gpus)][1] == mine[1]]
+        node_cpus = _core_order([c for c in mine[2] if c in set(allowed)])
+        if len(node_cpus) >= len(peers):
+            k, per = peers.index(local_rank), len(node_cpus) // len(peers)
+            return sorted(node_cpus[k * per : (k + 1) * per]), f"numa node {mine[1]} of GPU {mine[0]}, slice {k + 1}/{len(peers)}"
+    per = len(allowed) // local_world
+    if per == 0:
+        return allowed, "unrestricted (fewer CPUs than ranks)"
+    allowed = _core_order(allowed)
+    return sorted(allowed[local_rank * per : (local_rank + 1) * per]), f"even split of {len(allowed)} allowed CPUs (no GPU topology in sysfs)"
+
+
+def apply_rank_cpu_affinity(local_rank: int, local_world: int):
+    """Narrow this process to rank_cpu_affinity(...) -- call BEFORE importing torch / numpy thread pools / allocating pinned
+    memory.  Returns (cpus, how, cpus allowed before)."""
+    before = sorted(os.sched_getaffinity(0))
+    cpus, how = rank_cpu_affinity(local_rank, local_world, before)
+    if local_world > 1 and cpus and len(cpus) < len(before):
+        os.sched_setaffinity(0, cpus)
+    return cpus, how, before
+
+
 def shard_files(num_files: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous block [lo, hi) of file indices for `rank`: ceil(F/W) files per rank, last ranks may be short."""
     per = -(-int(num_files) // int(world)) if world > 0 else int(num_files)

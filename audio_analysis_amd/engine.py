@@ -697,6 +697,15 @@ class Engine:
         self._filter_pools[key] = pool
         return pool
 
+    def forget_filters(self) -> None:
+        """Forget which chirp-filter spectra the pools hold (their buffers stay): the next call of every length rebuilds
+        its filter.  bench.py's `value_new_lengths` calls this before every step -- the rate of a job whose fr / filter
+        segment lengths never repeat (they are data dependent: N - argmax|x|), against the pooled rate of a job that sees
+        the same lengths again."""
+        for pool in self._filter_pools.values():
+            cap = pool["cap"]
+            pool["slot_of"], pool["length_of"], pool["used"] = {}, [None] * cap, [0] * cap
+
     def _filters(self, lengths: np.ndarray, m: int):
         """Chirp-filter spectra for the distinct lengths in `lengths`; returns (bfilt device, bidx int32 host)."""
         t = self.torch
@@ -763,6 +772,10 @@ class Engine:
     # A real signal of EVEN (non-smooth) length L is transformed as the complex sequence x[2m] + i*x[2m+1] of length
     # L/2 (half the Bluestein convolution size) and split with a twiddle.  Set False for an A/B.
     half_real_ffts = True
+    # The untangling X[k] = E[k] + W^k O[k] of such a half-length transform happens where Z[k] and Z[n - k] already meet:
+    # in the second pass of the direct transform (smooth lengths), and in the dB / phase kernel for the Bluestein spectra of
+    # the fr / filter blocks (packed spectra).  False restores round 3's separate split passes (A/B).
+    fuse_half_split = True
 
     @staticmethod
     def _pair_by_key(idx: np.ndarray, keys: np.ndarray):
@@ -778,12 +791,15 @@ class Engine:
         return np.asarray(first, dtype=np.int64), np.asarray(second, dtype=np.int64)
 
     def rfft_any(self, x_dev, xoff: np.ndarray, lengths: np.ndarray, use_hann: bool,
-                 data_len: Optional[np.ndarray] = None, win_len: Optional[np.ndarray] = None):
+                 data_len: Optional[np.ndarray] = None, win_len: Optional[np.ndarray] = None, packed_ok: bool = False):
         """
         Half spectra (complex f64) of x[xoff[e] : xoff[e]+L[e]] (* hanning) for every element.
         data_len / win_len (optional, per element): numpy.fft.rfft(x[:d] * hanning(w)[:d], n=L) -- d samples are read
         (d < L zero-pads, d > L truncates) under the Hann window of length w (reference group_delay.py:95-109).
         Returns (spec float64 device viewed as (total_bins, 2), spec_off int64 host in complex elements).
+        packed_ok: the caller's consumer is spectrum_mag_phase(packed=...) -- even-length elements that ride a half-length
+        Bluestein transform may then stay PACKED: spec_off[e] holds the L/2 values Z = DFT(x[2m] + i x[2m+1]) instead of
+        the L/2 + 1 bins, and the third return value marks them (int32 per element; None when nothing is packed).
         """
         t = self.torch
         n = int(xoff.size)
@@ -823,7 +839,12 @@ class Engine:
                 paired = j2 >= 0
                 safe = np.maximum(j2, 0)
                 a_x2 = a_so2 = a_zo = zpair = None
-                if half_ok:
+                # round 4: with an even n1 the untangling of the half-length transform is part of its second pass
+                # (mirror-pair tiles, ira_rfft_smooth without zpair scratch); fuse_half_split = False is the A/B
+                fused = half_ok and self.fuse_half_split and self.smooth_split(nt)[0] % 2 == 0
+                if fused:
+                    pass
+                elif half_ok:
                     a_x2 = (xoff[j1] + 1).astype(np.int64)
                     a_so2 = spec_off[j1].astype(np.int64)
                     a_zo = (np.arange(j1.size, dtype=np.int64) * nt)
@@ -845,8 +866,9 @@ class Engine:
                                                _ptr(t1), _ptr(t2), _ptr(tf), _ptr(work), _ptr(spec), _ptr(d_so),
                                                _ptr(d_x2), _ptr(d_so2), _ptr(zpair), _ptr(d_zo), _ptr(d_dl), _ptr(d_wl),
                                                _ptr(d_dl2), _ptr(d_wl2), 1 if half_ok else 0, self.stream), "ira_rfft_smooth")
+        packed = np.zeros(n, dtype=np.int32)
         if not rest.any():
-            return spec, spec_off
+            return (spec, spec_off, None) if packed_ok else (spec, spec_off)
         rest_idx = np.nonzero(rest)[0]
         # ---- everything else: Bluestein, grouped by the power-of-two convolution size ------------------------------------
         # Jobs: "half" = one real signal of EVEN length carried as x[2m] + i*x[2m+1] (a complex transform of L/2: half
@@ -876,7 +898,16 @@ class Engine:
             two = paired | jh                                   # jobs that carry a second "signal"
             safe = np.maximum(j2, 0)
             a_x2 = a_so2 = a_zo = zpair = None
-            if two.any():
+            keep_packed = bool(packed_ok and self.fuse_half_split and jh.any() and not paired.any())
+            if keep_packed:
+                # the half-length transforms land in the spectrum array itself (L/2 values in the element's L/2 + 1 slots)
+                # and stay packed: the dB / phase kernel untangles them as it reads them
+                a_x2 = np.where(jh, xoff[j1] + 1, -1).astype(np.int64)
+                a_so2 = np.zeros(j1.size, dtype=np.int64)
+                a_zo = spec_off[j1].astype(np.int64)
+                zpair = spec
+                packed[j1[jh]] = 1
+            elif two.any():
                 a_x2 = np.where(jh, xoff[j1] + 1, np.where(paired, xoff[safe], -1)).astype(np.int64)
                 a_so2 = np.where(paired, spec_off[safe], 0).astype(np.int64)
                 zlen = np.where(two, jl.astype(np.int64), 0)
@@ -896,8 +927,11 @@ class Engine:
             check(self.lib.ira_rfft_any(_ptr(x_dev), _ptr(d_xo), _ptr(d_l), int(sel.size), 1 if use_hann else 0, lm,
                                         _ptr(t1), _ptr(t2), _ptr(tf), _ptr(bf), _ptr(d_bi), _ptr(work), _ptr(spec),
                                         _ptr(d_so), _ptr(d_x2), _ptr(d_so2), _ptr(zpair), _ptr(d_zo), int(jl.max()),
-                                        _ptr(d_dl), _ptr(d_wl), _ptr(d_dl2), _ptr(d_wl2), _ptr(d_il), self.stream),
+                                        _ptr(d_dl), _ptr(d_wl), _ptr(d_dl2), _ptr(d_wl2), _ptr(d_il),
+                                        1 if keep_packed else 0, self.stream),
                   "ira_rfft_any")
+        if packed_ok:
+            return spec, spec_off, (packed if packed.any() else None)
         return spec, spec_off
 
     def band_irfft(self, spec_dev, spec_off: np.ndarray, lengths: np.ndarray, band_params: np.ndarray,
@@ -981,17 +1015,18 @@ class Engine:
                   "ira_band_irfft")
 
     def spectrum_mag_phase(self, spec_dev, spec_off: np.ndarray, lengths: np.ndarray, floor_db: float,
-                           want_phase: bool):
-        """mag_db (f32) [+ wrapped phase f64] laid out at the same per-element bin offsets as the spectra."""
+                           want_phase: bool, packed: Optional[np.ndarray] = None):
+        """mag_db (f32) [+ wrapped phase f64] laid out at the same per-element bin offsets as the spectra.  packed (int32 per
+        element, from rfft_any(packed_ok=True)): elements whose spectrum is still the packed half-length transform."""
         t = self.torch
         n = int(spec_off.size)
         lengths = np.ascontiguousarray(lengths, dtype=np.int32)
         total = int((lengths.astype(np.int64) // 2 + 1).sum())
         mag = self.empty(total, t.float32)
         ph = self.empty(total, t.float64) if want_phase else None
-        d_so, d_l = self.to_dev_pack(spec_off, lengths)
+        d_so, d_l, d_pk = self.to_dev_pack(spec_off, lengths, None if packed is None else np.ascontiguousarray(packed, np.int32))
         check(self.lib.ira_spectrum_mag_phase(_ptr(spec_dev), _ptr(d_so), _ptr(d_l), n, int(lengths.max()),
-                                              float(floor_db), _ptr(mag), _ptr(d_so), _ptr(ph), _ptr(d_so),
+                                              float(floor_db), _ptr(mag), _ptr(d_so), _ptr(ph), _ptr(d_so), _ptr(d_pk),
                                               self.stream), "ira_spectrum_mag_phase")
         return mag, ph
 

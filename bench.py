@@ -61,29 +61,56 @@ def _cpu_init():
 
 
 def _cpu_one(args):
-    index, seconds, blocks, band_mode, stereo = args
+    """One file through the oracle: (seconds of CPU work, per-channel value dicts, the oracle's spectrogram matrices of the
+    probe channels).  The values are what rank 0 compares the GPU's records of the SAME IR indices with (RT60
+    and pole radii as max and as fraction-within-tolerance over the batch): the timing sample doubles as the parity sample."""
+    index, seconds, blocks, band_mode, stereo, pcm16, want_spec = args
+    import numpy as np
     from audio_analysis_amd.synth import synth_ir
     from oracle import ira_oracle as O
     chans = [synth_ir(index, c, int(seconds * 48000)) for c in range(2 if stereo else 1)]
+    if pcm16:       # what a tap file holds (recorder.hpp:49-53) and what the reference's loader makes of it (io.py:58-59)
+        chans = [O.pcm_to_float32((x * np.float32(32767.0)).astype(np.int16)) for x in chans]
     t0 = time.perf_counter()
+    out, specs = [], []
     for x in chans:
+        v = {}
         if "decay" in blocks:
-            O.analyse_decay(x)
+            d = O.analyse_decay(x)
+            v["start"] = d["start"]
+            v["early10"] = d["early_10db"]
+            for name in ("T20", "T30"):
+                f = d["fits"].get(name)
+                v[name.lower() + "_rt60"] = None if f is None else f["rt60"]
         if "rt60bands" in blocks:
-            O.analyse_rt60_bands(x, band_mode=band_mode)
+            b = O.analyse_rt60_bands(x, band_mode=band_mode)
+            v["bands_t30"] = [b["metrics"][bd["name"]]["t30"] for bd in b["bands"]]
         if "fr" in blocks:
-            O.analyse_frequency_response(x)
+            f = O.analyse_frequency_response(x)
+            v["fr_peak_hz"], v["fr_centroid_hz"] = f["peak_hz"], f["centroid_hz"]
         if "filter" in blocks:
-            O.analyse_filter_response(x)
+            f = O.analyse_filter_response(x)
+            v["filter_peak_hz"], v["filter_1k_db"] = f["peak_hz"], f["mag_1k_db"]
         if "spectrogram" in blocks:
-            O.analyse_spectrogram(x)
+            sp = O.analyse_spectrogram(x)
+            v["spec_frames"] = int(sp["magnitude_db"].shape[1])
+            if want_spec:
+                specs.append(sp["magnitude_db"])
         if "waterfall" in blocks:
-            O.analyse_waterfall(x)
+            w = O.analyse_waterfall(x)
+            v["wf_slices"], v["wf_bins"] = int(w["slice_rel_db"].shape[0]), int(w["slice_rel_db"].shape[1])
         if "modalcloud" in blocks:
-            O.analyse_modal_cloud(x)
+            mc = O.analyse_modal_cloud(x)
+            rt = np.array([p[1] for p in mc["points"]], dtype=np.float64)
+            v["modal_points"] = int(rt.size)
+            if rt.size:
+                v["modal_median"], v["modal_p90"], v["modal_max"] = (float(np.median(rt)), float(np.percentile(rt, 90)),
+                                                                     float(np.max(rt)))
         if "zplane" in blocks:
-            O.analyse_zplane(x, ar_order=64)
-    return time.perf_counter() - t0
+            z = O.analyse_zplane(x, ar_order=64)
+            v["ar_max_radius"], v["ar_median_radius"], v["ar_unstable"] = z["max_radius"], z["median_radius"], z["unstable"]
+        out.append(v)
+    return time.perf_counter() - t0, out, specs
 
 
 def _cpu_noop(_):
@@ -100,7 +127,7 @@ def cpu_model():
     return "unknown"
 
 
-def host_cpu_share():
+def host_cpu_share(share_cap=None):
     """CPUs this process may actually use: the affinity mask, cut by the cgroup CPU quota when one is set, and by the
     GPU box's per-GPU CPU share (16; IRA_BENCH_CPU_WORKERS overrides) -- a one-GPU lease of a 8-GPU host shows every
     core of the host in its affinity mask but is entitled to its share of them."""
@@ -115,18 +142,26 @@ def host_cpu_share():
             quota = max(1, int(float(q) / float(per)))
     except Exception:
         pass
-    share = int(os.environ.get("IRA_BENCH_CPU_WORKERS", "16"))
+    share = int(os.environ.get("IRA_BENCH_CPU_WORKERS", str(share_cap or 16)))
     workers = max(1, min(affinity, quota or affinity, share))
     return {"affinity": affinity, "cgroup_quota": quota, "share_cap": share, "workers": workers}
 
 
-def cpu_baseline(seconds: float, blocks, band_mode: str, stereo: bool, per_ir_guess_s: float, unit: str):
+def cpu_baseline(seconds: float, blocks, band_mode: str, stereo: bool, per_ir_guess_s: float, unit: str,
+                 first_index: int = 0, pcm16: bool = False, spec_probe: int = 0, allowed_cpus=None, share_cap=None):
     """One worker process per core this process may run on (the GPU box's CPU share), single-threaded NumPy in each,
-    >= 64 units of work (4 per worker); pool start-up and imports are outside the timed wall."""
+    >= 64 units of work (4 per worker); pool start-up and imports are outside the timed wall.  The files are the FIRST ones
+    the GPU analysed in the timed region (indices first_index ..), so the oracle's values come back with the timing:
+    returns (baseline dict, per-file value dicts, oracle spectrograms of the first `spec_probe` files)."""
     import multiprocessing as mp
     for k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
         os.environ[k] = "1"
-    avail = host_cpu_share()
+    if allowed_cpus is not None:                     # multi-rank runs narrowed rank 0 to its GPU's cores: the other ranks
+        try:                                         # are done by now, the baseline may use the host share again
+            os.sched_setaffinity(0, allowed_cpus)
+        except OSError:
+            pass
+    avail = host_cpu_share(share_cap)
     workers = avail["workers"]
     # bounded sample: >= 64 files, but no more than ~25 s of wall at the guessed per-file cost
     count = max(64, 4 * workers)
@@ -136,18 +171,94 @@ def cpu_baseline(seconds: float, blocks, band_mode: str, stereo: bool, per_ir_gu
     with ctx.Pool(workers, initializer=_cpu_init) as pool:
         pool.map(_cpu_noop, range(4 * workers))                       # every worker has started and imported
         t0 = time.perf_counter()
-        per = pool.map(_cpu_one, [(1000 + i, seconds, tuple(blocks), band_mode, stereo) for i in range(count)],
-                       chunksize=1)
+        res = pool.map(_cpu_one, [(first_index + i, seconds, tuple(blocks), band_mode, stereo, pcm16, i < spec_probe)
+                                  for i in range(count)], chunksize=1)
         wall = time.perf_counter() - t0
-    return {
+    per = [r[0] for r in res]
+    base = {
         "value": count / wall, "unit": unit, "cores": workers, "kind": "port", "cpu_model": cpu_model(),
         "logical_cpus_on_box": os.cpu_count(), "cpus_in_affinity_mask": avail["affinity"],
         "cgroup_cpu_quota": avail["cgroup_quota"], "worker_cap": avail["share_cap"],
-        "sample": f"{count} synthetic {seconds:g} s {'stereo files' if stereo else 'mono IRs'} over {workers} worker "
+        "sample": f"{count} synthetic {seconds:g} s {'stereo files' if stereo else 'mono IRs'} (generator indices "
+                  f"{first_index}..{first_index + count - 1}: the first files of the GPU's timed region) over {workers} worker "
                   f"processes (one per core this process may use; single-threaded NumPy oracle, same blocks as the GPU "
                   f"step: {','.join(blocks)}); mean {sum(per)/len(per):.2f} s per file per core, wall {wall:.1f} s "
                   f"(pool start-up excluded)",
     }
+    return base, [r[1] for r in res], [m for r in res[:spec_probe] for m in r[2]]
+
+
+# ---- parity of the gathered records against the oracle's values for the same IRs -----------------------
+def parity_report(records, oracle_values, nbands: int):
+    """records: (channels, METRICS_WIDTH) rows of the GPU's gathered records, oracle_values: one dict per channel (same
+    order).  Relative quantities: n compared, max relative difference, fraction within 1e-4 (north star: RT60 values and
+    pole radii within 1e-4 relative); integer / index quantities: exact-match counts; None patterns must agree."""
+    import numpy as np
+    from audio_analysis_amd import pipeline as P
+    rel = {"early_10db_s": ("early10", P.M_EARLY10), "t20_rt60_s": ("t20_rt60", P.M_FIT_T20 + 6),
+           "t30_rt60_s": ("t30_rt60", P.M_FIT_T30 + 6), "fr_centroid_hz": ("fr_centroid_hz", P.M_FR_CENTROID),
+           "modal_median_rt60_s": ("modal_median", P.M_MODAL_MEDIAN), "modal_p90_rt60_s": ("modal_p90", P.M_MODAL_P90),
+           "modal_max_rt60_s": ("modal_max", P.M_MODAL_MAX), "ar_max_radius": ("ar_max_radius", P.M_AR_MAX_R),
+           "ar_median_radius": ("ar_median_radius", P.M_AR_MEDIAN_R)}
+    exact = {"start_index": ("start", P.M_START), "fr_peak_hz": ("fr_peak_hz", P.M_FR_PEAK),
+             "filter_peak_hz": ("filter_peak_hz", P.M_FILT_PEAK), "spectrogram_frames": ("spec_frames", P.M_SPEC_FRAMES),
+             "waterfall_slices": ("wf_slices", P.M_WF_SLICES), "waterfall_bins": ("wf_bins", P.M_WF_BINS),
+             "modal_points": ("modal_points", P.M_MODAL_POINTS), "ar_unstable_poles": ("ar_unstable", P.M_AR_UNSTABLE)}
+    out = {}
+
+    def rel_entry(pairs):
+        got = np.array([g for g, _ in pairs], dtype=np.float64)
+        ref = np.array([np.nan if r is None else r for _, r in pairs], dtype=np.float64)
+        none_ok = int(np.sum(np.isnan(got) == np.isnan(ref)))
+        both = ~np.isnan(got) & ~np.isnan(ref)
+        e = {"n": int(both.sum()), "none_pattern_matches": none_ok, "of": int(got.size)}
+        if both.any():
+            d = np.abs(got[both] - ref[both]) / np.maximum(np.abs(ref[both]), 1e-300)
+            e.update(max_rel=float(d.max()), frac_within_1e_4=float(np.mean(d <= 1e-4)), frac_within_1e_6=float(np.mean(d <= 1e-6)))
+        return e
+
+    for name, (key, col) in rel.items():
+        pairs = [(records[i, col], v.get(key)) for i, v in enumerate(oracle_values) if key in v]
+        if pairs:
+            out[name] = rel_entry(pairs)
+    bands = [(records[i, P.M_BANDS + 3 * k], v["bands_t30"][k]) for i, v in enumerate(oracle_values) if "bands_t30" in v
+             for k in range(min(nbands, len(v["bands_t30"])))]
+    if bands:
+        out["band_t30_rt60_s"] = rel_entry(bands)
+    f1k = [(records[i, P.M_FILT_1K], v["filter_1k_db"]) for i, v in enumerate(oracle_values) if "filter_1k_db" in v]
+    if f1k:
+        d = np.abs(np.array([g - r for g, r in f1k], dtype=np.float64))
+        out["filter_1k_db"] = {"n": len(f1k), "max_abs_db": float(d.max()), "frac_within_1e_3_db": float(np.mean(d <= 1e-3))}
+    for name, (key, col) in exact.items():
+        pairs = [(records[i, col], v[key]) for i, v in enumerate(oracle_values) if key in v]
+        if pairs:
+            out[name] = {"n": len(pairs), "exact_matches": int(sum(1 for g, r in pairs if float(g) == float(r)))}
+    status = [records[i, P.M_STATUS] for i in range(len(oracle_values))]
+    out["status_ok"] = {"n": len(status), "exact_matches": int(sum(1 for v in status if v == 0.0))}
+    return out
+
+
+def spectrogram_parity(gpu_mats, oracle_mats, floor_db: float):
+    """float32 STFT dB against the ORACLE's float64 spectrogram of the same channels, on the bins SURVEY.md 8d names
+    (reference value > floor + 20 dB): max |delta dB| and the fractions within 1e-3 / 4e-3 dB."""
+    import numpy as np
+    worst, in1, in4, total = 0.0, 0, 0, 0
+    for g, r in zip(gpu_mats, oracle_mats):
+        if g.shape != r.shape:
+            return {"error": f"shape mismatch {g.shape} vs {r.shape}"}
+        mask = r > (floor_db + 20.0)
+        err = np.abs(g.astype(np.float64) - r.astype(np.float64))[mask]
+        if err.size:
+            worst = max(worst, float(err.max()))
+            in1 += int((err <= 1e-3).sum()); in4 += int((err <= 4e-3).sum()); total += int(err.size)
+    return {"against": "the oracle's spectrogram (NumPy float64 STFT, the reference's algorithm) of the same synthetic IRs, "
+                       "computed by the cpu_baseline workers", "channels": len(oracle_mats), "bins": total,
+            "bins_rule": "reference value > floor_db + 20 dB (SURVEY.md 8d)", "max_abs_err_db": worst,
+            "fraction_within_1e-3_db": (in1 / total) if total else None,
+            "fraction_within_4e-3_db": (in4 / total) if total else None,
+            "tolerance_met": "max <= 4e-3 dB and >= 99.9 % within 1e-3 dB (tests/test_gpu_decay_stft.py); SURVEY.md 8d asks "
+                             "1e-3 dB on every such bin: met on all but the weakest bins of a frame (a float32 transform's "
+                             "error is ~2e-7 of the frame's rms)"}
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -210,6 +321,13 @@ def make_roof(ev, roof_steps, settings, L, n, nchan, traffic_tab):
         nb = len(_build_band_definitions(settings.rt60_bands, settings.sample_rate_hz))
     nfits_decay = 1 if settings.run_decay else 0
 
+    # group delay (section 8f): the zero-padded transform length of every channel
+    gd_bins, gd_nfft = 0.0, None
+    if getattr(settings, "run_group_delay", False):
+        from audio_analysis_amd.analyse.group_delay import fft_size_for
+        gd_nfft = np.array([fft_size_for(int(v), settings.group_delay) for v in L], dtype=np.float64)
+        gd_bins = float(np.sum(gd_nfft // 2 + 1))
+
     def stft_bytes(nfft, hop):
         frames = 1 + (L - nfft) // hop
         return float(np.sum(4.0 * L + 4.0 * (nfft // 2 + 1) * frames))
@@ -242,6 +360,9 @@ def make_roof(ev, roof_steps, settings, L, n, nchan, traffic_tab):
         elif name.startswith("ira_rfft_any"):
             b = float(np.sum(4.0 * L + 16.0 * (L // 2 + 1)))
             what = "per channel: 4L + 16(L/2+1) bytes (fr/filter spectrum of arbitrary length)"
+        elif name.startswith("ira_rfft_smooth") and "[gd]" in name:
+            b = float(np.sum(4.0 * np.minimum(L, gd_nfft))) + 16.0 * gd_bins
+            what = "per channel: 4 min(L, n_fft) sample bytes + 16(n_fft/2+1) (zero-padded group-delay transform, n_fft = 2^19)"
         elif name.startswith("ira_rfft_smooth"):
             b = float(nchan) * (4.0 * n + 16.0 * (n // 2 + 1))
             what = "per channel: 4n + 16(n/2+1) bytes (RT60 full-file forward transform, direct mixed radix, half-length complex)"
@@ -260,6 +381,28 @@ def make_roof(ev, roof_steps, settings, L, n, nchan, traffic_tab):
         elif name.startswith("ira_peak_index"):
             b = float(nchan) * 4.0 * n
             what = "4N bytes per channel"
+        elif name.startswith("ira_edc_fits"):
+            # the decay segment is the trimmed channel (L samples), a band segment the band signal from the start index on
+            b = float(np.sum(4.0 * L)) * (nfits_decay + nb)
+            what = (f"4L bytes per segment (samples read once; the EDC is never written): {nfits_decay} decay + {nb} band "
+                    f"segments per channel")
+        elif name.startswith("ira_spectrum_mag_phase"):
+            bins = gd_bins if "[gd]" in name else np.sum(L // 2 + 1)
+            b = float(bins) * (16.0 + 4.0 + 8.0)
+            what = "per bin: 16 B spectrum in + 4 B dB + 8 B phase out"
+        elif name.startswith("ira_phase_unwrap"):
+            bins = gd_bins if "[gd]" in name else np.sum(L // 2 + 1)
+            b = float(bins) * (8.0 + (8.0 if "[gd]" in name else 4.0))
+            what = "per bin: 8 B wrapped phase in + unwrapped phase out (float32 degrees; float64 radians for the group delay)"
+        elif name.startswith("ira_spectrum_stats"):
+            b = float(np.sum(L // 2 + 1)) * 4.0
+            what = "4 B dB per bin read once"
+        elif name.startswith("ira_group_delay"):
+            b = float(gd_bins) * 16.0
+            what = "per bin: 8 B unwrapped phase in + 8 B group delay out"
+        elif name.startswith("ira_diffusion"):
+            b = float(nchan) * 4.0 * n
+            what = "4N bytes per channel (every window's samples read once; windows overlap through LDS)"
         if b is None:
             return {"kernel": name, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": None, "traffic": None, "avg_launch_ms": step_ms / launches, "ms_per_step": step_ms,
@@ -280,10 +423,15 @@ def make_roof(ev, roof_steps, settings, L, n, nchan, traffic_tab):
             stream_b = full * (16.0 * (n // 2 + 1) + 16.0 * n + 16.0 * n + 2 * 4.0 * n) + \
                        half * (16.0 * (n // 2 + 1) + 16.0 * h + 16.0 * h + 4.0 * n)
             flops = full * 5.0 * n * np.log2(n) + half * 5.0 * h * np.log2(h)
+        elif name.startswith("ira_rfft_smooth") and "[gd]" in name:
+            h = gd_nfft / 2.0
+            stream_b = float(np.sum(4.0 * np.minimum(L, gd_nfft) + 16.0 * h * 3 + 16.0 * (h + 1)))
+            flops = float(np.sum(5.0 * h * np.log2(h)))
         elif name.startswith("ira_rfft_smooth"):
-            # one real signal of even length = ONE half-length complex transform (x[2m] + i x[2m+1]) + the untangling pass
+            # one real signal of even length = ONE half-length complex transform (x[2m] + i x[2m+1]); the untangling is
+            # part of the second pass since round 4 (no separate split pass)
             h = n // 2
-            stream_b = nchan * (4.0 * n + 16.0 * h + 16.0 * h + 16.0 * h + 16.0 * h + 16.0 * (h + 1))
+            stream_b = nchan * (4.0 * n + 16.0 * h + 16.0 * h + 16.0 * (h + 1))
             flops = nchan * 5.0 * h * np.log2(h)
         elif name.startswith("ira_rfft_any"):
             # Bluestein: an even length rides a half-length transform (2 l - 1 lags), an odd one a full-length transform of a
@@ -303,6 +451,16 @@ def make_roof(ev, roof_steps, settings, L, n, nchan, traffic_tab):
                                   "f64_vector_peak_TFLOPs": F64_VECTOR_PEAK_TFLOPS,
                                   "frac_of_f64_vector_peak": flops / (step_ms * 1e-3) / 1e12 / F64_VECTOR_PEAK_TFLOPS,
                                   "model": "2.5 n_fft log2(n_fft) flop per frame (SURVEY.md 8d); the kernel computes in float64"}
+        if name.startswith("ira_diffusion"):
+            from audio_analysis_amd.analyse.diffusion import window_geometry, _frame_count, trim_start
+            win, hop, max_lag = window_geometry(settings.sample_rate_hz, settings.diffusion)
+            frames = np.array([_frame_count(int(v), win, hop) for v in L], dtype=np.float64)
+            mac = float(np.sum(frames)) * win * max_lag
+            out["flops_model"] = {"flop": 2.0 * mac, "achieved_TFLOPs": 2.0 * mac / (step_ms * 1e-3) / 1e12,
+                                  "f64_vector_peak_TFLOPs": F64_VECTOR_PEAK_TFLOPS,
+                                  "frac_of_f64_vector_peak": 2.0 * mac / (step_ms * 1e-3) / 1e12 / F64_VECTOR_PEAK_TFLOPS,
+                                  "model": f"windows x {win} samples x {max_lag} lags multiply-adds in float64 (the reference's "
+                                           f"windowed autocorrelation over all lags, diffusion.py:139-226)"}
         if stream_b is not None:
             out["streaming_model"] = {"bytes": stream_b, "achieved_GBps": stream_b / (step_ms * 1e-3) / 1e9,
                                       "frac_of_hbm_peak": stream_b / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -337,7 +495,8 @@ SINGLE_KERNEL_CALLS = {"ira_stft_logbin": "stft5_kernel", "ira_stft_mag_db_tf": 
 
 def dominant_kernel_of_profile(cfg: str):
     """The kernel with the largest total duration in the committed rocprofv3 --kernel-trace --stats summary of this
-    configuration (profiles/rNN_kernel_stats_cfg<cfg>.csv): (short name, share of device time) or None."""
+    configuration (profiles/rNN_kernel_stats_cfg<cfg>.csv): (short name, share of device time, file, template arguments,
+    average duration in ms, calls) or None."""
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "profiles", f"r0[3-9]*_kernel_stats_cfg{cfg}.csv")))
@@ -350,11 +509,20 @@ def dominant_kernel_of_profile(cfg: str):
         t = float(r["TotalDurationNs"])
         total += t
         if best is None or t > best[1]:
-            best = (r["Name"], t)
+            best = (r["Name"], t, float(r["AverageNs"]) / 1e6, int(r["Calls"]))
     if best is None or total <= 0:
         return None
-    name = best[0].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0]
-    return name, best[1] / total, os.path.basename(files[-1])
+    full = best[0].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+    name = full.split("<")[0]
+    targs = full[len(name):]
+    return name, best[1] / total, os.path.basename(files[-1]), targs, best[2], best[3]
+
+
+# kernels of multi-launch ABI calls: (the call they belong to, bytes one launch streams as a function of the job geometry)
+MULTI_KERNEL_CALLS = {"smooth_cols_kernel<1": "ira_band_irfft_smooth", "smooth_rows_kernel<1": "ira_band_irfft_smooth",
+                      "smooth_cols_kernel<0": "ira_rfft_smooth", "smooth_rows_kernel<0": "ira_rfft_smooth",
+                      "cols_fwd_kernel<0": "ira_rfft_any", "rows_kernel<1": "ira_rfft_any", "cols_inv_kernel<0": "ira_rfft_any",
+                      "edc_moments_kernel": "ira_edc_fits", "edc_fit_kernel": "ira_edc_fits", "edc_sums_kernel": "ira_edc_fits"}
 
 
 def stft_error_distribution(eng, batch, settings, channels: int = 4):
@@ -375,10 +543,12 @@ def stft_error_distribution(eng, batch, settings, channels: int = 4):
     r, r_off, _ = eng.stft_mag_db(batch.x, off, nframes, sp.n_fft, sp.hop_length, sp.use_hann_window, sp.floor_db, 64)
     eng.sync()
     worst, inside, total = 0.0, 0, 0
+    host = []                                                 # the float32 (F, T) matrices, for the comparison with the oracle's
     for i in range(k):
         T = int(cols[i])
         ai = a[int(a_off[i]) : int(a_off[i]) + f * T]
         ai = ai.view(T, f).t() if eng.stft_frame_major_ok(sp.n_fft, 32) else ai.view(f, T)
+        host.append(ai.cpu().numpy().copy())
         ri = r[int(r_off[i]) : int(r_off[i]) + f * T].view(f, T)
         mask = ri > (sp.floor_db + 20.0)
         err = (ai.double() - ri.double()).abs()[mask]
@@ -386,24 +556,50 @@ def stft_error_distribution(eng, batch, settings, channels: int = 4):
             worst = max(worst, float(err.max().item()))
             inside += int((err <= 1e-3).sum().item())
             total += int(err.numel())
-    return {"against": "float64 STFT of the same samples on the device (pinned to the oracle at <= 2e-5 dB by the parity suite)",
-            "bins": total, "bins_rule": "reference value > floor_db + 20 dB (SURVEY.md 8d)", "channels": k,
-            "max_abs_err_db": worst, "fraction_within_1e-3_db": (inside / total) if total else None}
+    return ({"against": "float64 STFT of the same samples on the device (pinned to the oracle at <= 2e-5 dB by the parity suite)",
+             "bins": total, "bins_rule": "reference value > floor_db + 20 dB (SURVEY.md 8d)", "channels": k,
+             "max_abs_err_db": worst, "fraction_within_1e-3_db": (inside / total) if total else None}, host)
 
 
-def roofline_kernel(cfg, tot, roof):
-    """`roofline` is per ABI CALL (a call may be several kernels: ira_rfft_any is four).  This entry is per KERNEL: the
-    kernel rocprofv3 ranks first in the committed profile of this configuration, timed live when its call is a single
-    launch (then the call's HIP-event time is the kernel's own duration)."""
+def roofline_kernel(cfg, tot, roof, geom=None):
+    """`roofline` is per ABI CALL (a call may be several kernels: ira_rfft_any is three).  This entry is per KERNEL: the
+    kernel rocprofv3 ranks first in the committed profile of this configuration.  When its call is a single launch the
+    kernel is timed live (the call's HIP-event time is the kernel's own duration).  When the call is several launches no
+    live per-kernel time exists: the entry then carries the kernel's AVERAGE DURATION FROM THE COMMITTED PROFILE with the
+    bytes one launch of it streams (geom: channels, n, bands), and the live roofline of its call beside it."""
     dom = dominant_kernel_of_profile(cfg)
     if dom is None:
         return None
-    kname, share, src = dom
+    kname, share, src, targs, avg_ms, calls = dom
     call = next((c for c, k in SINGLE_KERNEL_CALLS.items() if k == kname), None)
     live = next((n for n in tot if call and n.startswith(call)), None)
-    out = {"kernel": kname, "share_of_device_time_in_profile": share, "profile": f"profiles/{src}"}
+    out = {"kernel": kname + targs, "share_of_device_time_in_profile": share, "profile": f"profiles/{src}"}
     if live is None:
-        out["note"] = "not a single-launch call: no live per-kernel duration (see the per-kernel CSV of the profile)"
+        mcall = next((c for k, c in MULTI_KERNEL_CALLS.items() if (kname + targs).startswith(k)), None)
+        mlive = next((n for n in tot if mcall and n.startswith(mcall)), None)
+        out.update(duration_source=f"average of {calls} launches in profiles/{src} (rocprofv3 --kernel-trace --stats): its call "
+                                   f"{mcall} is several launches, so HIP events around the call do not time one kernel",
+                   avg_launch_ms=avg_ms, call=mcall)
+        if geom is not None and mcall is not None:
+            nchan, n, nb = geom["channels"], geom["n"], geom["bands"]
+            b, what = None, None
+            if (kname + targs).startswith("smooth_cols_kernel<1"):
+                jobs = nchan * (nb // 2)
+                b, what = jobs * (16.0 * (n // 2 + 1) + 16.0 * n), (f"{jobs} two-band jobs: 16(n/2+1) B of spectrum in + 16n B of "
+                                                                    f"column-transformed work array out")
+            elif (kname + targs).startswith("smooth_rows_kernel<1"):
+                jobs = nchan * (nb // 2)
+                b, what = jobs * (16.0 * n + 8.0 * n), f"{jobs} two-band jobs: 16n B of work array in + two float32 band signals out"
+            elif kname == "edc_moments_kernel" or kname == "edc_sums_kernel":
+                segs = nchan * (nb + (1 if geom.get("decay") else 0))
+                b, what = segs * 4.0 * float(geom["mean_len"]), f"{segs} segments: 4L B of samples read once"
+            if b is not None:
+                ach = b / (avg_ms * 1e-3) / 1e9
+                out.update(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                           algorithmic_bytes=b, algorithmic=what + " (streaming model of this pass; the call's compulsory "
+                                                                  "bytes are in call_roofline)")
+        if mlive is not None:
+            out["call_roofline"] = roof(mlive)
         return out
     r = roof(live)
     r["call"] = r.pop("kernel")
@@ -511,19 +707,36 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a.gpus))
     if a.spawn_probe:
-        import numpy as np
         from audio_analysis_amd import dist as D
+        _, lr0, _ = D.env_world()
+        my_cpus, how, before = D.apply_rank_cpu_affinity(lr0, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+        import numpy as np
         rank, local_rank, world = D.init_process_group("gloo")
         got = D.gather_metrics(np.full((3, 4), float(rank)), equal_rows=True)
+        row = np.full((1, 64), -1.0)
+        now = sorted(os.sched_getaffinity(0))                        # what the kernel says, not what we asked for
+        row[0, : min(64, len(now))] = now[:64]
+        cpus = D.gather_metrics(row, equal_rows=True)
         D.barrier()
         if rank == 0:
-            print(json.dumps({"n_gpus": world, "ranks": sorted(set(got[:, 0].tolist())), "rows": int(got.shape[0])}))
+            sets = [sorted(int(c) for c in r if c >= 0) for r in cpus]
+            print(json.dumps({"n_gpus": world, "ranks": sorted(set(got[:, 0].tolist())), "rows": int(got.shape[0]),
+                              "affinity": sets, "how": how, "cpus_before": len(before),
+                              "disjoint": all(set(sets[i]).isdisjoint(sets[j]) for i in range(len(sets)) for j in range(i))}))
         return
+
+    # ---- one rank = one GPU = the cores of that GPU's NUMA node: BEFORE torch is imported and before any pinned host batch
+    # is allocated (first touch puts its pages on the node of the allocating thread), for ranks started by spawn_ranks and
+    # by torch.distributed.run alike
+    from audio_analysis_amd import dist as D
+    _, lr0, _ = D.env_world()
+    lw0 = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    my_cpus, affinity_how, cpus_before = D.apply_rank_cpu_affinity(lr0, lw0)
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(16, len(my_cpus)))))
 
     import numpy as np
     import torch
 
-    from audio_analysis_amd import dist as D
     from audio_analysis_amd.engine import Engine
     from audio_analysis_amd.feed import DeviceFeed, HostBatch, run_pipelined
     from audio_analysis_amd.pipeline import METRICS_WIDTH, FullReport
@@ -548,8 +761,25 @@ def main():
     report = FullReport(eng, settings)
     blocks = block_names(settings)
 
+    # every rank's CPU set travels to rank 0 with one small gather (first cpu, last cpu, count, 64-bit masks of cpus 0..255)
+    aff_row = np.zeros((1, 8), dtype=np.float64)
+    aff_row[0, :4] = [rank, my_cpus[0] if my_cpus else -1, my_cpus[-1] if my_cpus else -1, len(my_cpus)]
+    for c in my_cpus:
+        if c < 208:
+            aff_row[0, 4 + c // 52] += float(1 << (c % 52))           # 52-bit pieces: exact in a float64
+    aff_all = D.gather_metrics(aff_row, eng.device, equal_rows=True)
+    affinity = None
+    if rank == 0:
+        ranks = []
+        for r in aff_all:
+            cpus = [52 * j + b for j in range(4) for b in range(52) if (int(r[4 + j]) >> b) & 1]
+            ranks.append({"rank": int(r[0]), "cpus": int(r[3]), "first": int(r[1]), "last": int(r[2]), "_set": cpus})
+        sets = [set(x.pop("_set")) for x in ranks]
+        affinity = {"how_rank0": affinity_how, "cpus_allowed_before": len(cpus_before), "ranks": ranks,
+                    "disjoint": all(sets[i].isdisjoint(sets[j]) for i in range(len(sets)) for j in range(i))
+                                if world > 1 else True}
     if a.config == "5":
-        return bench_bundle(a, cfg, eng, rank, world, B, n, steps, blocks)
+        return bench_bundle(a, cfg, eng, rank, world, B, n, steps, blocks, affinity, cpus_before)
 
     # ---- K distinct synthetic batches per rank in pinned host memory (float32 and the PCM16 the recorder would store) -----
     K = max(1, a.host_batches)
@@ -643,7 +873,22 @@ def main():
         run_resident(2)
         el_res = timed(run_resident, steps)
 
-    note("variants done" + ("" if el_res is None else f": int16 {B * world * steps / el_i16:.0f}, resident {B * world * steps / el_res:.0f} IRs/s"))
+    # ---- cold plan data: the same steps with the chirp-filter pools forgotten before every step, i.e. every fr / filter
+    # segment length is NEW to the engine (they are data dependent: N - argmax|x|; a bundle of real taps sees new lengths
+    # all the time) and ira_bluestein_filter runs inside the timed region
+    el_cold = ev_cold = None
+    if a.variants == "all":
+        def cold_batches(count):
+            for i in range(count):
+                eng.forget_filters()
+                yield host_f32[i % K]
+        run_pipelined(report, feed, cold_batches(2), gather)
+        eng.events = []
+        el_cold = timed(lambda c: run_pipelined(report, feed, cold_batches(c), gather), steps)
+        ev_cold = eng.collect_events()
+        eng.events = None
+    note("variants done" + ("" if el_res is None else f": int16 {B * world * steps / el_i16:.0f}, resident {B * world * steps / el_res:.0f}, "
+                                                      f"new lengths every step {B * world * steps / el_cold:.0f} IRs/s"))
     # ---- per-kernel durations: a short SERIALISED pass (one stream, kernels one at a time) in the same run ---------------
     lanes_used = eng.num_lanes
     eng.num_lanes = 1
@@ -653,6 +898,12 @@ def main():
     run_fed(a.roofline_steps, host_f32)
     D.barrier(); torch.cuda.synchronize()
     ev = eng.collect_events()
+    ev_cold_serial = None
+    if a.variants == "all":
+        eng.events = []
+        run_pipelined(report, feed, cold_batches(a.roofline_steps), gather)
+        D.barrier(); torch.cuda.synchronize()
+        ev_cold_serial = eng.collect_events()
     eng.events = None
     eng.num_lanes = lanes_used
     roof_steps = a.roofline_steps
@@ -668,13 +919,25 @@ def main():
                    "ms_per_step": 1e3 * el2 / a.literal_steps, "blocks": rep2.s.blocks(),
                    "note": "same step (H2D included) plus the reference's default-on group-delay and diffusion blocks "
                            "(SURVEY.md 8f); only the IR waveform plots and PNG rendering remain excluded"}
+        # per-call device times of the literal step: the same serialised (one stream) pass as the headline's
+        eng.num_lanes = 1
+        run_fed(K, host_f32, rep2)
+        D.barrier(); torch.cuda.synchronize()
+        eng.events = []
+        run_fed(a.roofline_steps, host_f32, rep2)
+        D.barrier(); torch.cuda.synchronize()
+        ev_lit = eng.collect_events()
+        eng.events = None
+        eng.num_lanes = lanes_used
+        literal["_events"] = ev_lit
+        literal["_settings"] = rep2.s
 
     flush()
-    stft_err = None
+    stft_err, stft_probe = None, []
     if settings.run_spectrogram and a.variants == "all":      # (profiling runs skip the probe: its extra peak pick and STFT
         probe = feed.push(host_f32[0])                        # launches would be counted as a step by the traffic tools)
         eng.peaks_begin(probe); eng.peaks(probe)
-        stft_err = stft_error_distribution(eng, probe, settings)
+        stft_err, stft_probe = stft_error_distribution(eng, probe, settings)
 
     if rank != 0:
         return
@@ -734,7 +997,8 @@ def main():
                      "value_pull_kernel": "float32 upload by the pull kernel (ira_host_pull) instead of hipMemcpyAsync (A/B)"},
         "h2d_GBps": B * n * 4.0 * steps / elapsed / 1e9,
         "roofline": roof(dominant),
-        "roofline_kernel": roofline_kernel(a.config, tot, roof),
+        "roofline_kernel": roofline_kernel(a.config, tot, roof, dict(channels=B, n=n, bands=nb_bands(settings),
+                                                                    decay=settings.run_decay, mean_len=float(np.mean(L)))),
         "roofline_stft": rs,
         "roofline_measured": f"serialised pass of {roof_steps} steps in this run (one stream, kernels one at a time, H2D "
                              f"included); the timed region deals the report blocks onto {lanes_used} streams",
@@ -745,14 +1009,61 @@ def main():
                                              sorted(ev_timed.items(), key=lambda kv: -sum(kv[1]))},
         "literal_full_report": literal,
     }
+    out["affinity"] = affinity
+    if el_cold is not None:
+        out["value_new_lengths"] = total_irs / el_cold
+        out["variants"]["value_new_lengths"] = ("the same steps with the chirp-filter pools forgotten before every step: every "
+                                                "fr / filter segment length is new to the engine and ira_bluestein_filter runs "
+                                                "inside the timed region (a job whose lengths never repeat)")
+        tot_c = {k: sum(v) / roof_steps for k, v in ev_cold_serial.items()}
+        out["new_lengths"] = {"ms_per_step": 1e3 * el_cold / steps,
+                              "device_ms_per_step_by_call": dict(sorted(tot_c.items(), key=lambda kv: -kv[1])),
+                              "device_ms_per_step": sum(tot_c.values()),
+                              "ira_bluestein_filter_ms_per_step": tot_c.get("ira_bluestein_filter"),
+                              "timed_region_ira_bluestein_filter_ms_per_step":
+                                  sum(ev_cold.get("ira_bluestein_filter", [])) / steps}
+    if literal is not None:
+        ev_lit, set_lit = literal.pop("_events"), literal.pop("_settings")
+        tot_l, roof_l = make_roof(ev_lit, roof_steps, set_lit, L, n, B, traffic_tab)
+        literal["device_ms_per_step_by_call"] = {k: v / roof_steps for k, v in sorted(tot_l.items(), key=lambda kv: -kv[1])}
+        literal["device_ms_per_step"] = sum(tot_l.values()) / roof_steps
+        literal["added_blocks_device_ms"] = {
+            "groupdelay": sum(v for k, v in tot_l.items() if "[gd]" in k or k.startswith("ira_group_delay")
+                              or k.startswith("ira_order_stats")) / roof_steps,
+            "diffusion": sum(v for k, v in tot_l.items() if k.startswith("ira_diffusion")) / roof_steps}
+        literal["rooflines"] = [roof_l(k) for k in tot_l if "[gd]" in k or k.startswith("ira_group_delay")
+                                or k.startswith("ira_diffusion")]
     note("device side done; cpu baseline next")
-    if world == 1 and not a.no_cpu_baseline:
+    if not a.no_cpu_baseline:
         bm = settings.rt60_bands.band_mode
-        out["cpu_baseline"] = cpu_baseline(seconds, blocks, bm, False, cfg["cpu_s"], "IRs/s")
+        row0 = first + ((0 if a.gather == "final" else steps - 1) % K) * B          # generator index of gathered row 0
+        base, oracle_values, oracle_specs = cpu_baseline(seconds, blocks, bm, False, cfg["cpu_s"], "IRs/s", first_index=row0,
+                                                         spec_probe=len(stft_probe) if row0 == first else 0, allowed_cpus=cpus_before if world > 1 else None,
+                                                         share_cap=16 * world)
+        if world > 1:
+            base["sample"] += f"; run on rank 0 after the device side of all {world} ranks, over the host share of {world} GPUs"
+        out["cpu_baseline"] = base
+        # the timed region's step s analysed host batch s % K = generator indices first + (s % K) B ...: rank 0's rows of
+        # step 0 are the files the workers just analysed
+        vals = [v[0] for v in oracle_values][:B]
+        out["parity"] = parity_report(gathered[: len(vals)], vals, nb_bands(settings))
+        out["parity"]["sample"] = (f"the GPU's gathered records of generator indices {row0}..{row0 + len(vals) - 1} (rank 0, "
+                                   f"{'first' if a.gather == 'final' else 'last'} step of the timed region) against the oracle values the cpu_baseline workers returned "
+                                   f"for the same indices")
+        if oracle_specs and rs is not None:
+            rs["f32_error_vs_device_f64"] = rs.get("f32_error")
+            rs["f32_error"] = spectrogram_parity(stft_probe[: len(oracle_specs)], oracle_specs, settings.spectrogram.floor_db)
     print(json.dumps(out))
 
 
-def bench_bundle(a, cfg, eng, rank, world, B, n, steps, blocks):
+def nb_bands(settings) -> int:
+    if not settings.run_rt60_bands:
+        return 0
+    from audio_analysis_amd.analyse.rt60bands import _build_band_definitions
+    return len(_build_band_definitions(settings.rt60_bands, settings.sample_rate_hz))
+
+
+def bench_bundle(a, cfg, eng, rank, world, B, n, steps, blocks, affinity=None, cpus_before=None):
     """BASELINE config 5: stereo PCM16 tap files -> bundle.run_bundle_metrics.  A step = one group of B tap files."""
     import shutil
     import tempfile
@@ -819,14 +1130,25 @@ def bench_bundle(a, cfg, eng, rank, world, B, n, steps, blocks):
                                    "D2H + gather"},
         "channels_per_s": 2 * files / elapsed,
         "roofline": roof(dominant),
+        "roofline_kernel": roofline_kernel("5", tot, roof, dict(channels=2 * B, n=n, bands=nb_bands(settings),
+                                                                decay=settings.run_decay, mean_len=float(np.mean(L)))),
         "roofline_measured": f"serialised pass ({roof_steps} steps, one stream) in this run",
+        "affinity": affinity,
         "lanes": lanes_used,
         "device_ms_per_step_by_call": {k: v / roof_steps for k, v in sorted(tot.items(), key=lambda kv: -kv[1])},
         "device_ms_per_step": sum(tot.values()) / roof_steps,
     }
-    if world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(n / 48000, blocks, settings.rt60_bands.band_mode, True, cfg["cpu_s"],
-                                           "stereo taps/s")
+    if not a.no_cpu_baseline:
+        base, oracle_values, _ = cpu_baseline(n / 48000, blocks, settings.rt60_bands.band_mode, True, cfg["cpu_s"],
+                                              "stereo taps/s", first_index=200000, pcm16=True,
+                                              allowed_cpus=cpus_before if world > 1 else None, share_cap=16 * world)
+        out["cpu_baseline"] = base
+        # tap i of rank 0's timed bundle is generator index 200000 + i (the first `distinct` taps are distinct files), its two
+        # channels are rows 2i and 2i + 1 of the gathered records
+        vals = [v for per_file in oracle_values[: min(len(oracle_values), distinct)] for v in per_file]
+        out["parity"] = parity_report(gathered[: len(vals)], vals, nb_bands(settings))
+        out["parity"]["sample"] = (f"both channels of the first {len(vals) // 2} taps of rank 0's timed bundle (generator indices "
+                                   f"200000.., PCM16 as the recorder stores it) against the oracle on the same PCM16 samples")
     print(json.dumps(out))
 
 

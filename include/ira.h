@@ -33,7 +33,7 @@ extern "C" {
 #define IRA_E_FORMAT (-5)     /* a file is not RIFF/WAVE (host-side ingest entry points only) */
 #define IRA_E_HIP_BASE (-1000)
 
-#define IRA_ABI_VERSION 5   /* bumped whenever an exported signature or a scratch-size constant changes */
+#define IRA_ABI_VERSION 6   /* bumped whenever an exported signature or a scratch-size constant changes */
 
 int32_t ira_abi_version(void);
 const char* ira_error_string(int32_t code);
@@ -188,7 +188,11 @@ int32_t ira_bluestein_filter(const int32_t* L_dev, int32_t nfilt, int32_t m, con
  * interleave_dev (may be NULL): interleave[e] = 1 makes element e ONE real signal of even length 2*L[e] carried as the
  * complex sequence x[2m] + i*x[2m+1] (x2off_dev[e] must be xoff_dev[e] + 1, zpair scratch L[e] complex): half the
  * transform size; its L[e]+1 spectrum bins go to spec_off_dev[e].  Window lengths then refer to the real signal
- * (win_len = 2*L[e]). */
+ * (win_len = 2*L[e]).
+ * keep_packed != 0 (round 4): the L[e]-point transforms Z of interleaved elements are NOT untangled -- they stay where
+ * the last pass wrote them, zpair_dev + 2*zpair_off_dev[e] (the caller may point that into spec_out_dev: L[e] values fit
+ * the element's L[e]+1 bins), and the consumer forms X[k] = E[k] + W^k O[k] as it reads them
+ * (ira_spectrum_mag_phase, packed_dev): one read-modify-write pass over every such spectrum less. */
 int32_t ira_rfft_any(const float* x_dev, const int64_t* xoff_dev, const int32_t* L_dev, int32_t nb,
                      int32_t use_hann, int32_t m, const void* t1_dev, const void* t2_dev,
                      const void* tf_dev, const double* bfilt_dev, const int32_t* bidx_dev,
@@ -196,7 +200,7 @@ int32_t ira_rfft_any(const float* x_dev, const int64_t* xoff_dev, const int32_t*
                      const int64_t* x2off_dev, const int64_t* spec_off2_dev, double* zpair_dev,
                      const int64_t* zpair_off_dev, int32_t max_len, const int32_t* data_len_dev,
                      const int32_t* win_len_dev, const int32_t* data_len2_dev, const int32_t* win_len2_dev,
-                     const int32_t* interleave_dev, void* stream);
+                     const int32_t* interleave_dev, int32_t keep_packed, void* stream);
 
 /* Band filter bank: element e takes the half spectrum at spec_dev + 2*spec_off_dev[e] (length L[e]/2+1),
  * multiplies it by TWO real masks (band_params_dev: 2 records of IRA_BAND_DOUBLES doubles per element:
@@ -217,11 +221,14 @@ int32_t ira_band_irfft(const double* spec_dev, const int64_t* spec_off_dev, cons
 
 /* ---- a17/a18: spectrum post-processing -------------------------------------------------------------------
  * mag_db[e][k] = float32(20 log10(max(|X|, 10^(floor_db/20)))), optional phase[e][k] = atan2(im, re) (f64).
- * Reference analyse/frequency_response.py:213-218, analyse/filterplot.py:152-160. */
+ * Reference analyse/frequency_response.py:213-218, analyse/filterplot.py:152-160.
+ * packed_dev (may be NULL): packed[e] != 0 says element e (even L[e]) is still the PACKED half-length transform
+ * Z = DFT(x[2m] + i x[2m+1]) of L[e]/2 values (ira_rfft_any, keep_packed) at spec_off_dev[e]; its L[e]/2+1 bins are formed
+ * on the fly. */
 int32_t ira_spectrum_mag_phase(const double* spec_dev, const int64_t* spec_off_dev, const int32_t* L_dev,
                                int32_t nb, int32_t max_len, double floor_db, float* mag_db_dev,
                                const int64_t* mag_off_dev, double* phase_dev,
-                               const int64_t* phase_off_dev, void* stream);
+                               const int64_t* phase_off_dev, const int32_t* packed_dev, void* stream);
 
 /* numpy.unwrap (optional) + rad2deg (optional) -> float32 (out_dev, may be NULL), and/or the unwrapped phase in
  * float64 radians (out64_dev, may be NULL; same offsets).  Reference analyse/filterplot.py:162-168 and
@@ -374,7 +381,9 @@ int32_t ira_fir_numerator(const double* coeffs_dev, int32_t order, const float* 
  * and its results cannot depend on its neighbours in a batch (byte-identical records for any sharding):
  *   ira_rfft_smooth(..., interleave = 1): every job is ONE real signal of even length 2 n carried as the n-point complex
  *     sequence x[2m] + i x[2m+1] (x2off_dev[e] = xoff_dev[e] + 1; data_len / win_len, when given, count REAL samples; the
- *     second signal's length arrays must be NULL); spec_off_dev[e] receives its n + 1 bins.  zpair: n complex per job.
+ *     second signal's length arrays must be NULL); spec_off_dev[e] receives its n + 1 bins.  zpair: n complex per job --
+ *     or NULL (round 4, n1 even): the untangling is then part of the second pass (the intermediate is laid out in tiles
+ *     of a row and its mirror row, so Z[k] and Z[n-k] meet in one workgroup) and no scratch or split pass exists.
  *   ira_band_irfft_smooth(..., half_out = 1): every job is ONE band (band record 2e; record 2e+1 is ignored) of a real
  *     signal of even length 2 n, computed by an n-point transform: the job's half spectrum has n + 1 bins, y1_off_dev[e]
  *     receives 2 n samples, y2_off_dev is ignored, spec_off2_dev must be NULL. */

@@ -111,6 +111,69 @@ def test_even_lengths_use_the_half_size_transform_and_match_unpacked():
             assert np.max(np.abs(g - g2)) / np.max(np.abs(ref)) < 1e-13
 
 
+def test_untangling_fused_into_the_producing_and_consuming_kernels():
+    """the separate split passes over a half-length transform are gone.  Smooth lengths with an even
+    n1: the second pass of ira_rfft_smooth forms X[k] from Z[k] and Z[n-k], which its mirror-pair tiles bring together
+    (240 000 = 480 x 500, 2^18 = 512 x 512, 48 000 = 200 x 240; 50 625 = 225 x 225 keeps round 3's split pass).  Bluestein
+    lengths: the spectrum stays packed and ira_spectrum_mag_phase untangles as it reads.  Both against numpy.fft.rfft and
+    against the unfused path (Engine.fuse_half_split = False), zero-padded / windowed variants included."""
+    from audio_analysis_amd.engine import get_engine
+    eng = get_engine()
+    rng = np.random.default_rng(23)
+    n = 530000
+    x = (rng.standard_normal(n) * np.exp(-np.arange(n) / 60000.0)).astype(np.float32)
+    b = eng.upload([x, x[::-1].copy()])
+    assert eng.fuse_half_split
+    smooth = [480000, 1 << 19, 96000, 101250, 2 * 3 * 5 * 128, 128]
+    for L in smooth:
+        assert eng.smooth_split(L // 2) is not None, L
+    try:
+        for hann in (False, True):
+            for L in smooth:
+                lens = np.array([L, L], np.int32)
+                ref = [np.fft.rfft(c[:L].astype(np.float64) * (np.hanning(L) if hann else 1.0)) for c in (x, x[::-1])]
+                out = {}
+                for fused in (True, False):
+                    eng.fuse_half_split = fused
+                    spec, off = eng.rfft_any(b.x, b.off, lens, hann)
+                    h = spec.cpu().numpy().reshape(-1, 2)
+                    out[fused] = [h[o : o + L // 2 + 1, 0] + 1j * h[o : o + L // 2 + 1, 1] for o in off]
+                for i in range(2):
+                    scale = np.max(np.abs(ref[i]))
+                    assert np.max(np.abs(out[True][i] - ref[i])) < 5e-14 * scale, (L, hann, i)
+                    assert np.max(np.abs(out[True][i] - out[False][i])) < 2e-15 * scale, (L, hann, i)
+                    assert out[True][i][0].imag == 0.0 and out[True][i][-1].imag == 0.0
+        # zero-padded with its own window length (the group-delay transform): 479 500 samples under hanning(479 500) in 2^19
+        eng.fuse_half_split = True
+        d, L = 479500, 1 << 19
+        spec, off = eng.rfft_any(b.x, b.off[:1], np.array([L], np.int32), True, data_len=np.array([d], np.int32),
+                                 win_len=np.array([d], np.int32))
+        h = spec.cpu().numpy().reshape(-1, 2)
+        ref = np.fft.rfft(x[:d].astype(np.float64) * np.hanning(d), n=L)
+        assert np.max(np.abs(h[: L // 2 + 1, 0] + 1j * h[: L // 2 + 1, 1] - ref)) < 5e-14 * np.max(np.abs(ref))
+        # Bluestein, even lengths: packed spectra through the dB / phase kernel
+        lens = np.array([479254, 95998], np.int32)
+        res = {}
+        for fused in (True, False):
+            eng.fuse_half_split = fused
+            spec, off, packed = eng.rfft_any(b.x, b.off, lens, True, packed_ok=True)
+            assert (packed is not None and list(packed) == [1, 1]) if fused else packed is None
+            mag, ph = eng.spectrum_mag_phase(spec, off, lens, -120.0, want_phase=True, packed=packed)
+            res[fused] = (mag.cpu().numpy(), ph.cpu().numpy(), off)
+        for i, L in enumerate(lens):
+            o, nb = int(res[True][2][i]), int(L) // 2 + 1
+            ref = np.fft.rfft((x if i == 0 else x[::-1])[:L].astype(np.float64) * np.hanning(L))
+            ref_db = (20.0 * np.log10(np.maximum(np.abs(ref), 1e-6))).astype(np.float32)
+            assert np.max(np.abs(res[True][0][o : o + nb] - ref_db)) < 2e-5
+            assert np.max(np.abs(res[True][0][o : o + nb] - res[False][0][o : o + nb])) < 1e-5
+            dphi = np.abs(res[True][1][o : o + nb] - np.angle(ref))
+            dphi = np.minimum(dphi, 2 * np.pi - dphi)                     # a bin on the negative real axis may land on either side
+            strong = np.abs(ref) > 1e-9 * np.max(np.abs(ref))
+            assert np.max(dphi[strong]) < 1e-7, np.max(dphi[strong])
+    finally:
+        eng.fuse_half_split = True
+
+
 def test_convolution_sizes_three_times_a_power_of_two():
     """
     Bluestein over M = 3 * 2^k (radix-3 column stage) and the reduced size rule for single real signals (M >= L + L/2: the

@@ -360,7 +360,80 @@ def test_bench_starts_its_own_ranks():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line == {"n_gpus": 2, "ranks": [0.0, 1.0], "rows": 6}
+    assert (line["n_gpus"], line["ranks"], line["rows"]) == (2, [0.0, 1.0], 6)
+    # every rank narrows itself to its own CPUs before anything allocates (the cores of its GPU's NUMA
+    # node where sysfs shows the topology, an even split of the allowed CPUs here): disjoint sets, whole set covered
+    if line["cpus_before"] >= 2:
+        assert line["disjoint"] and all(len(a) >= 1 for a in line["affinity"]), line
+        assert sum(len(a) for a in line["affinity"]) <= line["cpus_before"]
+
+
+def test_rank_affinity_follows_the_gpu_numa_nodes():
+    """dist.rank_cpu_affinity on a made-up two-socket, eight-GPU host: four ranks per NUMA node, each gets a quarter of its
+    node's CPUs, hardware threads of one core stay together when sysfs names the siblings (not here: identity order),
+    slices are disjoint and stay inside the rank's node; fewer CPUs than ranks or no topology -> documented fallbacks."""
+    from audio_analysis_amd import dist as D
+    node0 = list(range(0, 64)) + list(range(128, 192))
+    node1 = list(range(64, 128)) + list(range(192, 256))
+    gpus = [(f"0000:{b:02x}:00.0", 0 if i < 4 else 1, node0 if i < 4 else node1) for i, b in enumerate(range(5, 85, 10))]
+    got = [D.rank_cpu_affinity(r, 8, list(range(256)), gpus) for r in range(8)]
+    sets = [set(c) for c, _ in got]
+    assert all(len(x) == 32 for x in sets)
+    assert all(sets[i].isdisjoint(sets[j]) for i in range(8) for j in range(i))
+    assert all(sets[r] <= set(node0 if r < 4 else node1) for r in range(8))
+    assert "numa node 1" in got[5][1]
+    # the lease allows only some of the host's CPUs: slices come from the allowed ones
+    c, how = D.rank_cpu_affinity(1, 2, list(range(0, 16)), gpus)
+    assert set(c) <= set(range(16)) and len(c) == 8
+    # no topology: even split; one rank: untouched
+    c, how = D.rank_cpu_affinity(2, 4, list(range(12)), [])
+    assert c == [6, 7, 8] and "even split" in how
+    assert D.rank_cpu_affinity(0, 1, [3, 4, 5], [])[0] == [3, 4, 5]
+    assert D._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+
+
+def test_bench_parity_report_reads_the_record_layout():
+    """bench.py's cpu_baseline workers return the oracle's values for the files they time; rank 0 compares them with the
+    gathered records (RT60 and pole radii as max and fraction within 1e-4).  Here: records filled FROM the
+    oracle's values must compare as exact, a perturbed RT60 must show up, a None / NaN mismatch must be counted."""
+    sys.path.insert(0, str(REPO))
+    import bench
+    from audio_analysis_amd import pipeline as P
+    blocks = ("decay", "rt60bands", "fr", "filter", "spectrogram", "waterfall", "modalcloud", "zplane")
+    secs, vals, specs = bench._cpu_one((5, 0.5, blocks, "three", False, False, True))
+    assert secs > 0 and len(vals) == 1 and len(specs) == 1 and specs[0].shape[0] == 2049
+    v = vals[0]
+    rec = np.full((1, P.METRICS_WIDTH), np.nan)
+    rec[0, P.M_STATUS] = 0.0
+    rec[0, P.M_START] = v["start"]; rec[0, P.M_EARLY10] = v["early10"]
+    rec[0, P.M_FIT_T20 + 6], rec[0, P.M_FIT_T30 + 6] = v["t20_rt60"], v["t30_rt60"]
+    for k, t in enumerate(v["bands_t30"]):
+        rec[0, P.M_BANDS + 3 * k] = np.nan if t is None else t
+    rec[0, P.M_FR_PEAK], rec[0, P.M_FR_CENTROID] = v["fr_peak_hz"], v["fr_centroid_hz"]
+    rec[0, P.M_FILT_PEAK], rec[0, P.M_FILT_1K] = v["filter_peak_hz"], v["filter_1k_db"]
+    rec[0, P.M_SPEC_FRAMES], rec[0, P.M_WF_SLICES], rec[0, P.M_WF_BINS] = v["spec_frames"], v["wf_slices"], v["wf_bins"]
+    rec[0, P.M_MODAL_POINTS] = v["modal_points"]
+    if v["modal_points"]:
+        rec[0, P.M_MODAL_MEDIAN], rec[0, P.M_MODAL_P90], rec[0, P.M_MODAL_MAX] = v["modal_median"], v["modal_p90"], v["modal_max"]
+    rec[0, P.M_AR_MAX_R], rec[0, P.M_AR_MEDIAN_R], rec[0, P.M_AR_UNSTABLE] = v["ar_max_radius"], v["ar_median_radius"], v["ar_unstable"]
+    rep = bench.parity_report(rec, vals, 3)
+    for name, e in rep.items():
+        if "max_rel" in e:
+            assert e["max_rel"] == 0.0 and e["frac_within_1e_4"] == 1.0, (name, e)
+        if "exact_matches" in e:
+            assert e["exact_matches"] == e["n"], (name, e)
+        if "none_pattern_matches" in e:
+            assert e["none_pattern_matches"] == e["of"], (name, e)
+    assert rep["t30_rt60_s"]["n"] == 1 and rep["ar_max_radius"]["n"] == 1 and rep["band_t30_rt60_s"]["of"] == 3
+    rec2 = rec.copy()
+    rec2[0, P.M_FIT_T30 + 6] *= 1.0 + 3e-4
+    rec2[0, P.M_FIT_T20 + 6] = np.nan
+    rec2[0, P.M_START] += 1
+    rep2 = bench.parity_report(rec2, vals, 3)
+    assert 2.9e-4 < rep2["t30_rt60_s"]["max_rel"] < 3.1e-4 and rep2["t30_rt60_s"]["frac_within_1e_4"] == 0.0
+    assert rep2["t20_rt60_s"]["none_pattern_matches"] == 0 and rep2["start_index"]["exact_matches"] == 0
+    sp = bench.spectrogram_parity([specs[0] + np.float32(5e-4)], specs, -120.0)
+    assert 4e-4 < sp["max_abs_err_db"] < 6e-4 and sp["fraction_within_1e-3_db"] == 1.0
 
 
 # ---------------------------------------------------------------------------------------- report host helpers
