@@ -13,6 +13,13 @@ namespace {
 constexpr int PEAK_THREADS = 256;
 constexpr int PEAK_CHUNK = 16384;  // samples per workgroup
 
+__device__ __forceinline__ unsigned long long peak_key(float v, int64_t i) {
+  return ((unsigned long long)__float_as_uint(fabsf(v)) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
+}
+
+// Sixteen-byte loads, all of a thread's loads in flight together: the chunk is cut into a scalar head up to the first
+// 16-byte boundary (segments start anywhere: peak-trimmed offsets), PEAK_CHUNK / 4 - 1 aligned float4 values and a scalar
+// tail.  (Round 3 read one float per lane and iteration: 2.9 TB/s on a kernel that does nothing but read 4N bytes.)
 __global__ __launch_bounds__(PEAK_THREADS) void peak_partial_kernel(
     const float* __restrict__ x, const int64_t* __restrict__ off, const int64_t* __restrict__ len,
     unsigned long long* __restrict__ keys) {
@@ -22,12 +29,45 @@ __global__ __launch_bounds__(PEAK_THREADS) void peak_partial_kernel(
   if (c0 >= n) return;
   const int64_t c1 = (c0 + PEAK_CHUNK < n) ? c0 + PEAK_CHUNK : n;
   const float* p = x + off[s];
+  const int tid = threadIdx.x;
+  const int cnt = (int)(c1 - c0);
+  const float* q = p + c0;
+  int head = (int)(((16u - (unsigned)((uintptr_t)q & 15u)) & 15u) >> 2);
+  head = head < cnt ? head : cnt;
+  const int nvec = (cnt - head) >> 2;
+  const float4* v4 = reinterpret_cast<const float4*>(q + head);
   unsigned long long best = 0ull;
-  for (int64_t i = c0 + threadIdx.x; i < c1; i += PEAK_THREADS) {
-    const float a = fabsf(p[i]);
-    const unsigned long long k =
-        ((unsigned long long)__float_as_uint(a) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
+  constexpr int PU = PEAK_CHUNK / 4 / PEAK_THREADS;          // 16 vector loads per thread
+  if (nvec > 0) {                                             // (workgroup-uniform: a chunk of fewer than four aligned samples
+    float4 a[PU];                                             //  has no vector part and must not touch memory past its end)
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+      const int j = tid + PEAK_THREADS * u;
+      a[u] = v4[j < nvec ? j : nvec - 1];                     // clamped: unconditional loads, all in flight together
+    }
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+      const int j = tid + PEAK_THREADS * u;
+      if (j < nvec) {
+        const int64_t i = c0 + head + 4 * (int64_t)j;
+        unsigned long long k;
+        k = peak_key(a[u].x, i);     best = k > best ? k : best;
+        k = peak_key(a[u].y, i + 1); best = k > best ? k : best;
+        k = peak_key(a[u].z, i + 2); best = k > best ? k : best;
+        k = peak_key(a[u].w, i + 3); best = k > best ? k : best;
+      }
+    }
+  }
+  if (tid < head) {
+    const unsigned long long k = peak_key(q[tid], c0 + tid);
     best = k > best ? k : best;
+  }
+  {
+    const int t0 = head + 4 * nvec + tid;                     // at most three tail samples
+    if (t0 < cnt) {
+      const unsigned long long k = peak_key(q[t0], c0 + t0);
+      best = k > best ? k : best;
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {

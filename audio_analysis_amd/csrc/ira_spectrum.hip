@@ -44,6 +44,33 @@ __device__ __forceinline__ double atan2_table(double y, double x, const double* 
   return copysign(a, y);
 }
 
+// ---- numpy.unwrap correction between two neighbouring phases (the definition follows numpy operation by operation) ----
+__device__ __forceinline__ double unwrap_correction(double prev, double cur) {
+  const double dd = cur - prev;
+  const double period = 2.0 * kPi;
+  double a = dd + kPi;               // dd - interval_low
+  // numpy floor-mod for a positive divisor: md = fmod(a, period), moved up by one period when negative.  Phases come from
+  // atan2, so |dd| <= 2 pi and a lies in [-pi, 3 pi]: there fmod(a, period) is a itself or the EXACT difference a - period
+  // (Sterbenz), no division loop needed -- the library fmod (~150 instructions for a float64) was most of the arithmetic of
+  // the unwrap, which made a kernel that moves 12 bytes per bin VALU-bound.  Anything outside (a caller's own phase array)
+  // takes the library routine.
+  double md;
+  if (a >= 0.0 && a < period) md = a;
+  else if (a >= period && a < 2.0 * period) md = a - period;
+  else if (a < 0.0 && a > -period) md = a;
+  else md = fmod(a, period);
+  if (md != 0.0) {
+    if (md < 0.0) md += period;
+  } else {
+    md = 0.0;
+  }
+  double ddmod = md + (-kPi);
+  if (ddmod == -kPi && dd > 0.0) ddmod = kPi;
+  double corr = ddmod - dd;
+  if (fabs(dd) < kPi) corr = 0.0;
+  return corr;
+}
+
 __global__ __launch_bounds__(256) void mag_phase_kernel(const cd* __restrict__ spec, const int64_t* __restrict__ spec_off,
                                  const int32_t* __restrict__ L, double floor_lin, float* __restrict__ mag_db,
                                  const int64_t* __restrict__ mag_off, double* __restrict__ phase,
@@ -108,23 +135,6 @@ __global__ __launch_bounds__(256) void mag_phase_kernel(const cd* __restrict__ s
 constexpr int UW_THREADS = 1024;
 constexpr int UW_PER = 4;
 constexpr int UW_TILE = UW_THREADS * UW_PER;
-
-__device__ __forceinline__ double unwrap_correction(double prev, double cur) {
-  const double dd = cur - prev;
-  const double period = 2.0 * kPi;
-  double a = dd + kPi;               // dd - interval_low
-  double md = fmod(a, period);       // numpy floor-mod for a positive divisor
-  if (md != 0.0) {
-    if (md < 0.0) md += period;
-  } else {
-    md = 0.0;
-  }
-  double ddmod = md + (-kPi);
-  if (ddmod == -kPi && dd > 0.0) ddmod = kPi;
-  double corr = ddmod - dd;
-  if (fabs(dd) < kPi) corr = 0.0;
-  return corr;
-}
 
 __global__ __launch_bounds__(UW_THREADS) void unwrap_kernel(const double* __restrict__ phase,
                                                             const int64_t* __restrict__ phase_off,

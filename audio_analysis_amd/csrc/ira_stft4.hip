@@ -520,6 +520,246 @@ __global__ __launch_bounds__(TL5) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// STFT v8: ONE FRAME ON EIGHT WAVES (512 lanes, 8 complex values per lane), M = 4096 = 8 * 8 * 8 * 8 (round 4).
+// v5's own ablation (profiles/r03_stft5_isa_segments.txt): the transform + exchange part of a frame is a latency chain
+// (1360 instructions, 12 workgroup barriers) that four waves per SIMD hide only half of; registers (122) and LDS (35 KB per
+// frame) both stop at four frames per CU.  With eight values per lane a frame needs <= 64 registers, so the same four
+// frames per CU bring EIGHT waves per SIMD -- and the radix-8 decomposition makes the first digit of the output index the
+// WAVE number, which turns two of the three exchanges into wave-private transposes without any workgroup barrier:
+//   n = 512 n1 + 64 n2 + 8 n3 + n4,  k = k1 + 8 k2 + 64 k3 + 512 k4
+//   step 1  wave n2, lane 8 n4 + n3: 8-point DFT over n1 of the windowed packed samples, twiddle W_M^(k1 m), m = 64 n2 + 8 n3 + n4
+//   E1      the only cross-wave exchange, half the frame at a time: rows k1 of 256 complex; wave k1 reads the n2 = 0..3
+//           then 4..7 entries of ITS row, lane-linear both ways (conflict free)                        -- 4 barriers
+//   step 2  wave k1, lane 8 n4 + n3: DFT over n2, twiddle W_512^(k2 m'), m' = 8 n3 + n4
+//   E2      wave-private 8 x 8 transpose (k2 <-> n3) through the wave's own 4.6 KB, real then imaginary parts: lane stride 9
+//           doubles for the writes, 8 n3 + ... gathers for the reads, both bank-conflict free            -- no barrier
+//   step 3  wave k1, lane 8 n4 + k2: DFT over n3, twiddle W_64^(k3 n4)
+//   E3      wave-private transpose (k3 <-> n4): rows k3 of 72 doubles                                    -- no barrier
+//   step 4  wave k1, lane 8 k3 + k2: DFT over n4 -> the lane holds Z[r + 512 k4], r = k1 + 8 k2 + 64 k3
+//   mirror  as v5: every lane publishes its upper four values at its own (wave, lane) slot; the partner of r is
+//           wave 8 - k1, lane 63 - lane (wave 0: a permutation of its own lanes)                       -- 3 barriers
+//   post    as v5 (dB, or linear magnitudes -> log-bin means)
+// LDS per frame: 36 864 B of exchange + the 2 KB log table: four frames per CU.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int TL8 = 512;
+constexpr int REG8 = 576;                      // doubles of one wave's transpose region: 64 lanes x 9 = 8 rows x 72
+constexpr int EX8 = 8 * REG8;                  // doubles per workgroup
+static_assert(EX8 >= 2 * 8 * 256 && EX8 >= 2 * 4 * TL8 && EX8 >= F4, "exchange buffer too small");
+
+__global__ __launch_bounds__(TL8) __attribute__((amdgpu_waves_per_eu(8, 8))) void stft8_kernel(
+    const float* __restrict__ x, const int64_t* __restrict__ off, const int32_t* __restrict__ nframes, int hop,
+    const double* __restrict__ window, const cdd* __restrict__ tw, double floor_lin, float floor_db,
+    float* __restrict__ out, const int64_t* __restrict__ out_off, const int32_t* __restrict__ frame_sel,
+    const int64_t* __restrict__ sel_off, int lb_nbins, int lb_kbase, const int32_t* __restrict__ lb_first,
+    const int32_t* __restrict__ lb_count) {
+  __shared__ __attribute__((aligned(16))) double exd[EX8];
+  __shared__ ira::LogTabEntry ltab[ira::LOGTAB_N];
+  __shared__ int lb_range[2];
+  __shared__ int frame_bad;
+  cdd* ex = reinterpret_cast<cdd*>(exd);
+  const unsigned gx = gridDim.x, nwg = gridDim.x * gridDim.y;
+  const unsigned orig = blockIdx.y * gx + blockIdx.x;
+  const unsigned xq = nwg / 8, xr = nwg % 8, xcd = orig % 8;
+  const unsigned wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + orig / 8;
+  const int seg = (int)(wg / gx);
+  const int col = (int)(wg % gx);
+  const int T_out = nframes[seg];
+  if (col >= T_out) return;
+  const int q = threadIdx.x, wave = q >> 6, lane = q & 63;
+  ira::build_log_table(ltab, q);
+  if (q < 2) lb_range[q] = q == 0 ? F4 : 0;
+  const int64_t frame = frame_sel ? (int64_t)frame_sel[sel_off[seg] + col] : (int64_t)col;
+  const float* fx = x + off[seg] + frame * hop;
+  cdd wuni[4];                                                   // wave-uniform post factors W_N^(512 i): scalar loads, up front
+#pragma unroll
+  for (int i = 0; i < 4; ++i) wuni[i] = tw[TL8 * i];
+
+  // ---- step 1: lane (n4 = lane >> 3, n3 = lane & 7) of wave n2 transforms m = 64 n2 + 8 n3 + n4 ------------------------------
+  cdd v[8];
+  {
+    const int m = wave * 64 + (lane & 7) * 8 + (lane >> 3);
+    float2 xs[8];
+    double2 ws[8];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) {
+      const int n = n1 * 512 + m;
+      xs[n1] = *reinterpret_cast<const float2*>(fx + 2 * n);
+      ws[n1] = *reinterpret_cast<const double2*>(window + 2 * n);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) v[n1] = {(double)xs[n1].x * ws[n1].x, (double)xs[n1].y * ws[n1].y};
+    dft_dif<double, 8>(v);
+    ira::twiddle8<double, true>(v, tw[2 * m]);                   // W_M^(k1 m) = W_N^(2 m k1), k1 at v[brev3(k1)]
+  }
+
+  // ---- E1: rows k1 of 256 complex, the writers' lane order kept; wave k1 reads its row ----------------------------------------
+  cdd b[8];
+  const bool lower = q < 256;
+  if (lower) {
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) ex[k1 * 256 + q] = v[brev_bits(k1, 3)];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int n2 = 0; n2 < 4; ++n2) b[n2] = ex[wave * 256 + n2 * 64 + lane];
+  __syncthreads();
+  if (!lower) {
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) ex[k1 * 256 + (q - 256)] = v[brev_bits(k1, 3)];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int n2 = 0; n2 < 4; ++n2) b[4 + n2] = ex[wave * 256 + n2 * 64 + lane];
+  __syncthreads();                                               // E1 fully read: the wave regions below overlap it
+
+  // ---- step 2 (wave = k1, lane = 8 n4 + n3) and the wave-private transpose k2 <-> n3 ----------------------------------------------
+  double* reg = exd + wave * REG8;
+  dft_dif<double, 8>(b);
+  ira::twiddle8<double, true>(b, tw[16 * ((lane & 7) * 8 + (lane >> 3))]);      // W_512^(k2 m') = W_N^(16 m' k2)
+  cdd c[8];
+  {
+    const int rd = (lane >> 3) * 72 + (lane & 7);               // (8 n4 + n3) * 9 + k2 with n4 = lane >> 3, k2 = lane & 7, n3 = 0
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) reg[lane * 9 + k2] = b[brev_bits(k2, 3)].re;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int n3 = 0; n3 < 8; ++n3) c[n3].re = reg[rd + n3 * 9];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) reg[lane * 9 + k2] = b[brev_bits(k2, 3)].im;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int n3 = 0; n3 < 8; ++n3) c[n3].im = reg[rd + n3 * 9];
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // ---- step 3 (lane = 8 n4 + k2) and the wave-private transpose k3 <-> n4 ---------------------------------------------------
+  dft_dif<double, 8>(c);
+  ira::twiddle8<double, true>(c, tw[128 * (lane >> 3)]);        // W_64^(k3 n4) = W_N^(128 n4 k3)
+  cdd d[8];
+  {
+    const int rd = (lane >> 3) * 72 + (lane & 7);               // row k3 = lane >> 3, column 8 n4 + k2 with k2 = lane & 7, n4 = 0
+#pragma unroll
+    for (int k3 = 0; k3 < 8; ++k3) reg[k3 * 72 + lane] = c[brev_bits(k3, 3)].re;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int n4 = 0; n4 < 8; ++n4) d[n4].re = reg[rd + n4 * 8];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k3 = 0; k3 < 8; ++k3) reg[k3 * 72 + lane] = c[brev_bits(k3, 3)].im;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int n4 = 0; n4 < 8; ++n4) d[n4].im = reg[rd + n4 * 8];
+  }
+
+  // ---- step 4: lane (k3 = lane >> 3, k2 = lane & 7) of wave k1 holds Z[r + 512 k4] at d[brev3(k4)] --------------------------------
+  dft_dif<double, 8>(d);
+  const int r = wave + 8 * (lane & 7) + 64 * (lane >> 3);
+
+  // ---- mirror exchange: the upper four values of every lane at its own slot; partner of r = (512 - r) mod 512 -------------------
+  __syncthreads();                                               // every wave has left its transpose region
+#pragma unroll
+  for (int j = 0; j < 4; ++j) ex[j * TL8 + q] = d[brev_bits(4 + j, 3)];
+  __syncthreads();
+  double zkr[4], zki[4], zpr[4], zpi[4], midr, midi;
+  {
+    int pos;
+    if (wave > 0) {
+      pos = (8 - wave) * 64 + (63 - lane);
+    } else {
+      const int k2 = lane & 7, k3 = lane >> 3;
+      pos = k2 > 0 ? (7 - k3) * 8 + (8 - k2) : ((8 - k3) & 7) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // partner entry k4 = 7 - i (slot 3 - i); r = 0 pairs with itself: k4 = 8 - i (slot 4 - i), i = 0 -> Z[0] itself
+      const int slot = r == 0 ? 4 - i : 3 - i;
+      cdd zp = d[0];
+      if (!(r == 0 && i == 0)) zp = ex[slot * TL8 + pos];
+      zkr[i] = d[brev_bits(i, 3)].re; zki[i] = d[brev_bits(i, 3)].im;
+      zpr[i] = zp.re; zpi[i] = zp.im;
+    }
+    const cdd mid = ex[0];                                       // Z[2048]: r = 0, k4 = 4
+    midr = mid.re; midi = mid.im;
+  }
+  if (q == 0) frame_bad = !((zkr[0] - zkr[0]) + (zki[0] - zki[0]) == 0.0) ? 1 : 0;   // NaN / infinity in the frame (see v4)
+  __syncthreads();                                               // mirror slots fully read; frame_bad, lb_range visible
+  const bool bad_frame = frame_bad != 0;
+  const float qnan32 = __uint_as_float(0x7fc00000u);
+
+  // ---- post ---------------------------------------------------------------------------------------------------
+  const double floor_pow = floor_lin * floor_lin;
+  const cdd wlane = tw[r];
+  if (lb_nbins <= 0) {
+    float* fo = out + out_off[seg] + (int64_t)col * F4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = r + TL8 * i;
+      const cdd e = {0.5 * (zkr[i] + zpr[i]), 0.5 * (zki[i] - zpi[i])};
+      const cdd dd = {0.5 * (zkr[i] - zpr[i]), 0.5 * (zki[i] + zpi[i])};
+      const cdd o = {dd.im, -dd.re};
+      const cdd wk = ira::cmul(wlane, wuni[i]);                  // W_N^k = W_N^r W_N^(512 i); second factor wave-uniform
+      const cdd pp = ira::cmul(wk, o);
+      fo[k] = bad_frame ? qnan32 : db_of4(e.re + pp.re, e.im + pp.im, floor_pow, floor_db, ltab);
+      fo[M4 - k] = bad_frame ? qnan32 : db_of4(e.re - pp.re, e.im - pp.im, floor_pow, floor_db, ltab);   // k = 0 -> bin M
+    }
+    if (q == 0) fo[M4 / 2] = bad_frame ? qnan32 : db_of4(midr, midi, floor_pow, floor_db, ltab);
+    return;
+  }
+  // fused modal-cloud aggregation, as in v4 / v5
+  {
+    int lo = F4, hi = 0;
+    for (int bb = q; bb < lb_nbins; bb += TL8) {
+      const int cn = lb_count[bb];
+      if (cn > 0) {
+        const int f0 = lb_kbase + lb_first[bb];
+        lo = f0 < lo ? f0 : lo;
+        hi = f0 + cn > hi ? f0 + cn : hi;
+      }
+    }
+    if (q < lb_nbins) { atomicMin(&lb_range[0], lo); atomicMax(&lb_range[1], hi); }
+  }
+  __syncthreads();
+  const int k_lo = lb_range[0], k_hi = lb_range[1];
+  const double floor_lin32 = exp10((double)floor_db * 0.05);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = r + TL8 * i;
+    const bool need_a = k >= k_lo && k < k_hi, need_b = (M4 - k) >= k_lo && (M4 - k) < k_hi;
+    if (!need_a && !need_b) continue;
+    const cdd e = {0.5 * (zkr[i] + zpr[i]), 0.5 * (zki[i] - zpi[i])};
+    const cdd dd = {0.5 * (zkr[i] - zpr[i]), 0.5 * (zki[i] + zpi[i])};
+    const cdd o = {dd.im, -dd.re};
+    const cdd wk = ira::cmul(wlane, wuni[i]);
+    const cdd pp = ira::cmul(wk, o);
+    if (need_a) exd[k] = lin_of4(e.re + pp.re, e.im + pp.im, floor_pow, floor_db, floor_lin32, ltab);
+    if (need_b) exd[M4 - k] = lin_of4(e.re - pp.re, e.im - pp.im, floor_pow, floor_db, floor_lin32, ltab);
+  }
+  if (q == 0 && M4 / 2 >= k_lo && M4 / 2 < k_hi) exd[M4 / 2] = lin_of4(midr, midi, floor_pow, floor_db, floor_lin32, ltab);
+  __syncthreads();
+  float* co = out + out_off[seg];
+  for (int bb = q; bb < lb_nbins; bb += TL8) {
+    const int cn = lb_count[bb];
+    float val = qnan32;
+    if (cn > 0) {
+      const double* rr = exd + lb_kbase + lb_first[bb];
+      double acc = rr[0];
+      for (int k0 = 1; k0 < cn; k0 += 8) {
+        double v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v8[u] = (k0 + u < cn) ? rr[k0 + u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (k0 + u < cn) acc += v8[u];
+      }
+      val = (float)(6.0205999132796239 * ira::log2_table<6>(fmax(acc / (double)cn, 1e-30), ltab));
+    }
+    co[(int64_t)bb * T_out + col] = (bad_frame && cn > 0) ? qnan32 : val;
+  }
+}
+
 }  // namespace
 
 // float64 / n_fft 8192, frame-major output only; anything else returns IRA_E_UNSUPPORTED.
@@ -534,10 +774,14 @@ int32_t ira_stft4_dispatch_tf(const float* x, const int64_t* off, const int32_t*
     stft4_kernel<<<grid, TL4, 0, st>>>(x, off, nframes, hop, static_cast<const double*>(window),
                                        static_cast<const cdd*>(tw), floor_lin, (float)floor_db, out, out_off, frame_sel,
                                        sel_off, 0, 0, nullptr, nullptr);
-  else
+  else if (ira_tune_flag("IRA_STFT_V5"))
     stft5_kernel<<<grid, TL5, 0, st>>>(x, off, nframes, hop, static_cast<const double*>(window),
                                        static_cast<const cdd*>(tw), floor_lin, (float)floor_db, out, out_off, frame_sel,
                                        sel_off, 0, 0, nullptr, nullptr, ira_tune_int("IRA_STFT5_ABLATE", 0));
+  else
+    stft8_kernel<<<grid, TL8, 0, st>>>(x, off, nframes, hop, static_cast<const double*>(window),
+                                       static_cast<const cdd*>(tw), floor_lin, (float)floor_db, out, out_off, frame_sel,
+                                       sel_off, 0, 0, nullptr, nullptr);
   IRA_RETURN_LAUNCH();
 }
 
@@ -554,9 +798,13 @@ int32_t ira_stft4_dispatch_logbin(const float* x, const int64_t* off, const int3
     stft4_kernel<<<grid, TL4, 0, st>>>(x, off, nframes, hop, static_cast<const double*>(window),
                                        static_cast<const cdd*>(tw), floor_lin, (float)floor_db, curves, curves_off,
                                        nullptr, nullptr, nbins, k_base, first, count);
-  else
+  else if (ira_tune_flag("IRA_STFT_V5"))
     stft5_kernel<<<grid, TL5, 0, st>>>(x, off, nframes, hop, static_cast<const double*>(window),
                                        static_cast<const cdd*>(tw), floor_lin, (float)floor_db, curves, curves_off,
                                        nullptr, nullptr, nbins, k_base, first, count, ira_tune_int("IRA_STFT5_ABLATE", 0));
+  else
+    stft8_kernel<<<grid, TL8, 0, st>>>(x, off, nframes, hop, static_cast<const double*>(window),
+                                       static_cast<const cdd*>(tw), floor_lin, (float)floor_db, curves, curves_off,
+                                       nullptr, nullptr, nbins, k_base, first, count);
   IRA_RETURN_LAUNCH();
 }

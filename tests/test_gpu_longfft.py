@@ -174,6 +174,38 @@ def test_untangling_fused_into_the_producing_and_consuming_kernels():
         eng.fuse_half_split = True
 
 
+def test_unwrap_equals_numpy_unwrap_on_winding_phases():
+    """The unwrap correction no longer calls the library fmod (phases from atan2 keep dd + pi inside [-pi, 3 pi], where the
+    floor-mod is a compare and an exact subtraction): against numpy.unwrap(numpy.angle(.)) on spectra whose phase winds
+    thousands of times, with exact 0 / pi / 0 steps, bin counts from 2 to 240 k in one batch, float32 degrees and float64
+    radians, and with the unwrap switched off."""
+    from audio_analysis_amd.engine import get_engine
+    eng = get_engine()
+    rng = np.random.default_rng(3)
+    lengths = np.array([2, 126, 128, 130, 254, 256, 8190, 200001, 479518], np.int32)
+    bins = lengths.astype(np.int64) // 2 + 1
+    off = (np.cumsum(bins) - bins).astype(np.int64)
+    spec = np.empty((int(bins.sum()), 2))
+    refs = []
+    for L, o, nb in zip(lengths, off, bins):
+        k = np.arange(nb)
+        ph = -2.0 * np.pi * k * (237.3 / max(int(L), 1)) + 0.3 * rng.standard_normal(nb)
+        z = (1.0 + rng.random(nb)) * np.exp(1j * ph)
+        if nb > 70:
+            z[64] = -abs(z[64]); z[63] = abs(z[63]); z[65] = abs(z[65])          # phases 0, pi, 0
+        spec[o : o + nb, 0], spec[o : o + nb, 1] = z.real, z.imag
+        refs.append(np.unwrap(np.angle(z)))
+    d_spec = eng.to_dev(spec.reshape(-1))
+    mag, ph = eng.spectrum_mag_phase(d_spec, off, lengths, -120.0, want_phase=True)
+    rad = eng.phase_unwrap(ph, off, lengths, True, False, as_float64=True).cpu().numpy()
+    deg = eng.phase_unwrap(ph, off, lengths, True, True).cpu().numpy()
+    flat = eng.phase_unwrap(ph, off, lengths, False, False, as_float64=True).cpu().numpy()
+    assert np.array_equal(flat, ph.cpu().numpy())
+    for o, nb, ref in zip(off, bins, refs):
+        assert np.max(np.abs(rad[o : o + nb] - ref)) <= 1e-9 * max(1.0, np.max(np.abs(ref))), nb
+        assert np.allclose(deg[o : o + nb], np.rad2deg(ref).astype(np.float32), rtol=3e-7, atol=1e-4)
+
+
 def test_convolution_sizes_three_times_a_power_of_two():
     """
     Bluestein over M = 3 * 2^k (radix-3 column stage) and the reduced size rule for single real signals (M >= L + L/2: the

@@ -15,9 +15,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--block", default="modal")
 ap.add_argument("--batch", type=int, default=64); ap.add_argument("--seconds", type=float, default=10.0)
 ap.add_argument("--iters", type=int, default=3)
+ap.add_argument("--no-fused-split", action="store_true")
 a = ap.parse_args()
 eng = Engine("cuda:0")
 eng.num_lanes = 1
+eng.fuse_half_split = not a.no_fused_split
 n = int(a.seconds * 48000)
 host = np.stack([synth_ir(i, 0, n) for i in range(a.batch)])
 b = eng.wrap(eng.to_dev(host.reshape(-1)), np.arange(a.batch, dtype=np.int64) * n, np.full(a.batch, n, np.int64))
@@ -33,6 +35,7 @@ run = {
     "zplane": lambda: zplane.zplane_device(eng, b, 48000, s.zplane),
     "gd": lambda: group_delay.group_delay_device(eng, b, 48000, s.group_delay),
     "diffusion": lambda: diffusion.diffusion_device(eng, b, 48000, s.diffusion),
+    "peak": lambda: (setattr(b, "peak", None), eng.peaks_begin(b), eng.peaks(b)),
 }[a.block]
 for _ in range(2):
     run()
