@@ -528,19 +528,26 @@ __global__ __launch_bounds__(TL5) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // frames per CU bring EIGHT waves per SIMD -- and the radix-8 decomposition makes the first digit of the output index the
 // WAVE number, which turns two of the three exchanges into wave-private transposes without any workgroup barrier:
 //   n = 512 n1 + 64 n2 + 8 n3 + n4,  k = k1 + 8 k2 + 64 k3 + 512 k4
-//   step 1  wave n2, lane 8 n4 + n3: 8-point DFT over n1 of the windowed packed samples, twiddle W_M^(k1 m), m = 64 n2 + 8 n3 + n4
+//   step 1  wave n2, lane 8 n3 + n4 (m = 64 n2 + lane: contiguous loads): 8-point DFT over n1 of the windowed packed samples,
+//           twiddle W_M^(k1 m)
 //   E1      the only cross-wave exchange, half the frame at a time: rows k1 of 256 complex; wave k1 reads the n2 = 0..3
 //           then 4..7 entries of ITS row, lane-linear both ways (conflict free)                        -- 4 barriers
-//   step 2  wave k1, lane 8 n4 + n3: DFT over n2, twiddle W_512^(k2 m'), m' = 8 n3 + n4
-//   E2      wave-private 8 x 8 transpose (k2 <-> n3) through the wave's own 4.6 KB, real then imaginary parts: lane stride 9
-//           doubles for the writes, 8 n3 + ... gathers for the reads, both bank-conflict free            -- no barrier
-//   step 3  wave k1, lane 8 n4 + k2: DFT over n3, twiddle W_64^(k3 n4)
-//   E3      wave-private transpose (k3 <-> n4): rows k3 of 72 doubles                                    -- no barrier
-//   step 4  wave k1, lane 8 k3 + k2: DFT over n4 -> the lane holds Z[r + 512 k4], r = k1 + 8 k2 + 64 k3
+//   step 2  wave k1, lane m' = 8 n3 + n4: DFT over n2, twiddle W_512^(k2 m')
+//   E2      wave-private 8 x 8 transpose (k2 <-> n3) through the wave's own 4.6 KB, real then imaginary parts: rows k2 of
+//           72 doubles; reader lane 8 k2 + n4 gathers n3 = 0..7; both ways bank-conflict free            -- no barrier
+//   step 3  wave k1, lane 8 k2 + n4: DFT over n3, twiddle W_64^(k3 n4)
+//   E3      wave-private transpose (k3 <-> n4): lane stride 9 doubles; reader lane 8 k2 + k3             -- no barrier
+//   step 4  wave k1, lane 8 k2 + k3: DFT over n4 -> the lane holds Z[r + 512 k4], r = k1 + 8 k2 + 64 k3
 //   mirror  as v5: every lane publishes its upper four values at its own (wave, lane) slot; the partner of r is
 //           wave 8 - k1, lane 63 - lane (wave 0: a permutation of its own lanes)                       -- 3 barriers
 //   post    as v5 (dB, or linear magnitudes -> log-bin means)
 // LDS per frame: 36 864 B of exchange + the 2 KB log table: four frames per CU.
+// MEASURED (round 4, 256 x 10 s, modal cloud; profiles/r04_stft8_ab.txt): correct (every modal / waterfall golden), 64 registers
+// + 17 spilled, and SLOWER -- 5.80 ms against v5's 4.32 ms.  The instruction budget says why (tools/isa_budget.py): per FRAME
+// 8 x 1509 = 12.1 k VALU instructions against v5's 4 x 2508 = 10.0 k (three twiddle stages of eight lanes' worth of powers
+// instead of two, address arithmetic and exec-mask bookkeeping per lane on twice the lanes), and v5 already keeps the
+// float64 pipes 70 % busy: occupancy cannot buy back 20 % more instructions.  Kept as the A/B (IRA_STFT_V8, tuning build);
+// the product runs v5.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int TL8 = 512;
 constexpr int REG8 = 576;                      // doubles of one wave's transpose region: 64 lanes x 9 = 8 rows x 72
@@ -575,10 +582,10 @@ __global__ __launch_bounds__(TL8) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #pragma unroll
   for (int i = 0; i < 4; ++i) wuni[i] = tw[TL8 * i];
 
-  // ---- step 1: lane (n4 = lane >> 3, n3 = lane & 7) of wave n2 transforms m = 64 n2 + 8 n3 + n4 ------------------------------
+  // ---- step 1: lane (n3 = lane >> 3, n4 = lane & 7) of wave n2 transforms m = 64 n2 + lane (contiguous loads) --------------------
   cdd v[8];
   {
-    const int m = wave * 64 + (lane & 7) * 8 + (lane >> 3);
+    const int m = q;
     float2 xs[8];
     double2 ws[8];
 #pragma unroll
@@ -614,49 +621,51 @@ __global__ __launch_bounds__(TL8) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   for (int n2 = 0; n2 < 4; ++n2) b[4 + n2] = ex[wave * 256 + n2 * 64 + lane];
   __syncthreads();                                               // E1 fully read: the wave regions below overlap it
 
-  // ---- step 2 (wave = k1, lane = 8 n4 + n3) and the wave-private transpose k2 <-> n3 ----------------------------------------------
+  // ---- step 2 (wave = k1, lane = m' = 8 n3 + n4) and the wave-private transpose k2 <-> n3 -------------------------------------
   double* reg = exd + wave * REG8;
   dft_dif<double, 8>(b);
-  ira::twiddle8<double, true>(b, tw[16 * ((lane & 7) * 8 + (lane >> 3))]);      // W_512^(k2 m') = W_N^(16 m' k2)
+  ira::twiddle8<double, true>(b, tw[16 * lane]);                 // W_512^(k2 m') = W_N^(16 m' k2)
   cdd c[8];
   {
-    const int rd = (lane >> 3) * 72 + (lane & 7);               // (8 n4 + n3) * 9 + k2 with n4 = lane >> 3, k2 = lane & 7, n3 = 0
+    // rows k2 of 72 doubles, column = producer lane 8 n3 + n4; reader lane 8 k2 + n4 gathers n3 = 0..7
+    const int rd = (lane >> 3) * 72 + (lane & 7);
 #pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) reg[lane * 9 + k2] = b[brev_bits(k2, 3)].re;
+    for (int k2 = 0; k2 < 8; ++k2) reg[k2 * 72 + lane] = b[brev_bits(k2, 3)].re;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int n3 = 0; n3 < 8; ++n3) c[n3].re = reg[rd + n3 * 9];
+    for (int n3 = 0; n3 < 8; ++n3) c[n3].re = reg[rd + n3 * 8];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) reg[lane * 9 + k2] = b[brev_bits(k2, 3)].im;
+    for (int k2 = 0; k2 < 8; ++k2) reg[k2 * 72 + lane] = b[brev_bits(k2, 3)].im;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int n3 = 0; n3 < 8; ++n3) c[n3].im = reg[rd + n3 * 9];
+    for (int n3 = 0; n3 < 8; ++n3) c[n3].im = reg[rd + n3 * 8];
     __builtin_amdgcn_wave_barrier();
   }
 
-  // ---- step 3 (lane = 8 n4 + k2) and the wave-private transpose k3 <-> n4 ---------------------------------------------------
+  // ---- step 3 (lane = 8 k2 + n4) and the wave-private transpose k3 <-> n4 ---------------------------------------------------
   dft_dif<double, 8>(c);
-  ira::twiddle8<double, true>(c, tw[128 * (lane >> 3)]);        // W_64^(k3 n4) = W_N^(128 n4 k3)
+  ira::twiddle8<double, true>(c, tw[128 * (lane & 7)]);         // W_64^(k3 n4) = W_N^(128 n4 k3)
   cdd d[8];
   {
-    const int rd = (lane >> 3) * 72 + (lane & 7);               // row k3 = lane >> 3, column 8 n4 + k2 with k2 = lane & 7, n4 = 0
+    // producer lane 8 k2 + n4 writes its eight k3 values 9 doubles apart; reader lane 8 k2 + k3 gathers n4 = 0..7
+    const int rd = (lane >> 3) * 72 + (lane & 7);               // (8 k2 + n4) * 9 + k3 at n4 = 0
 #pragma unroll
-    for (int k3 = 0; k3 < 8; ++k3) reg[k3 * 72 + lane] = c[brev_bits(k3, 3)].re;
+    for (int k3 = 0; k3 < 8; ++k3) reg[lane * 9 + k3] = c[brev_bits(k3, 3)].re;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int n4 = 0; n4 < 8; ++n4) d[n4].re = reg[rd + n4 * 8];
+    for (int n4 = 0; n4 < 8; ++n4) d[n4].re = reg[rd + n4 * 9];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int k3 = 0; k3 < 8; ++k3) reg[k3 * 72 + lane] = c[brev_bits(k3, 3)].im;
+    for (int k3 = 0; k3 < 8; ++k3) reg[lane * 9 + k3] = c[brev_bits(k3, 3)].im;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int n4 = 0; n4 < 8; ++n4) d[n4].im = reg[rd + n4 * 8];
+    for (int n4 = 0; n4 < 8; ++n4) d[n4].im = reg[rd + n4 * 9];
   }
 
-  // ---- step 4: lane (k3 = lane >> 3, k2 = lane & 7) of wave k1 holds Z[r + 512 k4] at d[brev3(k4)] --------------------------------
+  // ---- step 4: lane (k2 = lane >> 3, k3 = lane & 7) of wave k1 holds Z[r + 512 k4] at d[brev3(k4)] --------------------------------
   dft_dif<double, 8>(d);
-  const int r = wave + 8 * (lane & 7) + 64 * (lane >> 3);
+  const int r = wave + 8 * (lane >> 3) + 64 * (lane & 7);
 
   // ---- mirror exchange: the upper four values of every lane at its own slot; partner of r = (512 - r) mod 512 -------------------
   __syncthreads();                                               // every wave has left its transpose region
@@ -669,8 +678,8 @@ __global__ __launch_bounds__(TL8) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     if (wave > 0) {
       pos = (8 - wave) * 64 + (63 - lane);
     } else {
-      const int k2 = lane & 7, k3 = lane >> 3;
-      pos = k2 > 0 ? (7 - k3) * 8 + (8 - k2) : ((8 - k3) & 7) * 8;
+      const int k2 = lane >> 3, k3 = lane & 7;
+      pos = k2 > 0 ? (8 - k2) * 8 + (7 - k3) : ((8 - k3) & 7);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -774,14 +783,14 @@ int32_t ira_stft4_dispatch_tf(const float* x, const int64_t* off, const int32_t*
     stft4_kernel<<<grid, TL4, 0, st>>>(x, off, nframes, hop, static_cast<const double*>(window),
                                        static_cast<const cdd*>(tw), floor_lin, (float)floor_db, out, out_off, frame_sel,
                                        sel_off, 0, 0, nullptr, nullptr);
-  else if (ira_tune_flag("IRA_STFT_V5"))
-    stft5_kernel<<<grid, TL5, 0, st>>>(x, off, nframes, hop, static_cast<const double*>(window),
-                                       static_cast<const cdd*>(tw), floor_lin, (float)floor_db, out, out_off, frame_sel,
-                                       sel_off, 0, 0, nullptr, nullptr, ira_tune_int("IRA_STFT5_ABLATE", 0));
-  else
+  else if (ira_tune_flag("IRA_STFT_V8"))                     // A/B (tuning build): one frame on eight waves, see stft8_kernel
     stft8_kernel<<<grid, TL8, 0, st>>>(x, off, nframes, hop, static_cast<const double*>(window),
                                        static_cast<const cdd*>(tw), floor_lin, (float)floor_db, out, out_off, frame_sel,
                                        sel_off, 0, 0, nullptr, nullptr);
+  else
+    stft5_kernel<<<grid, TL5, 0, st>>>(x, off, nframes, hop, static_cast<const double*>(window),
+                                       static_cast<const cdd*>(tw), floor_lin, (float)floor_db, out, out_off, frame_sel,
+                                       sel_off, 0, 0, nullptr, nullptr, ira_tune_int("IRA_STFT5_ABLATE", 0));
   IRA_RETURN_LAUNCH();
 }
 
@@ -798,13 +807,13 @@ int32_t ira_stft4_dispatch_logbin(const float* x, const int64_t* off, const int3
     stft4_kernel<<<grid, TL4, 0, st>>>(x, off, nframes, hop, static_cast<const double*>(window),
                                        static_cast<const cdd*>(tw), floor_lin, (float)floor_db, curves, curves_off,
                                        nullptr, nullptr, nbins, k_base, first, count);
-  else if (ira_tune_flag("IRA_STFT_V5"))
-    stft5_kernel<<<grid, TL5, 0, st>>>(x, off, nframes, hop, static_cast<const double*>(window),
-                                       static_cast<const cdd*>(tw), floor_lin, (float)floor_db, curves, curves_off,
-                                       nullptr, nullptr, nbins, k_base, first, count, ira_tune_int("IRA_STFT5_ABLATE", 0));
-  else
+  else if (ira_tune_flag("IRA_STFT_V8"))
     stft8_kernel<<<grid, TL8, 0, st>>>(x, off, nframes, hop, static_cast<const double*>(window),
                                        static_cast<const cdd*>(tw), floor_lin, (float)floor_db, curves, curves_off,
                                        nullptr, nullptr, nbins, k_base, first, count);
+  else
+    stft5_kernel<<<grid, TL5, 0, st>>>(x, off, nframes, hop, static_cast<const double*>(window),
+                                       static_cast<const cdd*>(tw), floor_lin, (float)floor_db, curves, curves_off,
+                                       nullptr, nullptr, nbins, k_base, first, count, ira_tune_int("IRA_STFT5_ABLATE", 0));
   IRA_RETURN_LAUNCH();
 }
