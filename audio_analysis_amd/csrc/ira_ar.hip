@@ -577,6 +577,146 @@ __global__ __launch_bounds__(SV_THREADS) void ar_solve_kernel(const double* __re
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// The same solve for p <= 64 on ONE WAVE per element (round 4).  ar_solve_kernel spends its time at workgroup barriers: the
+// factorisation and its six triangular sweeps (the solve and two inverse iterations for the condition estimate) are ~1000
+// barriers of a 256-thread workgroup for 87 k multiply-adds -- 0.25 ms per 256 elements at 2-18 % VALU activity.  Here lane i
+// owns row i of G in the wave's own LDS (row stride 65 doubles: a column walk touches every bank pair once), the right-hand
+// side lives one value per lane in a register, and nothing waits for another wave:
+//   * Cholesky LEFT-looking: column k of L is G[i][k] - sum_{m<k} L[i][m] L[k][m] for every lane i >= k at once -- the m loop
+//     only READS (own row, and row k as a broadcast), so its loads pipeline; one write per lane and column.  The running
+//     subtraction visits m in increasing order, exactly the order in which the right-looking kernel applies its rank-one
+//     updates to that entry: the factor is the same, bit for bit.
+//   * triangular sweeps: the pivot lane's value crosses the wave with v_readlane; the division by the diagonal, the
+//     multiply-subtract and the sequential norm sums are the workgroup kernel's own operations in its own order.
+// Same inputs, outputs, status codes and info record as ar_solve_kernel in lag mode (first solve and refinement mode).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int SW_LD = 65;
+
+__device__ __forceinline__ double wave_bcast(double v, int src_lane) {       // src_lane wave-uniform
+  int w[2];
+  __builtin_memcpy(w, &v, 8);
+  w[0] = __builtin_amdgcn_readlane(w[0], src_lane);
+  w[1] = __builtin_amdgcn_readlane(w[1], src_lane);
+  __builtin_memcpy(&v, w, 8);
+  return v;
+}
+
+// L y = r, then L^T a = y, on the lane-resident vector (lane j holds entry j)
+__device__ __forceinline__ double wave_chol_solve(const double* G, double vec, int p, int lane) {
+  for (int k = 0; k < p; ++k) {
+    const double yk = wave_bcast(vec, k) / G[k * SW_LD + k];
+    const double lik = G[(lane < p ? lane : 0) * SW_LD + k];
+    if (lane == k) vec = yk;
+    else if (lane > k && lane < p) vec -= lik * yk;
+  }
+  for (int k = p - 1; k >= 0; --k) {
+    const double ak = wave_bcast(vec, k) / G[k * SW_LD + k];
+    const double lki = G[k * SW_LD + (lane < p ? lane : 0)];
+    if (lane == k) vec = ak;
+    else if (lane < k) vec -= lki * ak;
+  }
+  return vec;
+}
+
+__global__ __launch_bounds__(64) void ar_solve_wave_kernel(const double* __restrict__ part, const int32_t* __restrict__ nlen,
+                                                           int p, double ridge, double* __restrict__ coeffs,
+                                                           double* __restrict__ info, int lag_nchunks_max,
+                                                           long long lag_rec_doubles, const double* __restrict__ gpart,
+                                                           double cond_threshold) {
+  __shared__ double G[64 * SW_LD];
+  __shared__ double rhs[64];
+  const int e = blockIdx.x, lane = threadIdx.x;
+  if (gpart != nullptr && !ar_needs_refinement(info, e, cond_threshold)) return;
+  const long long N = nlen[e];
+  const int nlag = p + 1;
+  const double* rec = part + (long long)e * lag_rec_doubles;
+  const double* head = rec + (long long)lag_nchunks_max * nlag;
+  const double* tail = head + nlag;
+  const int lchunks = lag_chunks(N, p);
+  // ---- G (lower triangle) and r from the lag sums and the head / tail samples: lane d walks diagonal d, as ar_solve_kernel ----
+  for (int d = lane; d < nlag; d += 64) {
+    double c = 0.0;
+    for (int ch = 0; ch < lchunks; ++ch) c += rec[(long long)ch * nlag + d];
+    if (d >= 1) rhs[d - 1] = -c;
+    double run = c, comp = 0.0;
+    for (int a = 1; a + d <= p; ++a) {
+      const int m = a - 1;
+      const double t1 = head[p - 1 - m] * head[p - 1 - m - d];
+      const double t2 = -tail[m] * tail[m + d];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const double term = q == 0 ? t1 : t2;
+        const double t = run + term;
+        comp += (fabs(run) >= fabs(term)) ? (run - t) + term : (term - t) + run;
+        run = t;
+      }
+      double v = run + comp;
+      if (d == 0) v += ridge;
+      G[(a + d - 1) * SW_LD + (a - 1)] = v;                      // G[r][c], r >= c
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  double vec = lane < p ? rhs[lane] : 0.0;
+  if (gpart != nullptr) {
+    const double* ge = gpart + (long long)e * lag_nchunks_max * (p + 1);
+    double c = 0.0;
+    if (lane < p)
+      for (int ch = 0; ch < lchunks; ++ch) c += ge[(long long)ch * (p + 1) + lane + 1];
+    vec = c;
+  }
+  double trace = 0.0;
+  for (int k = 0; k < p; ++k) trace += G[k * SW_LD + k];
+  // ---- Cholesky, left-looking ----------------------------------------------------------------------------------------------
+  int fail = 0;
+  double dmax = 0.0, dmin = INFINITY;
+  const int row = (lane < p ? lane : 0) * SW_LD;
+  for (int k = 0; k < p; ++k) {
+    double s = G[row + k];
+    const double* rk = G + k * SW_LD;
+    const double* ri = G + row;
+#pragma unroll 8
+    for (int m = 0; m < k; ++m) s -= ri[m] * rk[m];
+    const double dkk = wave_bcast(s, k);
+    double piv;
+    if (!(dkk > 0.0)) { fail = 1; piv = 1.0; }
+    else piv = sqrt(dkk);
+    dmax = fmax(dmax, piv); dmin = fmin(dmin, piv);
+    if (lane >= k && lane < p) G[row + k] = (lane == k) ? piv : s / piv;
+    __builtin_amdgcn_wave_barrier();
+  }
+  vec = wave_chol_solve(G, vec, p, lane);
+  double* co = coeffs + (long long)e * (p + 1);
+  if (gpart != nullptr) {
+    if (!fail && lane < p) co[lane + 1] += vec;
+    if (lane == 0 && !fail) info[IRA_AR_INFO_DOUBLES * e + 0] = 2.0;  // refined
+    return;
+  }
+  if (lane == 0) co[0] = 1.0;
+  if (lane < p) co[lane + 1] = vec;
+  if (info == nullptr) return;
+  double cond_est = INFINITY;
+  if (!fail) {
+    vec = lane < p ? ((lane & 1) ? -1.0 : 1.0) : 0.0;
+    for (int it = 0; it < 2; ++it) {
+      double q = 0.0;
+      for (int j = 0; j < p; ++j) { const double vj = wave_bcast(vec, j); q += vj * vj; }
+      const double inv = 1.0 / sqrt(q);
+      vec *= inv;
+      vec = wave_chol_solve(G, vec, p, lane);
+    }
+    double q = 0.0;
+    for (int j = 0; j < p; ++j) { const double vj = wave_bcast(vec, j); q += vj * vj; }
+    cond_est = trace * sqrt(q);
+  }
+  if (lane == 0) {
+    info[IRA_AR_INFO_DOUBLES * e + 0] = (double)fail;
+    info[IRA_AR_INFO_DOUBLES * e + 1] = dmax;
+    info[IRA_AR_INFO_DOUBLES * e + 2] = dmin;
+    info[IRA_AR_INFO_DOUBLES * e + 3] = cond_est;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Ill-conditioned fits: the normal equations in DOUBLE-DOUBLE arithmetic (~32 significant digits).
 // The reference solves min ||A a + y|| by SVD (numpy.linalg.lstsq, zplane.py:117), accurate to ~cond(A) eps.  float64 normal
 // equations lose cond(A)^2 eps: the corrected-semi-normal-equation steps of ira_ar_refine recover lstsq's accuracy while
@@ -1098,6 +1238,10 @@ extern "C" int64_t ira_ar_partial_doubles(int32_t p, int32_t max_len) {
 // flags & IRA_AR_DENSE_GRAM selects the dense MFMA Gram (cross-check / A-B); gram, solve and refine of one fit must be given
 // the same flags: they agree on the layout of the partial record through it.
 static inline bool ar_dense(int32_t flags) { return (flags & IRA_AR_DENSE_GRAM) != 0; }
+// one wave per element (ar_solve_wave_kernel): lag-sum record, order <= 64, unless the caller asks for the workgroup kernel
+static inline bool ar_wave_solve(int32_t flags, int order) {
+  return !ar_dense(flags) && order <= 64 && (flags & IRA_AR_WORKGROUP_SOLVE) == 0;
+}
 
 static int32_t ar_check(int32_t nb, int32_t max_len, int32_t order) {
   if (nb < 0) return IRA_E_SIZE;
@@ -1164,6 +1308,12 @@ extern "C" int32_t ira_ar_solve(const double* partial_dev, const int32_t* len_de
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ar_solve_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return ira_hip_status(e);
+  }
+  if (ar_wave_solve(flags, order)) {
+    ar_solve_wave_kernel<<<nb, 64, 0, (hipStream_t)stream>>>(partial_dev, len_dev, order, ridge, coeffs_dev, info_dev,
+                                                              lag_chunks(max_len, order), lag_record_doubles(max_len, order),
+                                                              nullptr, 0.0);
+    IRA_RETURN_LAUNCH();
   }
   ar_solve_kernel<<<nb, SV_THREADS, lds, (hipStream_t)stream>>>(partial_dev, len_dev, order, nchunks, ridge,
                                                                  gscratch_dev, coeffs_dev, info_dev,
@@ -1249,9 +1399,13 @@ extern "C" int32_t ira_ar_refine(const float* x_dev, const double* x64_dev, cons
     ar_grad_kernel<<<dim3(lchunks, 1, nb), LAG_THREADS, lds_g, st>>>(x64_dev ? nullptr : x_dev, x64_dev, xoff_dev, len_dev,
                                                                       divisor_dev, order, lchunks, coeffs_dev, info_dev,
                                                                       cond_threshold, grad_dev);
-    ar_solve_kernel<<<nb, SV_THREADS, lds_s, st>>>(partial_dev, len_dev, order, nchunks, 0.0, gscratch_dev, coeffs_dev,
-                                                    info_dev, ar_dense(flags) ? 0 : 1, lchunks,
-                                                    lag_record_doubles(max_len, order), grad_dev, cond_threshold);
+    if (ar_wave_solve(flags, order))
+      ar_solve_wave_kernel<<<nb, 64, 0, st>>>(partial_dev, len_dev, order, 0.0, coeffs_dev, info_dev, lchunks,
+                                              lag_record_doubles(max_len, order), grad_dev, cond_threshold);
+    else
+      ar_solve_kernel<<<nb, SV_THREADS, lds_s, st>>>(partial_dev, len_dev, order, nchunks, 0.0, gscratch_dev, coeffs_dev,
+                                                      info_dev, ar_dense(flags) ? 0 : 1, lchunks,
+                                                      lag_record_doubles(max_len, order), grad_dev, cond_threshold);
   }
   IRA_RETURN_LAUNCH();
 }

@@ -1194,7 +1194,7 @@ class Engine:
         info = self.empty(n * 4, t.float64)
         d_xo, d_l, d_div = self.to_dev_pack(np.ascontiguousarray(xoff, np.int64), lengths,
                                             np.ascontiguousarray(divisor, np.float64) if divisor is not None else None)
-        flags = 1 if self.ar_dense_gram else 0                 # IRA_AR_DENSE_GRAM
+        flags = (1 if self.ar_dense_gram else 0) | (2 if self.ar_workgroup_solve else 0)   # IRA_AR_DENSE_GRAM | IRA_AR_WORKGROUP_SOLVE
         check(self.lib.ira_ar_gram(0 if x_is_f64 else _ptr(x_dev), _ptr(x_dev) if x_is_f64 else 0, _ptr(d_xo),
                                    _ptr(d_l), _ptr(d_div), n, max_len, int(order), _ptr(part), flags, self.stream),
               "ira_ar_gram")
@@ -1230,6 +1230,8 @@ class Engine:
     ar_minnorm_cut = 1e-12
     # A/B: form the Gram matrix as a dense contraction on the FP64 matrix cores (IRA_AR_DENSE_GRAM) instead of the lag sums
     ar_dense_gram = False
+    # A/B: the 256-thread solve kernel also for order <= 64 (default there since round 4: one wave per element, same bits)
+    ar_workgroup_solve = False
     ar_refine_cond = 1e9          # on the estimate trace(G) ||G^-1|| (<= order * cond(G))
     ar_refine_steps = 2
     # Above this estimate (or when the float64 Cholesky breaks down) the normal equations are solved again in double-double

@@ -304,6 +304,8 @@ int32_t ira_log_smooth_db(float* mag_dev, const int64_t* off_dev, const int32_t*
 #define IRA_AR_DENSE_GRAM 1   /* flags: form G = A^T A as a dense contraction on the FP64 matrix cores (v_mfma_f64_16x16x4_f64)
                                * instead of the O(order * len) lag-sum form: the cross-check of the default path.  gram, solve
                                * and refine of one fit take the same flags (layout of partial_dev). */
+#define IRA_AR_WORKGROUP_SOLVE 2   /* flags (ira_ar_solve / ira_ar_refine): the 256-thread solve kernel also for order <= 64, where one wave
+                                    * per element is the default since round 4 (A/B and cross-check: both give the same bits) */
 int64_t ira_ar_partial_doubles(int32_t order, int32_t max_len);
 /* The two halves of ira_ar_fit, callable separately: the MFMA Gram contraction, and reduce + Cholesky solve. */
 int32_t ira_ar_gram(const float* x_dev, const double* x64_dev, const int64_t* xoff_dev,

@@ -272,6 +272,40 @@ def test_singular_gram_flagged_by_its_condition_estimate_gets_the_minimum_norm_s
     assert list(info[:, 0]) == [4.0, 4.0, 4.0], info[:, 0]
 
 
+def test_one_wave_solver_gives_the_workgroup_solvers_bits():
+    """Round 4: for order <= 64 the normal equations are factored and solved by ONE WAVE per element (left-looking Cholesky in
+    the wave's own LDS, the right-hand side one value per lane) instead of a 256-thread workgroup that spends its time at
+    ~1000 barriers.  Same operations in the same order: coefficients, status and the info record (pivots, condition estimate)
+    are IDENTICAL to the workgroup kernel's (flags = IRA_AR_WORKGROUP_SOLVE), for well-conditioned, refined (cond(G) ~ 1e10),
+    double-double and rank-deficient channels in one batch, at orders 1, 8, 33 and 64."""
+    from audio_analysis_amd.engine import get_engine
+    from audio_analysis_amd.synth import synth_ir
+    eng = get_engine()
+    n = 20000
+    rng = np.random.default_rng(8)
+    chans = [synth_ir(40 + i, 0, n, rt60_seconds=0.1, pre_delay=0) for i in range(3)]
+    chans.append(synth_ir(50, 0, n, rt60_seconds=0.2, pre_delay=0, lowpass_pole=0.97))        # refinement range
+    chans.append(synth_ir(51, 0, n, rt60_seconds=0.2, pre_delay=0, lowpass_pole=0.995))       # double-double range
+    chans.append(np.full(n, 0.25, np.float32))                                                # rank 1
+    chans.append(np.tile(rng.standard_normal(6).astype(np.float32), n // 6 + 1)[:n].copy())   # rank <= 6
+    b = eng.upload(chans)
+    try:
+        for order in (1, 8, 33, 64):
+            out = {}
+            for wg in (False, True):
+                eng.ar_workgroup_solve = wg
+                co, info = eng.ar_fit(b.x, b.off, b.length.astype(np.int32), None, order)
+                out[wg] = (co.cpu().numpy().copy(), info.cpu().numpy().copy())
+            assert np.array_equal(out[False][1], out[True][1], equal_nan=True), (order, out[False][1], out[True][1])
+            assert np.array_equal(out[False][0], out[True][0], equal_nan=True), order
+            st = out[False][1][:, 0]
+            assert set(st[:3]) <= {0.0}, (order, st)
+            if order >= 8:
+                assert st[5] == 4.0 and st[6] == 4.0, (order, st)             # the constant and the period-6 signal: rank deficient
+    finally:
+        eng.ar_workgroup_solve = False
+
+
 def _match_poles(got, ref):
     """Greedy nearest-neighbour matching of two pole sets (numpy.roots' order is unspecified): max |got - ref| over pairs."""
     got = list(got)
