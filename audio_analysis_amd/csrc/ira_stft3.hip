@@ -361,7 +361,7 @@ __global__ __launch_bounds__(64 * NT) void stft6_kernel(
     const float* __restrict__ x, const int64_t* __restrict__ off, const int32_t* __restrict__ nframes, int hop,
     const float* __restrict__ window, const cf* __restrict__ tw, float floor_lin, float floor_db,
     float* __restrict__ out, const int64_t* __restrict__ out_off, const int32_t* __restrict__ frame_sel,
-    const int64_t* __restrict__ sel_off, unsigned gx, unsigned ntiles, unsigned win_lds_off, int stagger) {
+    const int64_t* __restrict__ sel_off, unsigned gx, unsigned ntiles, unsigned win_lds_off, int stagger, int resync) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
   const int team = __builtin_amdgcn_readfirstlane(tid >> 6), q0 = tid & 63;
@@ -404,6 +404,17 @@ __global__ __launch_bounds__(64 * NT) void stft6_kernel(
 
   const unsigned t_step = wg_per_xcd;
   unsigned t = xcd * per + lane_wg;
+  // resync > 0: the sixteen waves meet at a workgroup barrier every `resync` positions of the walk.  Free-running waves drift
+  // apart by several tiles, and then the frames in flight on an XCD (32 workgroups x 16 waves x 16 KB) no longer fit its
+  // 4 MB L2: every sample was fetched 3.9 times (profiles/r03_traffic_report.json).  Every wave executes the same NUMBER of
+  // barriers whatever tiles it skips (a wave past the last frame of a segment has nothing to do there).
+  const unsigned t_first = t;
+  const unsigned n_pos = t_end > t_first ? (t_end - t_first + t_step - 1u) / t_step : 0u;
+  unsigned syncs_done = 0;
+  auto sync_up_to = [&](unsigned pos) {                       // pos = positions of the walk this wave has left behind
+    if (resync <= 0) return;
+    for (const unsigned want = pos / (unsigned)resync; syncs_done < want; ++syncs_done) __syncthreads();
+  };
   const float* fx = x;
   float* fo = out;
   bool have = false;
@@ -587,9 +598,14 @@ __global__ __launch_bounds__(64 * NT) void stft6_kernel(
       if (AB & 4) { if (sacc + mid == 12345.678f) fo[q] = sacc; }
       else if (q == 0) fo[M3 / 2] = mid;
     }
+    sync_up_to(have_n ? (tn - t_first) / t_step : n_pos);
     t = tn; fx = fxn; fo = fon; have = have_n;
   }
+  sync_up_to(n_pos);
 }
+
+// measured (profiles/r04_stft6_resync.txt): 2 brings the fetch traffic from 3.7x the samples down to 1.08x at the same run time
+constexpr int IRA_STFT6_RESYNC_DEFAULT = 2;
 
 template <int NT, bool PF>
 int32_t launch6(const float* x, const int64_t* off, const int32_t* nframes, int32_t nseg, int32_t max_frames, int32_t hop,
@@ -617,7 +633,8 @@ int32_t launch6(const float* x, const int64_t* off, const int32_t* nframes, int3
     if (attr != hipSuccess) return ira_hip_status(attr);                                                                  \
     stft6_kernel<NT, PF, AB><<<grid, 64 * NT, lds, st>>>(x, off, nframes, hop, static_cast<const float*>(window),         \
                                               static_cast<const cf*>(tw), (float)floor_lin, (float)floor_db, out, out_off, \
-                                              frame_sel, sel_off, gx, (unsigned)tiles, (unsigned)lds_main, stagger);      \
+                                              frame_sel, sel_off, gx, (unsigned)tiles, (unsigned)lds_main, stagger,       \
+                                              ira_tune_int("IRA_STFT6_RESYNC", IRA_STFT6_RESYNC_DEFAULT));                \
   } while (0)
 #ifdef IRA_TUNING_BUILD
   switch (ira_tune_int("IRA_STFT6_ABLATE", 0)) {
