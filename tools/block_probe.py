@@ -33,7 +33,7 @@ run = {
     "spectrum": lambda: frequency_response.spectrum_device(eng, b, 48000, s.frequency_response, "spectrum", want_phase=True),
     "stft": lambda: spectrogram.spectrogram_device(eng, b, 48000, s.spectrogram, frame_major=True),
     "zplane": lambda: zplane.zplane_device(eng, b, 48000, s.zplane),
-    "gd": lambda: group_delay.group_delay_device(eng, b, 48000, s.group_delay),
+    "gd": lambda: group_delay.summary_statistics_device(eng, group_delay.group_delay_device(eng, b, 48000, s.group_delay), 48000, s.group_delay),
     "diffusion": lambda: diffusion.diffusion_device(eng, b, 48000, s.diffusion),
     "peak": lambda: (setattr(b, "peak", None), eng.peaks_begin(b), eng.peaks(b)),
 }[a.block]
