@@ -253,10 +253,6 @@ __device__ __forceinline__ Ctx job_ctx(const Jobs& J, int e) {
 struct RawL { double a, b, c, d; float fa, fb; };
 constexpr int FL_UI = 4;    // K1: fetches in flight per thread and batch (a fetch is up to four doubles)
 constexpr int FL_U = 8;     // K2 / K3: 16-byte loads in flight per thread and batch
-#ifndef IRA_FL_PREFETCH
-#define IRA_FL_PREFETCH 1
-#endif
-constexpr bool FL_PREFETCH = IRA_FL_PREFETCH != 0;   // K2: touch the filter tile before the forward row transform (A/B at build time)
 
 template <int MODE>
 __device__ __forceinline__ RawL fetch_input(const Jobs& J, const Ctx& c, long long n) {
@@ -493,16 +489,6 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   const unsigned total = N2 * (unsigned)R;
   cd* twl = lds + total;                                               // two-level twiddle table of the sub-FFT
   const cd twv = ira::tw_split_fetch<double>(g.t2, N2 >> 1, tid);
-  // The filter tile this workgroup multiplies with AFTER its forward row transform is requested NOW, one 4-byte touch per
-  // 128-byte line, in the same round trip as the work tile: the multiply's own loads then find their lines in L2 / L1 instead
-  // of waiting a whole HBM round trip between the two transforms (DESIGN 7.0 lever (c); holding the tile in registers
-  // instead costs 32 of the 125 VGPRs the four-waves-per-SIMD build has).
-  float touch = 0.0f;
-  if (MODE == ROW_CONV && FL_PREFETCH) {
-    const char* fb = reinterpret_cast<const char*>(J.bfilt + (long long)filt * M + (long long)r0 * N2);
-    const unsigned lines = total / 8u;                                 // 16-byte values per 128-byte line: 8
-    for (unsigned l = tid; l < lines; l += FL_THREADS) touch += *reinterpret_cast<const volatile float*>(fb + (size_t)l * 128u);
-  }
   for (unsigned base = 0; base < total; base += FL_THREADS * FL_U) {
     // All loads of the batch in flight together.  Index clamped, and the LDS store NOT guarded (a lane past the end stores
     // the last element's own value onto itself): behind an `if (i < total)` the compiler sinks each load into its store's
@@ -522,7 +508,6 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   ira::tw_split_put(twl, twv, tid);
   __syncthreads();
   if (!(IRA_ABL(g.ablate & 8))) ira::lds_fft_dif<double, FL_LR, true>(lds, g.log2n2, twl, 1u, tid, FL_THREADS, R, N2);
-  if (MODE == ROW_CONV && FL_PREFETCH) asm volatile("" :: "v"(touch));   // the touches must have been issued, nothing more
   if (MODE == ROW_CONV) {
     const cd* b = J.bfilt + (long long)filt * M + (long long)r0 * N2;
     if (!(IRA_ABL(g.ablate & 16)))
