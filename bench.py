@@ -109,6 +109,17 @@ def _cpu_one(args):
         if "zplane" in blocks:
             z = O.analyse_zplane(x, ar_order=64)
             v["ar_max_radius"], v["ar_median_radius"], v["ar_unstable"] = z["max_radius"], z["median_radius"], z["unstable"]
+        if "groupdelay" in blocks:
+            g = O.analyse_group_delay(x)["gd"]
+            if g.size:
+                v["gd_median"], v["gd_p10"], v["gd_p90"] = (float(np.median(g)), float(np.percentile(g, 10)),
+                                                            float(np.percentile(g, 90)))
+        if "diffusion" in blocks:
+            import warnings
+            d = O.analyse_diffusion(x, hop_seconds=0.05, max_lag_milliseconds=5.0)      # pipeline.FullReportSettings.diffusion
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", category=RuntimeWarning)
+                v["diff_ac_median"], v["diff_ed_median"] = float(np.nanmedian(d["ac"])), float(np.nanmedian(d["ed"]))
         out.append(v)
     return time.perf_counter() - t0, out, specs
 
@@ -199,7 +210,10 @@ def parity_report(records, oracle_values, nbands: int):
            "t30_rt60_s": ("t30_rt60", P.M_FIT_T30 + 6), "fr_centroid_hz": ("fr_centroid_hz", P.M_FR_CENTROID),
            "modal_median_rt60_s": ("modal_median", P.M_MODAL_MEDIAN), "modal_p90_rt60_s": ("modal_p90", P.M_MODAL_P90),
            "modal_max_rt60_s": ("modal_max", P.M_MODAL_MAX), "ar_max_radius": ("ar_max_radius", P.M_AR_MAX_R),
-           "ar_median_radius": ("ar_median_radius", P.M_AR_MEDIAN_R)}
+           "ar_median_radius": ("ar_median_radius", P.M_AR_MEDIAN_R), "group_delay_median": ("gd_median", P.M_GD_MEDIAN),
+           "group_delay_p10": ("gd_p10", P.M_GD_P10), "group_delay_p90": ("gd_p90", P.M_GD_P90),
+           "diffusion_autocorr_median": ("diff_ac_median", P.M_DIFF_AC_MEDIAN),
+           "diffusion_echo_density_median": ("diff_ed_median", P.M_DIFF_ED_MEDIAN)}
     exact = {"start_index": ("start", P.M_START), "fr_peak_hz": ("fr_peak_hz", P.M_FR_PEAK),
              "filter_peak_hz": ("filter_peak_hz", P.M_FILT_PEAK), "spectrogram_frames": ("spec_frames", P.M_SPEC_FRAMES),
              "waterfall_slices": ("wf_slices", P.M_WF_SLICES), "waterfall_bins": ("wf_bins", P.M_WF_BINS),
@@ -277,6 +291,11 @@ def config_table():
         "report": dict(settings=full, batch=256, seconds=10.0, steps=20, cpu_s=1.3,
                        metric="IRs/sec full report (STFT+RT60bands+zplane), 48 kHz 10 s IR",
                        what="metrics-only full report", excluded=["png rendering", "group delay", "diffusion", "ir plots"]),
+        # the reference's literal default `report` (group delay + diffusion on top of the metric's blocks): a profiling target
+        # (tools/profile_config.sh literal); the default run reports it as `literal_full_report`
+        "literal": dict(settings=replace(full, run_group_delay=True, run_diffusion=True), batch=256, seconds=10.0, steps=10,
+                        cpu_s=1.3, metric="IRs/sec literal default report (metric blocks + group delay + diffusion), 48 kHz 10 s IR",
+                        what="metrics-only literal default report", excluded=["png rendering", "ir plots"]),
         "2": dict(settings=replace(none, run_decay=True, run_spectrogram=True), batch=256, seconds=2.0, steps=20, cpu_s=0.03,
                   metric="IRs/sec STFT spectrogram + Schroeder decay, 48 kHz 2 s IR (BASELINE config 2)",
                   what="spectrogram STFT 4096/512 + Schroeder decay (EDT/T20/T30)", excluded=["png rendering"]),
@@ -303,7 +322,8 @@ def block_names(settings):
     out = []
     for flag, name in (("run_decay", "decay"), ("run_rt60_bands", "rt60bands"), ("run_frequency_response", "fr"),
                        ("run_filter", "filter"), ("run_spectrogram", "spectrogram"), ("run_waterfall", "waterfall"),
-                       ("run_modal_cloud", "modalcloud"), ("run_zplane", "zplane")):
+                       ("run_modal_cloud", "modalcloud"), ("run_zplane", "zplane"), ("run_group_delay", "groupdelay"),
+                       ("run_diffusion", "diffusion")):
         if getattr(settings, flag):
             out.append(name)
     return out
@@ -479,7 +499,7 @@ def make_roof(ev, roof_steps, settings, L, n, nchan, traffic_tab):
 def load_traffic(cfg: str):
     """Per-call HBM traffic from the PMC passes committed under profiles/ (tools/profile_config.sh + traffic_profile.py;
     MI355X_MICROARCH.md's 2 x FETCH_SIZE + WRITE_SIZE rule): the newest round's table for this configuration."""
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         try:
             return json.load(open(os.path.join(REPO, "profiles", f"{rnd}_traffic_{cfg}.json")))["calls"]
         except Exception:
@@ -680,7 +700,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="report", choices=["report", "2", "3", "4", "5"])
+    ap.add_argument("--config", default="report", choices=["report", "literal", "2", "3", "4", "5"])
     ap.add_argument("--batch", type=int, default=None, help="IRs (config 5: stereo taps) per GPU per step")
     ap.add_argument("--seconds", type=float, default=None, help="IR length")
     ap.add_argument("--host-batches", type=int, default=4, help="distinct batches rotating in pinned host memory")
@@ -910,7 +930,7 @@ def main():
 
     # ---- second, shorter measurement: the LITERAL default report (group delay + diffusion blocks added) ------------------
     literal = None
-    if a.config == "report" and a.literal_steps > 0:
+    if a.config == "report" and a.literal_steps > 0 and a.variants == "all":
         from dataclasses import replace as _replace
         rep2 = FullReport(eng, _replace(settings, run_group_delay=True, run_diffusion=True))
         run_fed(max(2, K), host_f32, rep2)            # plan pass: every rotating batch once (its lengths' plan data), untimed

@@ -21,14 +21,17 @@ CALLS = [   # (substring of the kernel name, ABI call)
     ("smooth_half_split", "ira_rfft_smooth"), ("rows3_kernel", "ira_rfft_any"), ("edc_moments", "ira_edc_fits"),
     ("edc_line", "ira_edc_fits"), ("pcm16_jobs", "ira_pcm16_to_channels"),
     ("stft2_kernel<double, 1", "ira_stft_mag_db[f64,n4096,sel]"), ("stft2_kernel", "ira_stft_mag_db"),
-    ("smooth_cols_kernel<0", "ira_rfft_smooth"), ("smooth_rows_kernel<0>", "ira_rfft_smooth"), ("smooth_pair_split", "ira_rfft_smooth"),
+    ("smooth_cols_kernel<0", "ira_rfft_smooth"), ("smooth_rows_kernel<0>", "ira_rfft_smooth"), ("smooth_rows_kernel<2>", "ira_rfft_smooth"),
+    ("smooth_pair_split", "ira_rfft_smooth"),
     ("smooth_cols_kernel<1", "ira_band_irfft_smooth"), ("smooth_rows_kernel<1>", "ira_band_irfft_smooth"),
     ("cols_fwd_kernel<0>", "ira_rfft_any"), ("rows_kernel<1>", "ira_rfft_any"), ("cols_inv_kernel<0>", "ira_rfft_any"),
     ("pair_split_kernel", "ira_rfft_any"), ("half_split_kernel", "ira_rfft_any"),
     ("cols_fwd_kernel<1>", "ira_bluestein_filter"), ("rows_kernel<0>", "ira_bluestein_filter"),
     ("cols_fwd_kernel<2>", "ira_band_irfft"), ("cols_inv_kernel<1>", "ira_band_irfft"),
-    ("ar_lag_kernel", "ira_ar_gram"), ("ar_gram_kernel", "ira_ar_gram"), ("ar_solve", "ira_ar_solve"), ("ar_grad", "ira_ar_refine"),
-    ("ar_minnorm", "ira_ar_minnorm"), ("poly_roots", "ira_poly_roots"),
+    ("ar_lag_kernel", "ira_ar_gram"), ("ar_gram_kernel", "ira_ar_gram"), ("ar_solve_dd", "ira_ar_exact"), ("ar_solve", "ira_ar_solve"), ("ar_grad", "ira_ar_refine"),
+    ("ar_minnorm", "ira_ar_minnorm"), ("poly_roots", "ira_poly_roots"), ("ar_lag_dd", "ira_ar_exact"), ("ar_solve_dd", "ira_ar_exact"),
+    ("order_stats", "ira_order_stats"), ("gd_uniform", "ira_group_delay"), ("gd_gradient", "ira_group_delay"),
+    ("diffusion_mono", "ira_diffusion"), ("diffusion_stereo", "ira_diffusion_stereo"),
     ("edc_sums", "ira_edc_fits"), ("edc_carry", "ira_edc_fits"), ("edc_fit", "ira_edc_fits"), ("edc_emit", "ira_edc_fits"),
     ("crossing_search", "ira_curve_fits"), ("curve_fit", "ira_curve_fits"), ("peak_partial", "ira_peak_index"),
     ("peak_decode", "ira_peak_index"), ("mag_phase", "ira_spectrum_mag_phase"), ("unwrap", "ira_phase_unwrap"),
