@@ -46,7 +46,7 @@ PROTOTYPES = {
     "ira_spectrum_mag_phase": (i32, [vp, vp, vp, i32, i32, f64, vp, vp, vp, vp, vp, vp]),
     "ira_phase_unwrap": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "ira_log_smooth_db": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
-    "ira_group_delay": (i32, [vp, vp, vp, i32, i32, vp, f64, vp, vp, vp]),
+    "ira_group_delay": (i32, [vp, vp, vp, i32, i32, vp, f64, vp, i32, vp, vp]),
     "ira_fft_smooth_split": (i32, [i32, vp, vp]),
     "ira_rfft_smooth": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "ira_band_irfft_smooth": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),

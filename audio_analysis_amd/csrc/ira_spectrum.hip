@@ -644,16 +644,20 @@ extern "C" int32_t ira_phase_unwrap(const double* phase_dev, const int64_t* phas
 
 extern "C" int32_t ira_group_delay(const double* phase_dev, const int64_t* off_dev, const int32_t* nbins_dev,
                                    int32_t nb, int32_t max_bins, const double* bin_step_dev, double sample_rate_hz,
-                                   int32_t* flags_dev, double* gd_dev, void* stream) {
+                                   int32_t* flags_dev, int32_t flags_known, double* gd_dev, void* stream) {
   IRA_CHECK_PTR(phase_dev); IRA_CHECK_PTR(off_dev); IRA_CHECK_PTR(nbins_dev); IRA_CHECK_PTR(bin_step_dev);
   IRA_CHECK_PTR(flags_dev); IRA_CHECK_PTR(gd_dev);
   if (nb <= 0 || max_bins <= 0) return (nb == 0 || max_bins == 0) ? IRA_OK : IRA_E_SIZE;
   if (nb > 65535 || !(sample_rate_hz > 0.0)) return IRA_E_SIZE;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(flags_dev, 0, sizeof(int32_t) * (size_t)nb, st);
-  if (e != hipSuccess) return ira_hip_status(e);
   const dim3 grid((max_bins + 255) / 256, nb);
-  gd_uniform_kernel<<<grid, 256, 0, st>>>(nbins_dev, bin_step_dev, sample_rate_hz, flags_dev);
+  if (!flags_known) {
+    // which formula numpy.gradient takes is a function of (bins, bin step, sample rate) alone: a caller that has decided
+    // it once per distinct transform length passes the answers in flags_dev (flags_known) and this sweep is skipped
+    hipError_t e = hipMemsetAsync(flags_dev, 0, sizeof(int32_t) * (size_t)nb, st);
+    if (e != hipSuccess) return ira_hip_status(e);
+    gd_uniform_kernel<<<grid, 256, 0, st>>>(nbins_dev, bin_step_dev, sample_rate_hz, flags_dev);
+  }
   gd_gradient_kernel<<<grid, 256, 0, st>>>(phase_dev, off_dev, nbins_dev, bin_step_dev, sample_rate_hz, flags_dev,
                                            gd_dev);
   IRA_RETURN_LAUNCH();

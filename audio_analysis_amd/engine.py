@@ -1121,12 +1121,26 @@ class Engine:
         n = int(off.size)
         nbins = (np.ascontiguousarray(n_fft, dtype=np.int64) // 2 + 1).astype(np.int32)
         gd = self.empty(int(nbins.astype(np.int64).sum()), t.float64)
-        flags = self.empty(n, t.int32)
-        d_o, d_n = self.to_dev(np.ascontiguousarray(off, np.int64)), self.to_dev(nbins)
-        d_v = self.to_dev(np.ascontiguousarray(bin_step, np.float64))
+        # Which formula numpy.gradient takes (uniform spacing iff every diff of the axis is bit-identical) depends on the
+        # transform length, the bin step and the sample rate alone: decided once per distinct triple on the host, with the
+        # reference's own expression (group_delay.py:113-124), instead of a sweep over every bin of every channel per call.
+        bin_step = np.ascontiguousarray(bin_step, np.float64)
+        known = np.empty(n, dtype=np.int32)
+        for i in range(n):
+            key = (int(nbins[i]), float(bin_step[i]), float(sample_rate_hz))
+            f = self._gd_nonuniform.get(key)
+            if f is None:
+                w = 2.0 * np.pi * ((np.arange(key[0], dtype=np.float64) * key[1]) / key[2])
+                d = np.diff(w)
+                f = int(d.size > 0 and not bool(np.all(d == d[0])))
+                self._gd_nonuniform[key] = f
+            known[i] = f
+        d_o, d_n, d_v, flags = self.to_dev_pack(np.ascontiguousarray(off, np.int64), nbins, bin_step, known)
         check(self.lib.ira_group_delay(_ptr(phase64_dev), _ptr(d_o), _ptr(d_n), n, int(nbins.max()), _ptr(d_v),
-                                       float(sample_rate_hz), _ptr(flags), _ptr(gd), self.stream), "ira_group_delay")
+                                       float(sample_rate_hz), _ptr(flags), 1, _ptr(gd), self.stream), "ira_group_delay")
         return gd
+
+    _gd_nonuniform: dict = {}
 
     def spectrum_stats(self, mag_dev, off: np.ndarray, lengths: np.ndarray, freq_val: np.ndarray, f_min: float,
                        f_max: float, probe_hz: float = 1000.0):

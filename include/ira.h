@@ -241,10 +241,12 @@ int32_t ira_phase_unwrap(const double* phase_dev, const int64_t* phase_off_dev, 
  * sample_rate) in rad/sample, k < nbins[e]; numpy's rule "uniform formula only if every diff(w) is bit-identical,
  * three-point non-uniform formula otherwise" is reproduced (flags_dev: nb int32 of scratch, 1 = non-uniform).
  * phase/gd share off_dev (float64 elements).  Replaces the gradient step of _compute_group_delay_from_ir,
- * reference analyse/group_delay.py:117-124. */
+ * reference analyse/group_delay.py:117-124.   flags_known != 0 (round 4): flags_dev already holds, per element, whether numpy.gradient takes the
+ * non-uniform formula (a function of bins, bin step and sample rate alone: callers decide it once per transform length);
+ * the sweep that works it out on the device is skipped. */
 int32_t ira_group_delay(const double* phase_dev, const int64_t* off_dev, const int32_t* nbins_dev, int32_t nb,
                         int32_t max_bins, const double* bin_step_dev, double sample_rate_hz, int32_t* flags_dev,
-                        double* gd_dev, void* stream);
+                        int32_t flags_known, double* gd_dev, void* stream);
 
 /* Statistics over bins with f_min <= float32(k*freq_val[e]) <= f_max (float32 compares): out_dev[e*8..]:
  * [0] bin count [1] argmax bin of mag_db (first max) [2] its frequency [3] sum f*10^(dB/20) [4] sum 10^(dB/20)
