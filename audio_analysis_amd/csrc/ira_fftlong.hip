@@ -825,6 +825,8 @@ extern "C" int32_t ira_rfft_any(const float* x_dev, const int64_t* xoff_dev, con
   }
   rc = run_convolution<IN_SIGNAL, OUT_SPECTRUM>(p, J, reinterpret_cast<cd*>(work_dev), nb, (hipStream_t)stream);
   if (rc != IRA_OK || x2off_dev == nullptr) return rc;
+  // keep_packed calls carry no PAIRED elements (every second signal is the odd half of an interleaved one): nothing to split
+  if (keep_packed) return rc;
   pair_split_kernel<<<dim3((max_len / 2 + 1 + 255) / 256, nb), 256, 0, (hipStream_t)stream>>>(J);
   // keep_packed: the half-length transforms Z of interleaved elements stay as the column pass wrote them (zpair); the
   // consumer untangles them on the fly (ira_spectrum_mag_phase with packed_dev) -- no read-modify-write pass over Z

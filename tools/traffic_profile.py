@@ -112,7 +112,7 @@ with open(os.path.join(d, "per_kernel.csv"), "w") as f:
 try:
     batch = json.loads(open(os.path.join(d, "stats.log")).read().strip().splitlines()[-1])["config"]["batch_per_gpu"]
 except Exception:
-    batch = {"report": 256, "2": 256, "3": 256, "4": 256}.get(cfg, 64)
+    batch = {"report": 256, "literal": 256, "2": 256, "3": 256, "4": 256, "5": 256}.get(cfg, 64)   # channels per step
 out = {"source": f"tools/profile_config.sh {cfg}: rocprofv3 --kernel-trace [--stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc "
                  "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum], one pass each, IRA_STREAMS=1, copy-engine upload",
        "steps_in_run": steps, "batch": batch,
