@@ -21,42 +21,61 @@ constexpr int DF_MAX_WIN = 8192;
 constexpr int DF_MAX_LAG = 4096;
 constexpr int DF_MAX_LEAVES = DF_MAX_WIN / 64 + 2;
 
-struct PwShared {
-  int start[DF_MAX_LEAVES];
-  int len[DF_MAX_LEAVES];
-  float sum[DF_MAX_LEAVES];
-  int nleaves;
-  float result;
-};
-
-// numpy's float32 pairwise sum of a[0..n) held in LDS (all threads call; barriers inside).
+// numpy's float32 pairwise sum of n values (np.mean / np.sum of a float32 array):
 //   n < 8:            res = 0; res += a[i] in order
 //   n <= 128:         r[j] = a[j]; r[j] += a[i+j] for i = 8, 16, ..; res = ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)); tail in order
 //   n > 128:          n2 = n/2 - (n/2) % 8;  sum(a, n2) + sum(a + n2, n - n2)
-__device__ float np_pairwise_sum_f32(const float* a, int n, PwShared& pw) {
-  const int tid = threadIdx.x;
-  if (tid == 0) {
-    // leaves in left-to-right order (explicit DFS stack; depth <= log2(8192/128) + 1)
-    int ss[16], sl[16], sp = 0, nl = 0;
-    ss[0] = 0; sl[0] = n;
-    while (sp >= 0) {
-      const int s = ss[sp], l = sl[sp];
-      --sp;
-      if (l <= 128) {
-        pw.start[nl] = s; pw.len[nl] = l; ++nl;
-      } else {
-        int n2 = l / 2;
-        n2 -= n2 % 8;
-        ++sp; ss[sp] = s + n2; sl[sp] = l - n2;      // right (popped second)
-        ++sp; ss[sp] = s; sl[sp] = n2;               // left  (popped first)
-      }
-    }
-    pw.nleaves = nl;
+// The recursion depends on n alone, and n (the window length) is the same for every workgroup of a launch: the HOST unrolls it
+// once per call into a PLAN -- the leaves (<= 128 values each, left to right) and the post-order list of additions
+// sum[dst] += sum[src] that folds them -- and the plan travels as a kernel argument.  (Round 3 let thread 0 of every workgroup
+// walk the recursion with explicit stacks, twice per window: dynamically indexed private arrays live in scratch memory, and
+// those two serial walks plus the serial fold were most of a window's run time -- the autocorrelation itself is 15 k cycles.)
+struct PwPlan {
+  unsigned short start[DF_MAX_LEAVES];
+  unsigned short len[DF_MAX_LEAVES];
+  unsigned char dst[DF_MAX_LEAVES];
+  unsigned char src[DF_MAX_LEAVES];
+  int nleaves, nops;
+};
+static_assert(DF_MAX_LEAVES <= 256 && DF_MAX_WIN <= 65535, "plan fields");
+
+static void pw_plan_build(PwPlan& P, int start, int n, int& first_leaf) {
+  if (n <= 128) {
+    first_leaf = P.nleaves;
+    P.start[P.nleaves] = (unsigned short)start;
+    P.len[P.nleaves] = (unsigned short)n;
+    ++P.nleaves;
+    return;
   }
-  __syncthreads();
-  for (int j = tid; j < pw.nleaves; j += DF_THREADS) {
-    const float* p = a + pw.start[j];
-    const int l = pw.len[j];
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  int left = 0, right = 0;
+  pw_plan_build(P, start, n2, left);
+  pw_plan_build(P, start + n2, n - n2, right);
+  P.dst[P.nops] = (unsigned char)left;                 // post-order: both subtrees are folded before this addition
+  P.src[P.nops] = (unsigned char)right;
+  ++P.nops;
+  first_leaf = left;
+}
+
+static PwPlan pw_plan_of(int n) {
+  PwPlan P{};
+  int first = 0;
+  if (n > 0) pw_plan_build(P, 0, n, first);
+  return P;
+}
+
+struct PwShared {
+  float sum[DF_MAX_LEAVES];
+  float result;
+};
+
+// the float32 pairwise sum of a[0..n) held in LDS (all threads call; barriers inside)
+__device__ float np_pairwise_sum_f32(const float* a, const PwPlan& plan, PwShared& pw) {
+  const int tid = threadIdx.x;
+  for (int j = tid; j < plan.nleaves; j += DF_THREADS) {
+    const float* p = a + plan.start[j];
+    const int l = plan.len[j];
     float res;
     if (l < 8) {
       res = 0.0f;
@@ -75,45 +94,11 @@ __device__ float np_pairwise_sum_f32(const float* a, int n, PwShared& pw) {
   }
   __syncthreads();
   if (tid == 0) {
-    // post-order combination of the same tree: left + right, float32
-    int lk[16], st[16];
-    float lv[16];
-    int sp = 0, next = 0;
-    lk[0] = n; st[0] = 0;
-    float ret = 0.0f;
-    bool returning = false;
-    while (true) {
-      if (!returning) {
-        const int l = lk[sp];
-        if (l <= 128) {
-          ret = pw.sum[next++];
-          returning = true;
-        } else {
-          int n2 = l / 2;
-          n2 -= n2 % 8;
-          st[sp] = 1;
-          lk[sp + 1] = n2;
-          ++sp;
-        }
-      } else {
-        if (sp == 0) break;
-        --sp;
-        if (st[sp] == 1) {
-          lv[sp] = ret;
-          st[sp] = 2;
-          const int l = lk[sp];
-          int n2 = l / 2;
-          n2 -= n2 % 8;
-          lk[sp + 1] = l - n2;
-          ++sp;
-          returning = false;
-        } else {
-          ret = lv[sp] + ret;
-          returning = true;
-        }
-      }
+    for (int k = 0; k < plan.nops; ++k) {
+      const int d = plan.dst[k], sidx = plan.src[k];
+      pw.sum[d] = pw.sum[d] + pw.sum[sidx];              // left + right, float32
     }
-    pw.result = ret;
+    pw.result = plan.nleaves > 0 ? pw.sum[0] : 0.0f;
   }
   __syncthreads();
   const float r = pw.result;
@@ -122,7 +107,14 @@ __device__ float np_pairwise_sum_f32(const float* a, int n, PwShared& pw) {
 }
 
 // sum_n cur[n] * lagsrc[n - b] for b = b0..b0+LG-1 over n in [r_begin, r_end); lagsrc has a zero halo below index 0.
-constexpr int LG = 8;    // lags per thread: two LDS reads feed LG FMAs (16 lags: 32 KB of partials, one workgroup fewer per CU: 1.79 vs 1.27 ms)
+#ifndef IRA_DIFF_LG
+#define IRA_DIFF_LG 9
+#endif
+// lags per thread: two LDS reads feed LG FMAs.  ODD on purpose (round 4): neighbouring lanes read lagsrc LG doubles apart, and with
+// LG = 8 (16 dwords) the 30 lag groups of a half wave fell on FOUR bank pairs -- an 8-way conflict on every second LDS read,
+// which made the windowed autocorrelation LDS-bound at 15 % of the float64 vector peak.  9 doubles = 18 dwords: 32 lanes, 32 bank
+// pairs.  (16 lags: 32 KB of partials, one workgroup fewer per CU: 1.79 vs 1.27 ms.)
+constexpr int LG = IRA_DIFF_LG;
 __device__ __forceinline__ void lag_group(const double* cur, const double* lagsrc, int b0, int r_begin, int r_end,
                                           double (&acc)[LG]) {
   double a[LG], w[LG];
@@ -254,12 +246,12 @@ size_t diff_lds_bytes(int n, int max_lag, bool stereo) {
 
 // Mean-removed window in float32 (numpy semantics) -> dst (float64 copy with zero halo) and wf (float32 w0).
 __device__ void stage_mean_removed(const float* __restrict__ src, int n, float* wf, double* dst, int halo,
-                                   PwShared& pw) {
+                                   const PwPlan& plan, PwShared& pw) {
   const int tid = threadIdx.x;
   for (int i = tid; i < n; i += DF_THREADS) wf[i] = src[i];
   for (int i = tid; i < halo; i += DF_THREADS) dst[-1 - i] = 0.0;
   __syncthreads();
-  const float mean = np_pairwise_sum_f32(wf, n, pw) / (float)n;
+  const float mean = np_pairwise_sum_f32(wf, plan, pw) / (float)n;
   for (int i = tid; i < n; i += DF_THREADS) {
     const float v = wf[i] - mean;
     wf[i] = v;
@@ -271,7 +263,7 @@ __device__ void stage_mean_removed(const float* __restrict__ src, int n, float* 
 __global__ __launch_bounds__(DF_THREADS) void diffusion_mono_kernel(
     const float* __restrict__ x, const int64_t* __restrict__ xoff, const int32_t* __restrict__ nframes, int win, int hop,
     int max_lag, double thr_rms, double gauss_expected, float* __restrict__ ac_out, float* __restrict__ ed_out,
-    const int64_t* __restrict__ out_off) {
+    const int64_t* __restrict__ out_off, const PwPlan plan) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ PwShared pw;
   __shared__ double wtmp[DF_THREADS / 64];
@@ -282,7 +274,7 @@ __global__ __launch_bounds__(DF_THREADS) void diffusion_mono_kernel(
   const DiffLayout L = carve(smem, n, max_lag, false);
   const float* src = x + xoff[e] + (int64_t)f * hop;
   const float qnan = __uint_as_float(0x7fc00000u);
-  stage_mean_removed(src, n, L.wf, L.a0, L.halo, pw);
+  stage_mean_removed(src, n, L.wf, L.a0, L.halo, plan, pw);
 
   // ---- max |autocorrelation| -----------------------------------------------------------------------------------
   double den = 0.0;
@@ -297,7 +289,7 @@ __global__ __launch_bounds__(DF_THREADS) void diffusion_mono_kernel(
   // the comparison below reads |w0| back from the float64 copy (exact).
   for (int i = tid; i < n; i += DF_THREADS) L.wf[i] = L.wf[i] * L.wf[i];
   __syncthreads();
-  const float msq = np_pairwise_sum_f32(L.wf, n, pw) / (float)n;
+  const float msq = np_pairwise_sum_f32(L.wf, plan, pw) / (float)n;
   const float rms = sqrtf(msq);
   const float thr = (float)(thr_rms * (double)rms);          // python float product, then the weak-scalar cast to float32
   double cnt = 0.0;
@@ -318,7 +310,7 @@ __global__ __launch_bounds__(DF_THREADS) void diffusion_mono_kernel(
 __global__ __launch_bounds__(DF_THREADS) void diffusion_stereo_kernel(
     const float* __restrict__ x, const int64_t* __restrict__ loff, const int64_t* __restrict__ roff,
     const int32_t* __restrict__ nframes, int win, int hop, int max_lag, float* __restrict__ corr0_out,
-    float* __restrict__ iacc_out, const int64_t* __restrict__ out_off) {
+    float* __restrict__ iacc_out, const int64_t* __restrict__ out_off, const PwPlan plan) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ PwShared pw;
   __shared__ double wtmp[DF_THREADS / 64];
@@ -328,8 +320,8 @@ __global__ __launch_bounds__(DF_THREADS) void diffusion_stereo_kernel(
   const int n = win;
   const DiffLayout L = carve(smem, n, max_lag, true);
   const float qnan = __uint_as_float(0x7fc00000u);
-  stage_mean_removed(x + loff[e] + (int64_t)f * hop, n, L.wf, L.a0, L.halo, pw);
-  stage_mean_removed(x + roff[e] + (int64_t)f * hop, n, L.wf, L.b0, L.halo, pw);
+  stage_mean_removed(x + loff[e] + (int64_t)f * hop, n, L.wf, L.a0, L.halo, plan, pw);
+  stage_mean_removed(x + roff[e] + (int64_t)f * hop, n, L.wf, L.b0, L.halo, plan, pw);
   double aa = 0.0, bb = 0.0, ab = 0.0;
   for (int i = tid; i < n; i += DF_THREADS) {
     aa = fma(L.a0[i], L.a0[i], aa); bb = fma(L.b0[i], L.b0[i], bb); ab = fma(L.a0[i], L.b0[i], ab);
@@ -369,7 +361,7 @@ extern "C" int32_t ira_diffusion(const float* x_dev, const int64_t* xoff_dev, co
     if (e != hipSuccess) return ira_hip_status(e);
   }
   diffusion_mono_kernel<<<dim3(max_frames, nb), DF_THREADS, lds, (hipStream_t)stream>>>(
-      x_dev, xoff_dev, nframes_dev, win, hop, max_lag, thr_rms, gauss_expected, ac_dev, ed_dev, out_off_dev);
+      x_dev, xoff_dev, nframes_dev, win, hop, max_lag, thr_rms, gauss_expected, ac_dev, ed_dev, out_off_dev, pw_plan_of(win));
   IRA_RETURN_LAUNCH();
 }
 
@@ -389,6 +381,6 @@ extern "C" int32_t ira_diffusion_stereo(const float* x_dev, const int64_t* loff_
     if (e != hipSuccess) return ira_hip_status(e);
   }
   diffusion_stereo_kernel<<<dim3(max_frames, nb), DF_THREADS, lds, (hipStream_t)stream>>>(
-      x_dev, loff_dev, roff_dev, nframes_dev, win, hop, max_lag, corr0_dev, iacc_dev, out_off_dev);
+      x_dev, loff_dev, roff_dev, nframes_dev, win, hop, max_lag, corr0_dev, iacc_dev, out_off_dev, pw_plan_of(win));
   IRA_RETURN_LAUNCH();
 }
