@@ -296,6 +296,7 @@ __global__ __launch_bounds__(OS_THREADS) void order_stats_kernel(const double* _
   __shared__ int list_n[OS_LISTS];
   __shared__ int list_of[OS_MAX_RANKS];                 // which list holds rank r's candidates (after compaction)
   __shared__ int compact_now, compacted;
+  __shared__ long long scan_tot[4];
   const int e = blockIdx.x, tid = threadIdx.x;
   const long long n = count[e];
   const double* v = values + off[e];
@@ -422,20 +423,32 @@ __global__ __launch_bounds__(OS_THREADS) void order_stats_kernel(const double* _
       }
     }
     __syncthreads();
-    if (tid < nranks) {
-      long long rem = remaining[tid];
-      const int l = leader[tid];
-      unsigned int d = 0;
-      for (; d < 255; ++d) {
-        const long long c = hist[l][d];
-        if (rem < c) break;
-        rem -= c;
+    // descend: the bucket d of rank r is the one whose cumulative count first exceeds its remaining rank -- a 256-bin scan by
+    // the first four waves per rank (one thread walking the bins was 255 dependent LDS reads per pass and rank)
+    for (int r = 0; r < nranks; ++r) {
+      const int l = leader[r];
+      const long long rem = remaining[r];
+      const long long c = tid < 256 ? (long long)hist[l][tid] : 0ll;
+      long long incl = c;
+#pragma unroll
+      for (int o2 = 1; o2 < 64; o2 <<= 1) {
+        const long long up = __shfl_up(incl, o2, 64);
+        if (lane >= o2) incl += up;
       }
-      remaining[tid] = rem;
-      bucket[tid] = hist[l][d];
-      prefix[tid] = prefix[tid] | ((unsigned long long)d << shift);
+      if (tid < 256 && lane == 63) scan_tot[tid >> 6] = incl;
+      __syncthreads();
+      if (tid < 256) {
+        for (int w = 0; w < (tid >> 6); ++w) incl += scan_tot[w];
+        const long long excl = incl - c;
+        // (the last bin takes whatever is left, like the sequential walk that stopped at d = 255)
+        if ((excl <= rem && rem < incl) || (tid == 255 && rem >= incl)) {
+          remaining[r] = rem - excl;
+          bucket[r] = c;
+          prefix[r] = prefix[r] | ((unsigned long long)tid << shift);
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
   if (tid < nranks) o[tid] = os_unkey(prefix[tid]);
 }
