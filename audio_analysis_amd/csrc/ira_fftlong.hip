@@ -19,6 +19,7 @@
 // phase / band RT60 values are discrete functions of them.
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "ira_bandmask.h"
 #include "ira_fft_lds.h"
@@ -194,6 +195,11 @@ struct Ctx {
   long long st;                     // IN_SIGNAL: sample stride (2 = even / odd samples of one real signal)
   long long nd1, nd2, lw1, lw2;     // IN_SIGNAL: samples actually read / Hann window lengths of the two signals
   bool two;                         // IN_SPECTRUM: the two bands come from two different spectra
+  // the same in the form the tile loops use: 32-bit counts, wave-uniform bases
+  unsigned Lu, stu;
+  unsigned lim1, lim2;              // IN_SIGNAL: samples of signal 1 / 2 that lie inside the transform (0: none)
+  const float* p1; const float* p2; // IN_SIGNAL: first sample of each signal (J.x itself when there is nothing to read)
+  const cd* s1; const cd* s2;       // IN_SPECTRUM: the two spectra
   BandMask b1, b2;
   ira::MaskCuts k1, k2;             // first bins past each mask edge (ira_bandmask.h)
   double fv;
@@ -225,6 +231,11 @@ __device__ __forceinline__ Ctx job_ctx(const Jobs& J, int e) {
     c.nd2 = J.data_len2 ? (long long)ira::uniform(nd2) : c.nd1;
     c.lw1 = J.win_len ? (long long)ira::uniform(lw1) : c.L;
     c.lw2 = J.win_len2 ? (long long)ira::uniform(lw2) : c.lw1;
+    c.Lu = (unsigned)c.L; c.stu = (unsigned)c.st;
+    c.lim1 = (unsigned)(c.nd1 < c.L ? (c.nd1 > 0 ? c.nd1 : 0) : c.L);
+    c.lim2 = c.o2 >= 0 ? (unsigned)(c.nd2 < c.L ? (c.nd2 > 0 ? c.nd2 : 0) : c.L) : 0u;
+    c.p1 = c.lim1 ? J.x + c.o1 : J.x;
+    c.p2 = c.lim2 ? J.x + c.o2 : J.x;
   } else if (MODE == IN_SPECTRUM) {
     const long long o1 = J.spec_off[e];
     const long long o2 = J.spec_off2 ? (long long)J.spec_off2[e] : -1ll;
@@ -238,8 +249,11 @@ __device__ __forceinline__ Ctx job_ctx(const Jobs& J, int e) {
     c.b2 = uniform_band(b2);
     c.fv = ira::uniform(fv);
     ira::band_cuts(c.b1, c.b2, c.fv, (int)(c.L / 2), c.k1, c.k2);
+    c.Lu = (unsigned)c.L;
+    c.s1 = J.spec + c.o1; c.s2 = J.spec + c.o2;
   } else {
     c.L = ira::uniform(L);
+    c.Lu = (unsigned)c.L;
   }
   return c;
 }
@@ -255,18 +269,20 @@ constexpr int FL_UI = 4;    // K1: fetches in flight per thread and batch (a fet
 constexpr int FL_U = 8;     // K2 / K3: 16-byte loads in flight per thread and batch
 
 template <int MODE>
-__device__ __forceinline__ RawL fetch_input(const Jobs& J, const Ctx& c, long long n) {
+__device__ __forceinline__ RawL fetch_input(const Jobs& J, const Ctx& c, unsigned n) {
   RawL r{0.0, 0.0, 0.0, 0.0, 0.0f, 0.0f};
   if (MODE == IN_SIGNAL) {
-    r.fa = *((n < c.L && n < c.nd1) ? J.x + c.o1 + c.st * n : J.x);
-    r.fb = *((c.o2 >= 0 && n < c.L && n < c.nd2) ? J.x + c.o2 + c.st * n : J.x);
+    // 32-bit element indices on wave-uniform 64-bit bases: one compare, one select and one multiply per load (as 64-bit
+    // pointer selects the sixteen loads of a tile were a quarter of K1's VALU instructions)
+    r.fa = c.p1[n < c.lim1 ? c.stu * n : 0u];
+    r.fb = c.p2[n < c.lim2 ? c.stu * n : 0u];
   } else if (MODE == IN_SPECTRUM) {
-    const long long k = n > c.L / 2 ? c.L - n : n;
-    const long long kk = n < c.L ? k : 0;
-    const cd xk = J.spec[c.o1 + kk];
+    const unsigned k = n > c.Lu / 2 ? c.Lu - n : n;
+    const unsigned kk = n < c.Lu ? k : 0u;
+    const cd xk = c.s1[kk];
     r.a = xk.re; r.b = xk.im;
     if (c.two) {
-      const cd x2 = J.spec[c.o2 + kk];
+      const cd x2 = c.s2[kk];
       r.c = x2.re; r.d = x2.im;
     }
   }
@@ -274,33 +290,33 @@ __device__ __forceinline__ RawL fetch_input(const Jobs& J, const Ctx& c, long lo
 }
 
 template <int MODE>
-__device__ __forceinline__ cd value_input(const Jobs& J, const Ctx& c, long long n, long long M, cd w, double h,
-                                          double h2, const RawL& r) {
-  const long long L = c.L;
+__device__ __forceinline__ cd value_input(const Jobs& J, const Ctx& c, unsigned n, unsigned M, cd w, double h,
+                                          double h2, const RawL& r, bool hann, bool second) {
+  const unsigned L = c.Lu;
   if (MODE == IN_SIGNAL) {
-    if (n >= L) return {0.0, 0.0};
-    double v = n < c.nd1 ? (double)r.fa : 0.0, v2 = (c.o2 >= 0 && n < c.nd2) ? (double)r.fb : 0.0;
-    if (J.use_hann) {
+    // lim1 / lim2 = samples of the two signals inside the transform (0: no such signal): a lane beyond them dropped its load
+    double v = (double)(n < c.lim1 ? r.fa : 0.0f), v2 = (double)(n < c.lim2 ? r.fb : 0.0f);
+    if (hann) {
       v *= h; v2 *= h2;
     }
-    if (c.o2 < 0) return {v * w.re, v * w.im};
+    if (!second) return {v * w.re, v * w.im};
     return {v * w.re - v2 * w.im, v * w.im + v2 * w.re};
   } else if (MODE == IN_FILTER) {
     // b[j] = conj(w[|j|]) for -(L-1) <= j <= L-1 at position j mod M.  With M >= 2L - 1 the two sides do not meet; a
     // smaller M (>= L + L/2, single real signals whose bins k <= L/2 alone are wanted) lets them overlap, and then the
     // NEGATIVE side wins: output k needs j = k - n in [-(L-1), L/2], and positions above L/2 can only mean j < 0.
-    long long m = M - n;
+    unsigned m = M - n;
     if (m >= L) {
       m = n;
       if (m >= L) return {0.0, 0.0};
     }
-    const cd wm = chirp(m, chirp_scale(L));
+    const cd wm = chirp((long long)m, chirp_scale((long long)L));
     return {wm.re, -wm.im};  // conj(w)
   } else {
     if (n >= L) return {0.0, 0.0};
     // Hermitian extension of X * (m1 + i m2); the inverse DFT is conj(DFT(conj(.)))/L, so feed conj(W) * chirp
     const bool upper = n > L / 2;
-    const long long k = upper ? L - n : n;
+    const unsigned k = upper ? L - n : n;
     const cd xk = {r.a, upper ? -r.b : r.b};
     const double m1 = (double)ira::mask_cut(c.b1, c.k1, (int)k, c.fv);
     const double m2 = (double)ira::mask_cut(c.b2, c.k2, (int)k, c.fv);
@@ -352,91 +368,119 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   // (<= N1*C/FL_THREADS = 8 steps, so the recurrences add a few 1e-16.)
   {
     const unsigned c = tid & cm, n1_0 = tid >> lc;
-    const long long dn = (long long)(FL_THREADS >> lc) * N2;
-    const long long n0 = (long long)n1_0 * N2 + n2_0 + c;
+    const unsigned dn = (FL_THREADS >> lc) * N2;                          // all indices < M < 2^31
+    const unsigned n0 = n1_0 * N2 + n2_0 + c;
     const unsigned total = N1 * (unsigned)C;
-    const unsigned cnt = total > (unsigned)tid ? (total - (unsigned)tid + FL_THREADS - 1) / FL_THREADS : 0u;   // my elements
-    // The first batch of loads goes out BEFORE the trigonometric set-up below (~400 instructions that need no memory).
-    constexpr int UI = (MODE == IN_SIGNAL) ? 2 * FL_UI : FL_UI;             // a signal fetch is two floats: all eight at once
-    RawL raw[UI];
-    if (cnt > 0) {
-#pragma unroll
-      for (int u = 0; u < UI; ++u) {
-        const unsigned j = (unsigned)u < cnt ? (unsigned)u : cnt - 1;       // clamp: unconditional loads
-        raw[u] = fetch_input<MODE>(J, ctx, n0 + (long long)j * dn);
-      }
-    }
-    cd w = {1.0, 0.0}, d = {1.0, 0.0}, e2 = {1.0, 0.0};
-    // Hann windows of the (up to) two signals: window length and sample count may differ from the transform length
-    long long lw1 = L, lw2 = L;
-    if (MODE == IN_SIGNAL) {
-      lw1 = ctx.lw1;
-      lw2 = ctx.lw2;
-    }
-    const bool second = MODE == IN_SIGNAL && ctx.o2 >= 0;                   // a second signal (and so a second window) exists
-    double hc = 1.0, hs = 0.0, rc = 1.0, rs = 0.0, hc2 = 1.0, hs2 = 0.0, rc2 = 1.0, rs2 = 0.0;
-    if (MODE != IN_FILTER) {
-      const ChirpScale cs = chirp_scale(L);
-      const double n0d = (double)n0, dnd = (double)dn;
-      w = unit_q(n0d * n0d, cs);
-      d = unit_q(2.0 * n0d * dnd + dnd * dnd, cs);
-      const bool hann = MODE == IN_SIGNAL && J.use_hann;
-      const double st = (double)ctx.st;
-      const double inv1 = lw1 > 1 ? 1.0 / (double)(lw1 - 1) : 0.0, inv2 = lw2 > 1 ? 1.0 / (double)(lw2 - 1) : 0.0;
-      // The three values every thread of the job shares -- e2 and the two window rotation steps -- in ONE sincospi: lanes
-      // 0 / 1 / 2 of each wave evaluate one of them each, everybody reads the results from those lanes.
-      {
-        const int lane = tid & 63;
-        const double a = lane == 0 ? chirp_angle(2.0 * dnd * dnd, cs) : (2.0 * st * dnd) * (lane == 1 ? inv1 : inv2);
-        double s3, c3;
-        sincospi(a, &s3, &c3);
-        e2 = {lane_value(c3, 0), -lane_value(s3, 0)};
-        if (hann && lw1 > 1) { rs = lane_value(s3, 1); rc = lane_value(c3, 1); }
-        if (hann && second && lw2 > 1) { rs2 = lane_value(s3, 2); rc2 = lane_value(c3, 2); }
-      }
-      if (hann) {
-        // window index of transform index n: n (plain), or 2n / 2n+1 for the even / odd samples of an interleaved job
-        const double i1 = st * n0d, i2 = st * n0d + (st - 1.0);
-        if (lw1 > 1) sincospi((2.0 * i1 + 1.0 - (double)lw1) * inv1, &hs, &hc);
-        if (second && lw2 > 1) sincospi((2.0 * i2 + 1.0 - (double)lw2) * inv2, &hs2, &hc2);
-      }
-    }
-    // (nothing of the value phase -- not even the float -> double conversions of the loaded samples, which the optimiser
-    // otherwise hoists to right behind the loads -- may come before this line: the first use of a load is where the wave
-    // starts to wait for memory; the empty asm pins the loaded values here)
-    if (MODE == IN_SIGNAL) {
-#pragma unroll
-      for (int u = 0; u < UI; ++u) asm volatile("" : "+v"(raw[u].fa), "+v"(raw[u].fb));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    for (unsigned jb = 0; jb < cnt; jb += UI) {
-      if (jb > 0) {
-#pragma unroll
+    const unsigned cnt_mine = total > (unsigned)tid ? (total - (unsigned)tid + FL_THREADS - 1) / FL_THREADS : 0u;   // my elements
+    // Whole tiles (every M but the very smallest): each thread owns total / FL_THREADS elements, and a count the compiler
+    // can see is wave-uniform turns the element loop's `j < cnt` tests into scalar branches -- as per-lane tests they were
+    // ~300 v_cndmask per tile around the recurrences' state.  Likewise the job's two yes/no properties (Hann window, second
+    // signal): as run-time values every use is a select on a 64-bit double, as constants the unused half of the element
+    // loop is not there.  KNOWN bit 0: Hann windows of more than one sample; bit 1: two signals; bit 2: ask at run time.
+    // Several copies of the phase, one executed.
+    auto load_phase = [&](auto known, const unsigned cnt) __attribute__((always_inline)) {
+      constexpr int KNOWN = decltype(known)::value;
+      // The first batch of loads goes out BEFORE the trigonometric set-up below (~400 instructions that need no memory).
+      constexpr int UI = (MODE == IN_SIGNAL) ? 2 * FL_UI : FL_UI;             // a signal fetch is two floats: all eight at once
+      RawL raw[UI];
+      if (cnt > 0) {
+  #pragma unroll
         for (int u = 0; u < UI; ++u) {
-          const unsigned j = jb + u < cnt ? jb + u : cnt - 1;
-          raw[u] = fetch_input<MODE>(J, ctx, n0 + (long long)j * dn);
+          const unsigned j = (unsigned)u < cnt ? (unsigned)u : cnt - 1;       // clamp: unconditional loads
+          raw[u] = fetch_input<MODE>(J, ctx, n0 + j * dn);
         }
       }
-#pragma unroll
-      for (int u = 0; u < UI; ++u) {
-        const unsigned j = jb + u;
-        if (j < cnt) {
-          const unsigned n1 = (tid + FL_THREADS * j) >> lc;
-          const long long n = n0 + (long long)j * dn;
-          const double h = (lw1 > 1) ? 0.5 + 0.5 * hc : 1.0;
-          const double h2 = (lw2 > 1) ? 0.5 + 0.5 * hc2 : 1.0;
-          lds[c * stride + col_slot(g, n1)] = (IRA_ABL(g.ablate & 1)) ? cd{(double)n, 1.0} : value_input<MODE>(J, ctx, n, M, w, h, h2, raw[u]);
-          w = ira::cmul(w, d);
-          d = ira::cmul(d, e2);
-          const double nc = hc * rc - hs * rs;
-          hs = hs * rc + hc * rs;
-          hc = nc;
-          if (second) {
-            const double nc2 = hc2 * rc2 - hs2 * rs2;
-            hs2 = hs2 * rc2 + hc2 * rs2;
-            hc2 = nc2;
+      cd w = {1.0, 0.0}, d = {1.0, 0.0}, e2 = {1.0, 0.0};
+      // Hann windows of the (up to) two signals: window length and sample count may differ from the transform length
+      long long lw1 = L, lw2 = L;
+      if (MODE == IN_SIGNAL) {
+        lw1 = ctx.lw1;
+        lw2 = ctx.lw2;
+      }
+      const bool second = (KNOWN & 4) ? (MODE == IN_SIGNAL && ctx.o2 >= 0) : (KNOWN & 2) != 0;   // a second signal (and window)
+      const bool hann = (KNOWN & 4) ? (MODE == IN_SIGNAL && J.use_hann) : (KNOWN & 1) != 0;
+      const bool win1 = (KNOWN & 4) ? lw1 > 1 : true, win2 = (KNOWN & 4) ? lw2 > 1 : true;      // windows longer than one sample
+      double hc = 1.0, hs = 0.0, rc = 1.0, rs = 0.0, hc2 = 1.0, hs2 = 0.0, rc2 = 1.0, rs2 = 0.0;
+      if (MODE != IN_FILTER) {
+        const ChirpScale cs = chirp_scale(L);
+        const double n0d = (double)n0, dnd = (double)dn;
+        w = unit_q(n0d * n0d, cs);
+        d = unit_q(2.0 * n0d * dnd + dnd * dnd, cs);
+        const double st = (double)ctx.st;
+        const double inv1 = win1 ? 1.0 / (double)(lw1 - 1) : 0.0, inv2 = win2 ? 1.0 / (double)(lw2 - 1) : 0.0;
+        // The three values every thread of the job shares -- e2 and the two window rotation steps -- in ONE sincospi: lanes
+        // 0 / 1 / 2 of each wave evaluate one of them each, everybody reads the results from those lanes.
+        {
+          const int lane = tid & 63;
+          const double a = lane == 0 ? chirp_angle(2.0 * dnd * dnd, cs) : (2.0 * st * dnd) * (lane == 1 ? inv1 : inv2);
+          double s3, c3;
+          sincospi(a, &s3, &c3);
+          e2 = {lane_value(c3, 0), -lane_value(s3, 0)};
+          if (hann && win1) { rs = lane_value(s3, 1); rc = lane_value(c3, 1); }
+          if (hann && second && win2) { rs2 = lane_value(s3, 2); rc2 = lane_value(c3, 2); }
+        }
+        if (hann) {
+          // window index of transform index n: n (plain), or 2n / 2n+1 for the even / odd samples of an interleaved job
+          const double i1 = st * n0d, i2 = st * n0d + (st - 1.0);
+          if (win1) sincospi((2.0 * i1 + 1.0 - (double)lw1) * inv1, &hs, &hc);
+          if (second && win2) sincospi((2.0 * i2 + 1.0 - (double)lw2) * inv2, &hs2, &hc2);
+        }
+      }
+      // (nothing of the value phase -- not even the float -> double conversions of the loaded samples, which the optimiser
+      // otherwise hoists to right behind the loads -- may come before this line: the first use of a load is where the wave
+      // starts to wait for memory; the empty asm pins the loaded values here)
+      if (MODE == IN_SIGNAL) {
+  #pragma unroll
+        for (int u = 0; u < UI; ++u) asm volatile("" : "+v"(raw[u].fa), "+v"(raw[u].fb));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      for (unsigned jb = 0; jb < cnt; jb += UI) {
+        if (jb > 0) {
+  #pragma unroll
+          for (int u = 0; u < UI; ++u) {
+            const unsigned j = jb + u < cnt ? jb + u : cnt - 1;
+            raw[u] = fetch_input<MODE>(J, ctx, n0 + j * dn);
           }
         }
+  #pragma unroll
+        for (int u = 0; u < UI; ++u) {
+          const unsigned j = jb + u;
+          if (j < cnt) {
+            const unsigned n1 = (tid + FL_THREADS * j) >> lc;
+            const unsigned n = n0 + j * dn;
+            const double h = win1 ? 0.5 + 0.5 * hc : 1.0;
+            const double h2 = win2 ? 0.5 + 0.5 * hc2 : 1.0;
+            lds[c * stride + col_slot(g, n1)] = (IRA_ABL(g.ablate & 1)) ? cd{(double)n, 1.0} : value_input<MODE>(J, ctx, n, (unsigned)M, w, h, h2, raw[u], hann, second);
+            w = ira::cmul(w, d);
+            d = ira::cmul(d, e2);
+            if (hann) {
+              const double nc = hc * rc - hs * rs;
+              hs = hs * rc + hc * rs;
+              hc = nc;
+            }
+            if (hann && second) {
+              const double nc2 = hc2 * rc2 - hs2 * rs2;
+              hs2 = hs2 * rc2 + hc2 * rs2;
+              hc2 = nc2;
+            }
+          }
+        }
+      }
+    };
+    using std::integral_constant;
+    const unsigned cnt_all = total / FL_THREADS;
+    if (total % FL_THREADS != 0) {
+      load_phase(integral_constant<int, 4>{}, cnt_mine);
+    } else if (MODE != IN_SIGNAL) {
+      load_phase(integral_constant<int, 4>{}, cnt_all);
+    } else {
+      const bool two = ctx.o2 >= 0;
+      if (!J.use_hann) {
+        if (two) load_phase(integral_constant<int, 2>{}, cnt_all); else load_phase(integral_constant<int, 0>{}, cnt_all);
+      } else if (ctx.lw1 > 1 && (!two || ctx.lw2 > 1)) {
+        if (two) load_phase(integral_constant<int, 3>{}, cnt_all); else load_phase(integral_constant<int, 1>{}, cnt_all);
+      } else {
+        load_phase(integral_constant<int, 4>{}, cnt_all);
       }
     }
   }
