@@ -69,12 +69,14 @@ struct SmoothPlan {
                                     // rows {p, n1 - p} (n1 even, c2 = 2) -- so that Z[k] and Z[n - k] meet in one workgroup
   double pstep_c, pstep_s;          // pairs: cos / sin of -pi (256 / 2) / n2, the step of W_2n^k between a thread's
                                     // consecutive pass-2 elements (k advances by 128 n1)
+  int sparse_q;                     // narrow-band path: jobs whose band hull spans <= sparse_q * n2 bins skip pass 1 (0: off)
   int stamp;                        // diagnostics (IRA_SMOOTH_STAMP): per-phase cycle counts of one workgroup per kernel
   int ablate;                       // diagnostics (IRA_SMOOTH_ABLATE, timing only -- results are wrong): 1 pass-2 band output
                                     // written tile-major (contiguous per workgroup), 2 pass-1 output contiguous, 4 pass-1
                                     // spectrum gather contiguous, 8 / 16 no transform in pass 1 / 2, 32 no input arithmetic
                                     // in pass 1, 64 no output-twiddle loads in pass 1, 128 no digit-reversed slot lookups
-                                    // (tools/smooth_ablate.sh, profiles/r03_smooth_ablation.txt)
+                                    // (tools/smooth_ablate.sh, profiles/r03_smooth_ablation.txt); narrow-band kernel: 256 no
+                                    // terms, 512 no W_n^(k1 n2) loads, 1024 no transform, 2048 no output stores
 };
 
 // ---- radix butterflies, forward sign (W = exp(-2 pi i / r)), natural order in and out, registers only -------------------
@@ -286,7 +288,27 @@ struct SJobs {
   const double* freq_val;
   float* y;
   const int64_t* y1_off; const int64_t* y2_off;
+  // inverse, optional (null = off): per-job record of the NARROW-band path (SparseInfo below), written by
+  // band_compact_kernel and read by the three kernels that follow it
+  int32_t* info;
 };
+
+// ---- narrow bands: the first pass is a handful of terms per point, not a transform ---------------------------------------
+// A third-octave band around 100 Hz occupies ~500 of the 240 001 bins of a 10 s spectrum.  In the four-step inverse the
+// first pass transforms, for every column n2, the N1 bins n2, n2 + N2, n2 + 2 N2, ... -- of which a band of W bins (and its
+// Hermitian mirror) touches ceil(W / N2) each: for W <= q N2 the column "transform"
+//     Y[k1][n2] = W_n^(k1 n2) * sum over the <= 2q non-zero n1 of  x[n1 N2 + n2] W_N1^(n1 k1)
+// is cheaper evaluated as written than as an N1-point FFT, and it can be evaluated where it is consumed: in the input stage
+// of the second pass.  Such a job never touches its n-point work array (7.7 MB written and read back per 10 s pair) and
+// never runs pass 1 at all; the masked, Hermitian-extended values x[i] of the 2W bins are computed once per job
+// (band_compact_kernel, into the head of the job's otherwise unused work array) instead of once per column.
+// Which jobs are narrow is decided on the device from the same float32 mask cuts the regular path uses (no host copy of
+// that logic): SparseInfo = {narrow, lo, w, q} with [lo, lo + w) the hull of the job's band supports on the positive
+// side and q = ceil(w / N2) the terms per cluster.  Results are the regular path's up to the rounding of a different
+// (shorter) summation order.
+constexpr int SM_SPARSE_INFO = 4;       // int32 per job
+constexpr int SM_SPARSE_R = 16;         // row-twiddle table entries per row: q + 2 <= 16
+constexpr int SM_SPARSE_QMAX = SM_SPARSE_R - 2;
 
 enum { SM_SIGNAL = 0, SM_SPECTRUM = 1 };
 enum { SM_OUT_SPEC = 0, SM_OUT_BANDS = 1, SM_OUT_SPEC_PAIRS = 2 };
@@ -463,6 +485,50 @@ __device__ __forceinline__ bool smooth_nonzero(const SmoothPlan& P, const SCtx& 
   return (k >= c.s1_lo && k < c.s1_hi) || (k >= c.s2_lo && k < c.s2_hi);
 }
 
+
+// ---- narrow-band path, step 1: classify the job and compact its non-zero input.  grid (ceil(sparse_q n2 / 256), jobs) -----
+// work[e n + t] = x[lo + t], work[e n + wp + t] = x[n - (lo + t)] (0 where lo + t = 0: index n does not exist), t < w, with
+// x = the conjugated, masked, Hermitian-extended sequence the regular pass 1 builds on the fly (smooth_value); both
+// clusters are followed by n2 zeros (wp = w + n2), so that the consumer can step through them without range tests.
+template <bool HALF>
+__global__ __launch_bounds__(256) void band_compact_kernel(SmoothPlan P, SJobs J, cd* __restrict__ work) {
+  const int e = blockIdx.y, tid = threadIdx.x;
+  const SCtx ctx = smooth_ctx<SM_SPECTRUM>(P, J, e);
+  const int n = P.n;
+  const int nbins = HALF ? n + 1 : n / 2 + 1;                      // bins of the half spectrum the masks are defined on
+  int lo = 0x7fffffff, hi = 0;
+  if (ctx.s1_hi > ctx.s1_lo) { lo = min(lo, ctx.s1_lo); hi = max(hi, min(ctx.s1_hi, nbins)); }
+  if (!HALF && ctx.s2_hi > ctx.s2_lo) { lo = min(lo, ctx.s2_lo); hi = max(hi, min(ctx.s2_hi, nbins)); }
+  if (hi <= lo) { lo = 0; hi = 0; }                                 // nothing passes: an all-zero signal, zero terms
+  const int w = hi - lo;
+  // the two clusters [lo, hi) and (n - hi, n - lo] must not meet, and must fit the head of the work array
+  const int wp = w + P.n2;
+  const bool narrow = w <= P.sparse_q * P.n2 && 2 * hi <= n && 2 * wp <= n;
+  if (blockIdx.x == 0 && tid == 0) {
+    int32_t* r = J.info + (size_t)SM_SPARSE_INFO * e;
+    r[0] = narrow ? 1 : 0; r[1] = lo; r[2] = w; r[3] = (w + P.n2 - 1) / P.n2;
+  }
+  const int t = (int)blockIdx.x * 256 + tid;
+  if (!narrow || t >= wp) return;
+  cd* z = work + (long long)e * n;
+  if (t >= w) {
+    z[t] = cd{0.0, 0.0};
+    z[wp + t] = cd{0.0, 0.0};
+    return;
+  }
+  const long long i = lo + t, i2 = (long long)n - i;
+  const bool has2 = i > 0;
+  const RawIn r1 = smooth_fetch<SM_SPECTRUM, HALF>(P, J, ctx, i);
+  const RawIn r2 = smooth_fetch<SM_SPECTRUM, HALF>(P, J, ctx, has2 ? i2 : i);
+  double c1 = 1.0, s1 = 0.0, c2 = 1.0, s2 = 0.0;
+  if (HALF) {
+    sincospi((double)i / (double)n, &s1, &c1);
+    sincospi((double)(has2 ? i2 : i) / (double)n, &s2, &c2);
+  }
+  z[t] = smooth_value<SM_SPECTRUM, HALF>(P, J, ctx, i, r1, c1, s1);
+  z[wp + t] = has2 ? smooth_value<SM_SPECTRUM, HALF>(P, J, ctx, i2, r2, c2, s2) : cd{0.0, 0.0};
+}
+
 constexpr int SM_U = 8;     // independent loads in flight per thread (pass 2)
 constexpr int SM_UC = 5;    // (pass 1: a fetch is up to four doubles; 640 x 2 columns = 5 x 256: ONE round of loads)
 
@@ -493,6 +559,7 @@ __global__ __launch_bounds__(SM_THREADS, ((MODE == SM_SIGNAL || !HALF) ? 6 : 5))
   const int n2_0 = (int)bx * C;
   unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
   SM_STAMP(s0);
+  if (MODE == SM_SPECTRUM && J.info != nullptr && ira::uniform(J.info[SM_SPARSE_INFO * e]) != 0) return;   // narrow job: no pass 1
   const SCtx ctx = smooth_ctx<MODE>(P, J, e);
   const cd twv = twiddle_lds_fetch(P.t1, N1, tid);        // issued first: shares the round trip of the tile loads below
   const int total1 = N1 * C;
@@ -594,6 +661,7 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_rows_kernel(SmoothPlan P, S
   const int e = (int)by, tid = threadIdx.x;
   const int k1_0 = (int)bx * C;
   const cd* w = work + (long long)e * P.n;
+  if (OUT == SM_OUT_BANDS && J.info != nullptr && ira::uniform(J.info[SM_SPARSE_INFO * e]) != 0) return;   // narrow job: see below
   unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
   SM_STAMP(s0);
   // the job's output offsets, once (scalar registers; see SCtx)
@@ -710,6 +778,136 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_rows_kernel(SmoothPlan P, S
     SM_STAMP(s3);
     if (tid == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2)
       printf("SMOOTH rows<%d> N2 %d C %d: load %llu  fft %llu  output %llu cycles\n", OUT, N2, C, s1 - s0, s2 - s1, s3 - s2);
+  }
+}
+
+
+// ---- narrow-band path, step 2: pass 2 with the pruned pass 1 as its input stage.  grid (N1 / C, jobs) ----------------------
+// Element (c, n2) of the tile is  W_n^(k1 n2) * [ sum_m xp[n2 + N2 m] R[m] + sum_m' xn[N2 m' - n2] conj(R[m']) ]  with
+// R[m] = W_N1^(k1 m), xp / xn the two compacted clusters (i = n2 + N2 m and i = N2 m' - n2 run over the bins of [lo, hi);
+// the mirror element n - i sits at n1 = N1 - m').  R for the ~q + 2 values of m a job can meet lives in LDS per row, the
+// cluster values come from L2 (2 w values per job, read by every tile of the job), W_n^(k1 n2) from the same two global
+// tables pass 1 uses.  Everything after the input stage is smooth_rows_kernel<SM_OUT_BANDS>.
+__global__ __launch_bounds__(SM_THREADS, 5) void smooth_rows_sparse_kernel(SmoothPlan P, SJobs J, const cd* __restrict__ work) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  cd* a = reinterpret_cast<cd*>(smem);
+  const int C = P.c2, N1 = P.n1, N2 = P.n2;
+  const int LD = P.ld2;
+  cd* twl = a + (size_t)C * LD;
+  cd* rt = twl + SM_TW;                                    // per-row tables: C rows of SM_SPARSE_R + SM_TW entries
+  unsigned bx, by;
+  smooth_remap(bx, by);
+  const int e = (int)by, tid = threadIdx.x;
+  const int32_t* inf = J.info + (size_t)SM_SPARSE_INFO * e;
+  const int i_narrow = inf[0], i_lo = inf[1], i_w = inf[2], i_q = inf[3];
+  const long long y1 = J.y1_off[e], y2 = J.y2_off[e];
+  if (ira::uniform(i_narrow) == 0) return;
+  const int lo = ira::uniform(i_lo), W = ira::uniform(i_w), Q = ira::uniform(i_q);
+  const int Wp = W + N2;                                   // a cluster and its zero padding
+  const long long out1 = ira::uniform(y1), out2 = ira::uniform(y2);
+  const int k1_0 = (int)bx * C;
+  const cd* z = work + (long long)e * P.n;                 // xp = z[0 .. Wp), xn = z[Wp .. 2 Wp)
+  const cd twv = twiddle_lds_fetch(P.t2, N2, tid);
+  const int mb = (int)fdiv((unsigned)lo, P.dn2);           // smallest m any element can need
+  // per-row tables: R[m], m = mb .. mb + 15, and W_n^(k1 n2) = T[n2 >> 5] F[n2 & 31] (33 + 33 entries, the layout of the
+  // sub-transform's own table) -- all from the two global tables pass 1 uses: W_n^p = W_N1^(p / N2) W_n^(p mod N2)
+  for (int j = tid; j < C * (SM_SPARSE_R + SM_TW); j += SM_THREADS) {
+    const int c = j / (SM_SPARSE_R + SM_TW), q = j - c * (SM_SPARSE_R + SM_TW);
+    const unsigned k1 = (unsigned)(k1_0 + c);
+    cd v;
+    if (q < SM_SPARSE_R) {
+      const unsigned p = k1 * (unsigned)(mb + q);                      // < 2^21
+      v = P.t1[p - fdiv(p, P.dn1) * (unsigned)N1];
+    } else {
+      const int t = q - SM_SPARSE_R;
+      const unsigned p = k1 * (unsigned)(t < 33 ? 32 * t : t - 33);    // < 2^21
+      const unsigned ph = fdiv(p, P.dn2), pl = p - ph * (unsigned)N2;
+      v = ira::cmul(P.t1[ph - fdiv(ph, P.dn1) * (unsigned)N1], P.tf[pl]);
+    }
+    rt[j] = v;
+  }
+  twiddle_lds_put(twl, twv, tid);
+  __syncthreads();
+  // A thread owns COLUMNS: n2 = tid, tid + 256, ... for a pair of rows at a time -- the cluster values are the same for every
+  // row, so one load feeds both rows' sums, and the whole tile is one batch (Q dependent round trips to L2 per tile instead
+  // of 2 Q: what this stage costs is their latency, tools/r4_sparse_ablate.sh).
+  constexpr int NU = 3;                                    // columns per thread and batch (750 = 3 x 256 - 18)
+  constexpr int RS = SM_SPARSE_R + SM_TW;                  // table entries per row
+  for (int cg = 0; cg < C; cg += 2) {
+    const bool two = cg + 1 < C;
+    const cd* ra = rt + cg * RS;
+    const cd* rb = rt + (two ? cg + 1 : cg) * RS;
+    for (int base = 0; base < N2; base += SM_THREADS * NU) {
+      cd acc0[NU], acc1[NU];
+      int zp[NU], zn[NU], rp[NU], rn[NU];                  // first value in each cluster (then every N2-th), first R entries
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        int n2 = base + tid + SM_THREADS * u;
+        n2 = n2 < N2 ? n2 : N2 - 1;
+        const int d = lo - n2;
+        const int m0 = d > 0 ? (int)fdiv((unsigned)(d + N2 - 1), P.dn2) : 0;         // first m with n2 + N2 m >= lo
+        int m1 = (int)fdiv((unsigned)(lo + n2 + N2 - 1), P.dn2);                     // first m' with N2 m' - n2 >= lo ...
+        m1 = m1 < 1 ? 1 : m1;                                                        // ... and > 0
+        zp[u] = n2 + N2 * m0 - lo;
+        zn[u] = Wp + (N2 * m1 - n2 - lo);
+        rp[u] = m0 - mb;
+        rn[u] = m1 - mb;
+        acc0[u] = {0.0, 0.0};
+        acc1[u] = {0.0, 0.0};
+      }
+      // (no range tests: the clusters are zero-padded by N2 values, band_compact_kernel)
+      for (int m = 0; m < ((IRA_ABL(P.ablate & 256)) ? 0 : Q); ++m) {
+        cd xp[NU], xn[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          xp[u] = z[zp[u] + N2 * m];
+          xn[u] = z[zn[u] + N2 * m];
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          const cd p0 = ra[rp[u] + m], q0 = ra[rn[u] + m], p1 = rb[rp[u] + m], q1 = rb[rn[u] + m];
+          acc0[u].re = fma(xp[u].re, p0.re, acc0[u].re); acc0[u].re = fma(-xp[u].im, p0.im, acc0[u].re);
+          acc0[u].im = fma(xp[u].re, p0.im, acc0[u].im); acc0[u].im = fma(xp[u].im, p0.re, acc0[u].im);
+          acc0[u].re = fma(xn[u].re, q0.re, acc0[u].re); acc0[u].re = fma(xn[u].im, q0.im, acc0[u].re);    // conj(R)
+          acc0[u].im = fma(xn[u].im, q0.re, acc0[u].im); acc0[u].im = fma(-xn[u].re, q0.im, acc0[u].im);
+          acc1[u].re = fma(xp[u].re, p1.re, acc1[u].re); acc1[u].re = fma(-xp[u].im, p1.im, acc1[u].re);
+          acc1[u].im = fma(xp[u].re, p1.im, acc1[u].im); acc1[u].im = fma(xp[u].im, p1.re, acc1[u].im);
+          acc1[u].re = fma(xn[u].re, q1.re, acc1[u].re); acc1[u].re = fma(xn[u].im, q1.im, acc1[u].re);
+          acc1[u].im = fma(xn[u].im, q1.re, acc1[u].im); acc1[u].im = fma(-xn[u].re, q1.im, acc1[u].im);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int n2 = base + tid + SM_THREADS * u;
+        if (n2 >= N2) continue;
+        const int hi5 = SM_SPARSE_R + (n2 >> 5), lo5 = SM_SPARSE_R + 33 + (n2 & 31);
+        cd w0 = {1.0, 0.0}, w1 = {1.0, 0.0};
+        if (!(IRA_ABL(P.ablate & 512))) {
+          w0 = ira::cmul(ra[hi5], ra[lo5]);
+          w1 = ira::cmul(rb[hi5], rb[lo5]);
+        }
+        a[cg * LD + n2] = ira::cmul(acc0[u], w0);
+        if (two) a[(cg + 1) * LD + n2] = ira::cmul(acc1[u], w1);
+      }
+    }
+  }
+  __syncthreads();
+  const cd* r = a;
+  if (!(IRA_ABL(P.ablate & 1024))) lds_fft_dif_inplace(a, LD, P.p2, twl, tid, C);
+  const long long n = P.n;
+  const double sc = 1.0 / (double)n;
+  for (int i = tid; i < N2 * C; i += SM_THREADS) {
+    const int k2 = (int)fdiv((unsigned)i, P.dc2), c = i - k2 * C;
+    const long long k = (long long)(k1_0 + c) + (long long)N1 * k2;
+    const cd v = r[c * LD + dif_slot(k2, P.p2)];
+    if ((IRA_ABL(P.ablate & 2048)) && v.re != 12345.678) continue;
+    if (J.half_out) {
+      J.y[out1 + 2 * k] = (float)(v.re * sc);
+      J.y[out1 + 2 * k + 1] = (float)(-v.im * sc);
+    } else {
+      J.y[out1 + k] = (float)(v.re * sc);
+      if (out2 >= 0) J.y[out2 + k] = (float)(-v.im * sc);
+    }
   }
 }
 
@@ -888,6 +1086,11 @@ int32_t make_smooth_plan(int32_t n, const void* t1, const void* t2, const void* 
   P->c2_one = P->c2 <= 1 ? 1u : 0u;
   P->dn1 = fast_div_of((unsigned)n1); P->dn2 = fast_div_of((unsigned)n2);
   P->t1 = static_cast<const cd*>(t1); P->t2 = static_cast<const cd*>(t2); P->tf = static_cast<const cd*>(tf);
+  {
+    // narrow-band path: up to 9 terms per cluster and point (measured, config 3: see DESIGN.md section 4.6)
+    int q = ira_tune_int("IRA_SPARSE_Q", 9);
+    P->sparse_q = q < 0 ? 0 : (q > SM_SPARSE_QMAX ? SM_SPARSE_QMAX : q);
+  }
   P->stamp = ira_tune_flag("IRA_SMOOTH_STAMP");
   P->ablate = ira_tune_int("IRA_SMOOTH_ABLATE", 0);
   {
@@ -974,7 +1177,8 @@ extern "C" int32_t ira_band_irfft_smooth(const double* spec_dev, const int64_t* 
                                          const double* band_params_dev, const double* freq_val_dev,
                                          const void* t1_dev, const void* t2_dev, const void* tf_dev, double* work_dev,
                                          float* y_dev, const int64_t* y1_off_dev, const int64_t* y2_off_dev,
-                                         const int64_t* spec_off2_dev, int32_t half_out, void* stream) {
+                                         const int64_t* spec_off2_dev, int32_t half_out, int32_t* job_info_dev,
+                                         void* stream) {
   IRA_CHECK_PTR(spec_dev); IRA_CHECK_PTR(spec_off_dev); IRA_CHECK_PTR(band_params_dev); IRA_CHECK_PTR(freq_val_dev);
   IRA_CHECK_PTR(t1_dev); IRA_CHECK_PTR(t2_dev); IRA_CHECK_PTR(tf_dev); IRA_CHECK_PTR(work_dev); IRA_CHECK_PTR(y_dev);
   IRA_CHECK_PTR(y1_off_dev); IRA_CHECK_PTR(y2_off_dev);
@@ -996,6 +1200,16 @@ extern "C" int32_t ira_band_irfft_smooth(const double* spec_dev, const int64_t* 
   SM_TRY(allow(smooth_cols_kernel<SM_SPECTRUM, true>, l1));
   SM_TRY(allow(smooth_rows_kernel<SM_OUT_BANDS>, l2));
   cd* work = reinterpret_cast<cd*>(work_dev);
+  if (job_info_dev != nullptr && P.sparse_q > 0) {
+    // narrow jobs: compact + one fused pass; the two regular passes below return at once for them (and these for the rest)
+    J.info = job_info_dev;
+    const size_t ls = l2 + (size_t)P.c2 * (SM_SPARSE_R + SM_TW) * sizeof(cd);
+    SM_TRY(allow(smooth_rows_sparse_kernel, ls));
+    const unsigned cb = (unsigned)(((long long)(P.sparse_q + 1) * P.n2 + 255) / 256);     // a cluster + its padding
+    if (half_out) band_compact_kernel<true><<<dim3(cb, nb), 256, 0, st>>>(P, J, work);
+    else band_compact_kernel<false><<<dim3(cb, nb), 256, 0, st>>>(P, J, work);
+    smooth_rows_sparse_kernel<<<dim3(P.n1 / P.c2, nb), SM_THREADS, ls, st>>>(P, J, work);
+  }
   if (half_out) smooth_cols_kernel<SM_SPECTRUM, true><<<dim3(P.n2 / P.c1, nb), SM_THREADS, l1, st>>>(P, J, work);
   else smooth_cols_kernel<SM_SPECTRUM, false><<<dim3(P.n2 / P.c1, nb), SM_THREADS, l1, st>>>(P, J, work);
   smooth_rows_kernel<SM_OUT_BANDS><<<dim3(P.n1 / P.c2, nb), SM_THREADS, l2, st>>>(P, J, work);

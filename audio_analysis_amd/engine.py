@@ -776,6 +776,11 @@ class Engine:
     # in the second pass of the direct transform (smooth lengths), and in the dB / phase kernel for the Bluestein spectra of
     # the fr / filter blocks (packed spectra).  False restores round 3's separate split passes (A/B).
     fuse_half_split = True
+    # Band inverses of smooth lengths: jobs whose bands span few bins (third-octave bands below ~800 Hz of a 10 s file)
+    # skip the first pass and the n-point work array (ira_band_irfft_smooth, job_info_dev).  False = both passes for every
+    # job (A/B).
+    sparse_bands = True
+    last_band_info = ()
 
     @staticmethod
     def _pair_by_key(idx: np.ndarray, keys: np.ndarray):
@@ -788,6 +793,28 @@ class Engine:
                 first.append(order[i]); second.append(order[i + 1]); i += 2
             else:
                 first.append(order[i]); second.append(-1); i += 1
+        return np.asarray(first, dtype=np.int64), np.asarray(second, dtype=np.int64)
+
+    @staticmethod
+    def _pair_bands(keys: np.ndarray, width: np.ndarray):
+        """Like _pair_by_key over all entries, but a group of odd size leaves its entry of smallest `width` alone (the first
+        of them on a tie) and pairs the others in order."""
+        first, second = [], []
+        order = np.argsort(keys, kind="stable")
+        i = 0
+        while i < order.size:
+            j = i
+            while j < order.size and keys[order[j]] == keys[order[i]]:
+                j += 1
+            grp = order[i:j]
+            lone = -1
+            if grp.size % 2:
+                lone = int(grp[int(np.argmin(width[grp]))])
+                grp = grp[grp != lone]
+            first.extend(grp[0::2].tolist()); second.extend(grp[1::2].tolist())
+            if lone >= 0:
+                first.append(lone); second.append(-1)
+            i = j
         return np.asarray(first, dtype=np.int64), np.asarray(second, dtype=np.int64)
 
     def rfft_any(self, x_dev, xoff: np.ndarray, lengths: np.ndarray, use_hann: bool,
@@ -945,6 +972,7 @@ class Engine:
         with the same length and bin step from different channels.)
         """
         t = self.torch
+        self.last_band_info = []          # the job_info records of this call's launches (tests, diagnostics)
         lengths = np.ascontiguousarray(lengths, dtype=np.int32)
         spec_off = np.ascontiguousarray(spec_off, dtype=np.int64)
         y_off = np.ascontiguousarray(y_off, dtype=np.int64)
@@ -955,7 +983,15 @@ class Engine:
         if not self.pair_across_channels:
             cols.append(spec_off.astype(np.float64))
         _, key = np.unique(np.stack(cols, axis=1), axis=0, return_inverse=True)
-        if self.pair_real_ffts:
+        if self.pair_real_ffts and self.sparse_bands:
+            # the band left over in a group of odd size is the NARROWEST one (round 4): alone it is a narrow job of the
+            # half-length inverse and skips the first pass, paired with a wide neighbour it would not
+            kind, width = band_params[:, 0], np.full(lengths.size, np.inf)
+            width[kind == 1.0] = band_params[kind == 1.0, 4]
+            width[kind == 3.0] = band_params[kind == 3.0, 4] - band_params[kind == 3.0, 1]
+            width[(kind != 1.0) & (kind != 2.0) & (kind != 3.0)] = 0.0
+            j1, j2 = self._pair_bands(key.reshape(-1), width)
+        elif self.pair_real_ffts:
             j1, j2 = self._pair_by_key(np.arange(lengths.size), key.reshape(-1))
         else:
             j1, j2 = np.arange(lengths.size, dtype=np.int64), np.full(lengths.size, -1, dtype=np.int64)
@@ -990,10 +1026,13 @@ class Engine:
                         spec_off[j1][sel], np.ascontiguousarray(el_par[sel]), np.ascontiguousarray(freq_val[j1][sel]),
                         np.ascontiguousarray(y_off[j1][sel]), np.ascontiguousarray(el_y2[sel]),
                         None if halves else np.ascontiguousarray(el_so2[sel]))
+                    # round 4: narrow bands skip the first pass (ira.h, job_info_dev); sparse_bands = False is the A/B
+                    info = self.empty(4 * int(sel.size), t.int32) if self.sparse_bands else None
                     check(self.lib.ira_band_irfft_smooth(_ptr(spec_dev), _ptr(d_so), nt, int(sel.size), _ptr(d_bp),
                                                          _ptr(d_fv), _ptr(t1), _ptr(t2), _ptr(tf), _ptr(work), _ptr(y_dev),
                                                          _ptr(d_y1), _ptr(d_y2), _ptr(d_so2), 1 if halves else 0,
-                                                         self.stream), "ira_band_irfft_smooth")
+                                                         _ptr(info), self.stream), "ira_band_irfft_smooth")
+                    self.last_band_info.append(info)
         if not rest.any():
             return
         rest_idx = np.nonzero(rest)[0]

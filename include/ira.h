@@ -33,7 +33,7 @@ extern "C" {
 #define IRA_E_FORMAT (-5)     /* a file is not RIFF/WAVE (host-side ingest entry points only) */
 #define IRA_E_HIP_BASE (-1000)
 
-#define IRA_ABI_VERSION 6   /* bumped whenever an exported signature or a scratch-size constant changes */
+#define IRA_ABI_VERSION 7   /* bumped whenever an exported signature or a scratch-size constant changes */
 
 int32_t ira_abi_version(void);
 const char* ira_error_string(int32_t code);
@@ -391,7 +391,14 @@ int32_t ira_fir_numerator(const double* coeffs_dev, int32_t order, const float* 
  *     of a row and its mirror row, so Z[k] and Z[n-k] meet in one workgroup) and no scratch or split pass exists.
  *   ira_band_irfft_smooth(..., half_out = 1): every job is ONE band (band record 2e; record 2e+1 is ignored) of a real
  *     signal of even length 2 n, computed by an n-point transform: the job's half spectrum has n + 1 bins, y1_off_dev[e]
- *     receives 2 n samples, y2_off_dev is ignored, spec_off2_dev must be NULL. */
+ *     receives 2 n samples, y2_off_dev is ignored, spec_off2_dev must be NULL.
+ *   ira_band_irfft_smooth(..., job_info_dev): nb * 4 int32 of device scratch, or NULL.  With it (round 4) NARROW jobs -- the
+ *     hull of the job's band supports spans at most 9 n2 bins, e.g. the third-octave bands below ~800 Hz of a 10 s file --
+ *     skip the first pass and the n-point work array altogether: their few non-zero bins are compacted once per job and
+ *     the second pass sums the <= 2 x 9 terms of the pruned first pass per point in its input stage.  Which jobs are narrow
+ *     is decided on the device from the mask records (job_info_dev[4e .. 4e+3] = {narrow, first bin, bins, terms}, an
+ *     output for the curious).  Same results up to float64 rounding of a different summation order; NULL = every job
+ *     takes both passes. */
 int32_t ira_fft_smooth_split(int32_t n, int32_t* n1, int32_t* n2);
 int32_t ira_rfft_smooth(const float* x_dev, const int64_t* xoff_dev, int32_t n, int32_t nb, int32_t use_hann,
                         const void* t1_dev, const void* t2_dev, const void* tf_dev, double* work_dev,
@@ -403,7 +410,7 @@ int32_t ira_band_irfft_smooth(const double* spec_dev, const int64_t* spec_off_de
                               const double* band_params_dev, const double* freq_val_dev, const void* t1_dev,
                               const void* t2_dev, const void* tf_dev, double* work_dev, float* y_dev,
                               const int64_t* y1_off_dev, const int64_t* y2_off_dev, const int64_t* spec_off2_dev,
-                              int32_t half_out, void* stream);
+                              int32_t half_out, int32_t* job_info_dev, void* stream);
 
 /* k-th smallest values (0-based ranks, clipped to the segment) of float64 segments values_dev + off_dev[e], count_dev[e]
  * long: out_dev[e*nranks + j] = sorted(segment)[ranks_dev[e*nranks + j]], 1 <= nranks <= 8 (radix select, exact).

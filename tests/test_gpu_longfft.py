@@ -541,6 +541,61 @@ def test_band_masks_and_band_signals_vs_reference_goldens():
             assert np.mean(got[i] == want) > 0.9, (tag, name, float(np.mean(got[i] == want)))   # mostly the same float32
 
 
+def test_narrow_bands_skip_the_first_pass():
+    """Round 4: a band whose support spans few bins (third-octave bands below ~800 Hz of a 10 s file; a 250 Hz low-pass) does
+    not run the first pass of the direct inverse: ira_band_irfft_smooth compacts its non-zero bins and sums the few terms
+    of the pruned column transforms in the second pass.  Same band signals as with both passes (float32 outputs of float64
+    sums in a different order) and as numpy's irfft of the masked spectrum; pairs, single bands (half-length inverse),
+    a low-pass (bin 0 has no mirror) and wide bands in the same call."""
+    import ctypes as C
+    from audio_analysis_amd import _lib
+    from audio_analysis_amd.engine import get_engine
+    from audio_analysis_amd.analyse import rt60bands as rb
+    from audio_analysis_amd.analyse.frequency_response import rfft_bin_step
+    from audio_analysis_amd.synth import synth_ir
+    eng = get_engine()
+    t = eng.torch
+    st = rb.Rt60BandsAnalysisSettings(band_mode="third")
+    third = rb._build_band_definitions(st, SR)
+    low = rb.BandDefinition("Low", 70.0, "lowpass", None, 250.0)
+    for n, bands in ((96000, third), (480000, third[:9]), (96000, [low]), (96000, [low] + third[4:8])):
+        assert eng.smooth_split(n) is not None
+        x = synth_ir(7, 0, n, rt60_seconds=0.8)
+        fv = rfft_bin_step(n, SR)
+        recs = np.stack([rb.band_mask_record(b, st.transition_width_octaves, 0.5 * SR) for b in bands])
+        b = eng.upload([x])
+        spec, spec_off = eng.rfft_any(b.x, b.off, b.length, use_hann=False)
+        nb = len(bands)
+        args = (spec, np.full(nb, spec_off[0], np.int64), np.full(nb, n, np.int32), recs, np.full(nb, fv))
+        yoff = np.arange(nb, dtype=np.int64) * n
+        outs = {}
+        for sparse in (True, False):
+            try:
+                eng.sparse_bands = sparse
+                y = eng.empty(n * nb, t.float32)
+                y.fill_(123.0)
+                eng.band_irfft(*args, y, yoff)
+                outs[sparse] = y.cpu().numpy().reshape(nb, n)
+                if sparse:
+                    info = np.concatenate([i.cpu().numpy().reshape(-1, 4) for i in eng.last_band_info])
+            finally:
+                eng.sparse_bands = True
+        assert info[:, 0].any(), (n, info)                              # the path is exercised ...
+        if nb > 20:
+            assert not info[:, 0].all(), (n, info)                      # ... beside jobs that take both passes
+        X = np.fft.rfft(x.astype(np.float64))
+        for i in range(nb):
+            m = eng.empty(n // 2 + 1, t.float32)
+            assert eng.lib.ira_band_mask_values(_lib.dbl_array(list(recs[i])), float(fv), n // 2 + 1, int(m.data_ptr()),
+                                                eng.stream) == 0
+            want = np.fft.irfft(X * m.cpu().numpy().astype(np.float64), n)
+            peak = float(np.abs(want).max())
+            for sparse in (True, False):
+                err = np.abs(outs[sparse][i].astype(np.float64) - want)
+                assert np.all(err <= 2e-7 * peak + 2e-7 * np.abs(want)), (n, bands[i].name, sparse, float(err.max()), peak)
+            assert np.mean(outs[True][i] == outs[False][i]) > 0.95, (n, bands[i].name)
+
+
 def test_band_bank_with_edc_smoothing_vs_oracle():
     """The default-off dB smoothing of the EDC (decay.py:161-164) inside the band filter bank (rt60bands.py:356-360 hands the
     decay settings through): smoothed on the device (ira_edc_box_smooth), fitted on the smoothed curve."""
