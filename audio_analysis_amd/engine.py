@@ -781,6 +781,7 @@ class Engine:
     # job (A/B).
     sparse_bands = True
     last_band_info = ()
+    last_band_info_half = ()
 
     @staticmethod
     def _pair_by_key(idx: np.ndarray, keys: np.ndarray):
@@ -972,7 +973,8 @@ class Engine:
         with the same length and bin step from different channels.)
         """
         t = self.torch
-        self.last_band_info = []          # the job_info records of this call's launches (tests, diagnostics)
+        self.last_band_info = []          # the job_info records of this call's launches (tests, diagnostics) ...
+        self.last_band_info_half = []     # ... and whether the launch was the half-length (single band) one
         lengths = np.ascontiguousarray(lengths, dtype=np.int32)
         spec_off = np.ascontiguousarray(spec_off, dtype=np.int64)
         y_off = np.ascontiguousarray(y_off, dtype=np.int64)
@@ -1033,6 +1035,7 @@ class Engine:
                                                          _ptr(d_y1), _ptr(d_y2), _ptr(d_so2), 1 if halves else 0,
                                                          _ptr(info), self.stream), "ira_band_irfft_smooth")
                     self.last_band_info.append(info)
+                    self.last_band_info_half.append(bool(halves))
         if not rest.any():
             return
         rest_idx = np.nonzero(rest)[0]

@@ -540,6 +540,7 @@ def dominant_kernel_of_profile(cfg: str):
 
 # kernels of multi-launch ABI calls: (the call they belong to, bytes one launch streams as a function of the job geometry)
 MULTI_KERNEL_CALLS = {"smooth_cols_kernel<1": "ira_band_irfft_smooth", "smooth_rows_kernel<1": "ira_band_irfft_smooth",
+                      "smooth_rows_sparse_kernel": "ira_band_irfft_smooth", "band_compact_kernel": "ira_band_irfft_smooth",
                       "smooth_cols_kernel<0": "ira_rfft_smooth", "smooth_rows_kernel<0": "ira_rfft_smooth",
                       "cols_fwd_kernel<0": "ira_rfft_any", "rows_kernel<1": "ira_rfft_any", "cols_inv_kernel<0": "ira_rfft_any",
                       "edc_moments_kernel": "ira_edc_fits", "edc_fit_kernel": "ira_edc_fits", "edc_sums_kernel": "ira_edc_fits"}
@@ -581,6 +582,19 @@ def stft_error_distribution(eng, batch, settings, channels: int = 4):
              "max_abs_err_db": worst, "fraction_within_1e-3_db": (inside / total) if total else None}, host)
 
 
+def narrow_jobs_of(eng):
+    """Band-inverse jobs of the last step that skipped the first pass (the device's job_info records, ira.h):
+    (two-band jobs, single-band half-length jobs), or None with the narrow-band path off."""
+    try:
+        cnt = [0, 0]
+        for info, half in zip(eng.last_band_info, eng.last_band_info_half):
+            if info is not None:
+                cnt[1 if half else 0] += int(info.view(-1, 4)[:, 0].sum().item())
+        return tuple(cnt)
+    except Exception:
+        return None
+
+
 def roofline_kernel(cfg, tot, roof, geom=None):
     """`roofline` is per ABI CALL (a call may be several kernels: ira_rfft_any is three).  This entry is per KERNEL: the
     kernel rocprofv3 ranks first in the committed profile of this configuration.  When its call is a single launch the
@@ -603,13 +617,19 @@ def roofline_kernel(cfg, tot, roof, geom=None):
         if geom is not None and mcall is not None:
             nchan, n, nb = geom["channels"], geom["n"], geom["bands"]
             b, what = None, None
+            # jobs that skip the first pass (narrow bands, counted on the device) leave the regular kernels at once
+            npair, nhalf = geom.get("narrow_jobs") or (0, 0)
             if (kname + targs).startswith("smooth_cols_kernel<1"):
-                jobs = nchan * (nb // 2)
+                jobs = nchan * (nb // 2) - npair
                 b, what = jobs * (16.0 * (n // 2 + 1) + 16.0 * n), (f"{jobs} two-band jobs: 16(n/2+1) B of spectrum in + 16n B of "
                                                                     f"column-transformed work array out")
             elif (kname + targs).startswith("smooth_rows_kernel<1"):
-                jobs = nchan * (nb // 2)
+                jobs = nchan * (nb // 2) - npair
                 b, what = jobs * (16.0 * n + 8.0 * n), f"{jobs} two-band jobs: 16n B of work array in + two float32 band signals out"
+            elif kname == "smooth_rows_sparse_kernel" and (npair or nhalf):
+                b, what = (npair * 8.0 + nhalf * 4.0) * n, (f"{npair} narrow two-band jobs + {nhalf} narrow single-band jobs "
+                                                            f"(counted on the device, job_info): float32 band signals out; "
+                                                            f"their input is 2(w + n2) compacted bins per job, read from L2")
             elif kname == "edc_moments_kernel" or kname == "edc_sums_kernel":
                 segs = nchan * (nb + (1 if geom.get("decay") else 0))
                 b, what = segs * 4.0 * float(geom["mean_len"]), f"{segs} segments: 4L B of samples read once"
@@ -1018,7 +1038,8 @@ def main():
         "h2d_GBps": B * n * 4.0 * steps / elapsed / 1e9,
         "roofline": roof(dominant),
         "roofline_kernel": roofline_kernel(a.config, tot, roof, dict(channels=B, n=n, bands=nb_bands(settings),
-                                                                    decay=settings.run_decay, mean_len=float(np.mean(L)))),
+                                                                    decay=settings.run_decay, mean_len=float(np.mean(L)),
+                                                                    narrow_jobs=narrow_jobs_of(eng))),
         "roofline_stft": rs,
         "roofline_measured": f"serialised pass of {roof_steps} steps in this run (one stream, kernels one at a time, H2D "
                              f"included); the timed region deals the report blocks onto {lanes_used} streams",
@@ -1151,7 +1172,8 @@ def bench_bundle(a, cfg, eng, rank, world, B, n, steps, blocks, affinity=None, c
         "channels_per_s": 2 * files / elapsed,
         "roofline": roof(dominant),
         "roofline_kernel": roofline_kernel("5", tot, roof, dict(channels=2 * B, n=n, bands=nb_bands(settings),
-                                                                decay=settings.run_decay, mean_len=float(np.mean(L)))),
+                                                                decay=settings.run_decay, mean_len=float(np.mean(L)),
+                                                                narrow_jobs=narrow_jobs_of(eng))),
         "roofline_measured": f"serialised pass ({roof_steps} steps, one stream) in this run",
         "affinity": affinity,
         "lanes": lanes_used,

@@ -24,6 +24,7 @@ CALLS = [   # (substring of the kernel name, ABI call)
     ("smooth_cols_kernel<0", "ira_rfft_smooth"), ("smooth_rows_kernel<0>", "ira_rfft_smooth"), ("smooth_rows_kernel<2>", "ira_rfft_smooth"),
     ("smooth_pair_split", "ira_rfft_smooth"),
     ("smooth_cols_kernel<1", "ira_band_irfft_smooth"), ("smooth_rows_kernel<1>", "ira_band_irfft_smooth"),
+    ("smooth_rows_sparse", "ira_band_irfft_smooth"), ("band_compact", "ira_band_irfft_smooth"),
     ("cols_fwd_kernel<0>", "ira_rfft_any"), ("rows_kernel<1>", "ira_rfft_any"), ("cols_inv_kernel<0>", "ira_rfft_any"),
     ("pair_split_kernel", "ira_rfft_any"), ("half_split_kernel", "ira_rfft_any"),
     ("cols_fwd_kernel<1>", "ira_bluestein_filter"), ("rows_kernel<0>", "ira_bluestein_filter"),
