@@ -484,3 +484,26 @@ def test_bundle_settings_defaults_reproduce_the_reference_behaviour():
     s = BundleRunSettings()
     assert s.reports_subdir == "reports" and s.report_settings is None
     assert s.plot_workers == 0 and s.taps_per_batch >= 1           # inline rendering unless asked otherwise
+
+
+def test_band_pairing_leaves_the_narrowest_band_alone():
+    """Engine._pair_bands (host logic of the band filter bank): entries with equal keys ride one inverse transform two by two,
+    in order; a group of odd size leaves its NARROWEST band alone (it then is a narrow job of the half-length inverse and
+    skips the first pass, ira.h job_info_dev) -- the first of them on a tie -- and every entry appears exactly once."""
+    from audio_analysis_amd.engine import Engine
+    keys = np.array([0, 0, 0, 1, 1, 2, 2, 2, 2, 2, 3])
+    width = np.array([280.0, 1800.0, np.inf, 5.0, 7.0, 9.0, 3.0, 3.0, 8.0, 4.0, 1.0])
+    j1, j2 = Engine._pair_bands(keys, width)
+    pairs = list(zip(j1.tolist(), j2.tolist()))
+    assert pairs == [(1, 2), (0, -1), (3, 4), (5, 7), (8, 9), (6, -1), (10, -1)]
+    used = [i for p in pairs for i in p if i >= 0]
+    assert sorted(used) == list(range(keys.size))
+    # the three bands of the default report: low-pass 250 Hz (280 Hz wide with its ramp), 0.5-2 kHz, high-pass 4 kHz
+    from audio_analysis_amd.analyse import rt60bands as rb
+    st = rb.Rt60BandsAnalysisSettings()
+    recs = np.stack([rb.band_mask_record(b, st.transition_width_octaves, 24000.0) for b in rb._build_band_definitions(st, 48000)])
+    kind, w = recs[:, 0], np.full(3, np.inf)
+    w[kind == 1.0] = recs[kind == 1.0, 4]
+    w[kind == 3.0] = recs[kind == 3.0, 4] - recs[kind == 3.0, 1]
+    j1, j2 = Engine._pair_bands(np.zeros(3, dtype=np.int64), w)
+    assert list(zip(j1.tolist(), j2.tolist())) == [(1, 2), (0, -1)]
