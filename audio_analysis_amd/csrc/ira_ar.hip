@@ -731,7 +731,8 @@ __global__ __launch_bounds__(64) void ar_solve_wave_kernel(const double* __restr
 //   ar_lag_dd_kernel    grid (chunks of LAG_CHUNK rows, 1, nb): p+1 lag sums of the chunk, one or more lags per thread
 //   ar_solve_dd_kernel  one workgroup per element: G from the lag sums by the same diagonal walk as ar_solve_kernel (exact
 //                       products of head / tail samples), Cholesky + solves in global scratch (p^2 double-doubles).
-// A pivot that is not positive RELATIVE to the trace (1e-26) means G is singular to working precision -- the element is
+// A pivot that is not positive RELATIVE to the trace (lstsq's own rank cut, squared; at least 1e-26) means G is singular
+// to the reference's working precision -- the element is
 // given status 1 (whatever brought it here) and ira_ar_minnorm returns lstsq's minimum-norm solution as before.
 // ------------------------------------------------------------------------------------------------------------
 struct dd { double hi, lo; };
@@ -876,7 +877,12 @@ __global__ __launch_bounds__(SV_THREADS) void ar_solve_dd_kernel(const double* _
     trace_s = tr;
   }
   __syncthreads();
-  const double tiny = 1e-26 * trace_s.hi;
+  // numpy.linalg.lstsq(rcond=None) drops singular values of A below eps * max(rows, columns) * sigma_max, i.e. eigenvalues of
+  // G = A^T A below the SQUARE of that ratio times lambda_max (<= trace): a pivot under that cut means the reference
+  // truncates at least one direction, and the element goes to ira_ar_minnorm like every other rank-deficient fit
+  // (with 1e-26 alone, singular-value ratios between 1e-13 and eps * rows got a full-rank solution).
+  const double rc = 2.220446049250313e-16 * (double)((N - p) > p ? (N - p) : p);
+  const double tiny = fmax(1e-26, rc * rc) * trace_s.hi;
   for (int k = 0; k < p; ++k) {
     if (tid == 0) {
       const dd d = G[(long long)k * p + k];
@@ -898,7 +904,7 @@ __global__ __launch_bounds__(SV_THREADS) void ar_solve_dd_kernel(const double* _
     __syncthreads();
   }
   if (fail) {
-    // Singular to ~1e-26 of the trace even in double-double arithmetic.  The status is WRITTEN, not left as it was: an
+    // Singular to lstsq's rank cut even in double-double arithmetic.  The status is WRITTEN, not left as it was: an
     // element that came here on its condition estimate alone still carries status 0 (its float64 pivots stayed positive by
     // rounding noise) and would otherwise be refined from a meaningless float64 factor and reported as solved.  Status 1
     // hands it to ira_ar_minnorm, which returns lstsq's minimum-norm solution (status 4 + rank).

@@ -466,11 +466,14 @@ __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const float* __restri
   __shared__ double red[4][ST_THREADS / IRA_WAVE];
   __shared__ unsigned long long kred[2][ST_THREADS / IRA_WAVE];
   __shared__ long long lred[ST_THREADS / IRA_WAVE];
+  __shared__ double etab[ira::EXPTAB_N];
   const int e = blockIdx.x;
   const long long n = (long long)L[e] / 2 + 1;
   const float* m = mag_db + mag_off[e];
   const double val = freq_val[e];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  ira::build_exp_table(etab, t);
+  __syncthreads();
   double cnt = 0.0, sfl = 0.0, sl = 0.0;
   // argmax of float32 dB with first-max-wins: order-preserving key of the float, then smallest index
   unsigned long long best = 0ull;
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const float* __restri
   unsigned long long near = ~0ull;
   long long first_in = n;
   // ST_U loads per thread in flight before the first is used; the per-thread order of the additions is unchanged
-  constexpr int ST_U = 4;
+  constexpr int ST_U = 16;          // (64 KB of loads in flight per CU: one workgroup per spectrum has only its own loads to hide memory latency with)
   for (long long k0 = t; k0 < n; k0 += (long long)ST_THREADS * ST_U) {
     float dbv[ST_U];
 #pragma unroll
@@ -500,7 +503,11 @@ __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const float* __restri
         uu = (uu & 0x80000000u) ? ~uu : (uu | 0x80000000u);  // monotone map float -> uint
         const unsigned long long key = ((unsigned long long)uu << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)k);
         best = key > best ? key : best;
-        const double lin = exp10((double)db * 0.05);        // 10^(dB/20); pow() costs 4.5x the instructions
+        // 10^(dB/20): table-driven (ira_log.h) for finite values in the table's range -- the float64 exp10 was 70 of this
+        // kernel's 100 instructions per bin, and the kernel is VALU-bound (one workgroup per spectrum); NaN / infinite / huge
+        // values take the library routine
+        const double y = (double)db * 0.05;
+        const double lin = fabs(y) < 15.0 ? ira::exp10_table(y, etab) : exp10(y);
         cnt += 1.0; sfl += (double)f * lin; sl += lin;
         first_in = k < first_in ? k : first_in;
       }

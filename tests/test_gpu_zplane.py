@@ -272,6 +272,28 @@ def test_singular_gram_flagged_by_its_condition_estimate_gets_the_minimum_norm_s
     assert list(info[:, 0]) == [4.0, 4.0, 4.0], info[:, 0]
 
 
+def test_rank_cut_of_the_double_double_solver_is_lstsqs():
+    """numpy.linalg.lstsq(rcond=None) drops singular values below eps * max(rows, columns) * sigma_max
+    (1.3e-12 for 6000 rows).  Three sinusoids plus noise at 3e-13 of their level: six directions carry the signal, the other
+    26 sit BETWEEN the double-double solver's old absolute cut (singular-value ratio 1e-13) and lstsq's -- the reference returns
+    the rank-6 minimum-norm solution, and so must the device (status 4, rank 6), not a full-rank fit to the noise."""
+    from audio_analysis_amd.engine import get_engine
+    eng = get_engine()
+    n, order = 6000, 32
+    t = np.arange(n, dtype=np.float64)
+    rng = np.random.default_rng(5)
+    x = np.sin(0.3 * t) + 0.7 * np.sin(1.1 * t + 1.0) + 0.5 * np.sin(2.0 * t + 2.0) + 3e-13 * rng.standard_normal(n)
+    A = np.stack([x[order - k - 1 : n - k - 1] for k in range(order)], axis=1)
+    sv = np.linalg.svd(A, compute_uv=False)
+    rcond = np.finfo(np.float64).eps * max(A.shape)
+    assert sv[5] > 1e-3 * sv[0] and 1e-13 * sv[0] < sv[6] < rcond * sv[0], (sv[:8] / sv[0], rcond)   # the case is in the gap
+    ref = O.fit_ar(x, order)
+    co, info = eng.ar_fit(eng.to_dev(x), np.zeros(1, np.int64), np.full(1, n, np.int32), None, order, x_is_f64=True)
+    co, info = co.cpu().numpy(), info.cpu().numpy()
+    assert info[0, 0] == 4.0 and info[0, 3] == 6.0, info[0]
+    assert np.abs(co[0] - ref).max() <= 1e-6 * max(1.0, float(np.abs(ref).max())), np.abs(co[0] - ref).max()
+
+
 def test_one_wave_solver_gives_the_workgroup_solvers_bits():
     """Round 4: for order <= 64 the normal equations are factored and solved by ONE WAVE per element (left-looking Cholesky in
     the wave's own LDS, the right-hand side one value per lane) instead of a 256-thread workgroup that spends its time at
