@@ -558,7 +558,9 @@ def test_narrow_bands_skip_the_first_pass():
     st = rb.Rt60BandsAnalysisSettings(band_mode="third")
     third = rb._build_band_definitions(st, SR)
     low = rb.BandDefinition("Low", 70.0, "lowpass", None, 250.0)
-    for n, bands in ((96000, third), (480000, third[:9]), (96000, [low]), (96000, [low] + third[4:8])):
+    # (4800 = 60 x 80 and 28800 = 160 x 180: plans with six and eight rows per workgroup in the second pass)
+    for n, bands in ((96000, third), (480000, third[:9]), (96000, [low]), (96000, [low] + third[4:8]), (4800, third[8:]),
+                     (28800, third[3:])):
         assert eng.smooth_split(n) is not None
         x = synth_ir(7, 0, n, rt60_seconds=0.8)
         fv = rfft_bin_step(n, SR)
