@@ -760,6 +760,7 @@ struct Plan {
   Geom g;
   int C, R;
   size_t lds_cols, lds_rows;
+  int C3; size_t lds_cols3;          // the inverse column pass may take its own tile width (tuning: IRA_FFT_C3)
 };
 
 int32_t make_plan(int32_t m, const void* t1, const void* t2, const void* tf, Plan* p) {
@@ -788,6 +789,9 @@ int32_t make_plan(int32_t m, const void* t1, const void* t2, const void* tf, Pla
   p->C = C;
   p->R = R;
   p->lds_cols = ((size_t)C * col + ira::TW_SPLIT_ENTRIES) * sizeof(cd);          // tile + two-level twiddle table
+  p->C3 = C;
+  { const int v = ira_tune_int("IRA_FFT_C3", 0); if (v >= 1 && v <= N2 && v <= 64 && (v & (v - 1)) == 0) p->C3 = v; }
+  p->lds_cols3 = ((size_t)p->C3 * col + ira::TW_SPLIT_ENTRIES) * sizeof(cd);
   p->lds_rows = ((size_t)R * N2 + ira::TW_SPLIT_ENTRIES) * sizeof(cd);
   return IRA_OK;
 }
@@ -810,10 +814,10 @@ int32_t run_convolution(const Plan& p, const Jobs& J, cd* work, int nb, hipStrea
   const int N1 = p.g.n1, N2 = 1 << p.g.log2n2;
   IRA_TRY_HIP(allow_lds(cols_fwd_kernel<IN>, p.lds_cols));
   IRA_TRY_HIP(allow_lds(rows_kernel<ROW_CONV>, p.lds_rows));
-  IRA_TRY_HIP(allow_lds(cols_inv_kernel<OUT>, p.lds_cols));
+  IRA_TRY_HIP(allow_lds(cols_inv_kernel<OUT>, p.lds_cols3));
   cols_fwd_kernel<IN><<<dim3(N2 / p.C, nb), FL_THREADS, p.lds_cols, st>>>(p.g, J, work, p.C);
   rows_kernel<ROW_CONV><<<dim3(N1 / p.R, nb), FL_THREADS, p.lds_rows, st>>>(p.g, J, work, p.R);
-  cols_inv_kernel<OUT><<<dim3(N2 / p.C, nb), FL_THREADS, p.lds_cols, st>>>(p.g, J, work, p.C);
+  cols_inv_kernel<OUT><<<dim3(N2 / p.C3, nb), FL_THREADS, p.lds_cols3, st>>>(p.g, J, work, p.C3);
   IRA_RETURN_LAUNCH();
 }
 
