@@ -788,7 +788,7 @@ int32_t ira_stft4_dispatch_tf(const float* x, const int64_t* off, const int32_t*
                                        static_cast<const cdd*>(tw), floor_lin, (float)floor_db, out, out_off, frame_sel,
                                        sel_off, 0, 0, nullptr, nullptr);
   else
-    stft5_kernel<<<grid, TL5, 0, st>>>(x, off, nframes, hop, static_cast<const double*>(window),
+    stft5_kernel<<<grid, TL5, (size_t)ira_tune_int("IRA_STFT5_LDS_PAD", 0), st>>>(x, off, nframes, hop, static_cast<const double*>(window),
                                        static_cast<const cdd*>(tw), floor_lin, (float)floor_db, out, out_off, frame_sel,
                                        sel_off, 0, 0, nullptr, nullptr, ira_tune_int("IRA_STFT5_ABLATE", 0));
   IRA_RETURN_LAUNCH();
@@ -812,7 +812,7 @@ int32_t ira_stft4_dispatch_logbin(const float* x, const int64_t* off, const int3
                                        static_cast<const cdd*>(tw), floor_lin, (float)floor_db, curves, curves_off,
                                        nullptr, nullptr, nbins, k_base, first, count);
   else
-    stft5_kernel<<<grid, TL5, 0, st>>>(x, off, nframes, hop, static_cast<const double*>(window),
+    stft5_kernel<<<grid, TL5, (size_t)ira_tune_int("IRA_STFT5_LDS_PAD", 0), st>>>(x, off, nframes, hop, static_cast<const double*>(window),
                                        static_cast<const cdd*>(tw), floor_lin, (float)floor_db, curves, curves_off,
                                        nullptr, nullptr, nbins, k_base, first, count, ira_tune_int("IRA_STFT5_ABLATE", 0));
   IRA_RETURN_LAUNCH();
