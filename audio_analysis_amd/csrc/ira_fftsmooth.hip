@@ -543,7 +543,7 @@ __device__ __forceinline__ void smooth_remap(unsigned& bx, unsigned& by) {
   bx = wg % gx; by = wg / gx;
 }
 
-#define SM_STAMP(var) do { if (P.stamp) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define SM_STAMP(var) do { if (IRA_ABL(P.stamp)) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } } while (0)
 
 // ---- pass 1: columns.  grid (N2 / C, jobs) ------------------------------------------------------------------------------
 template <int MODE, bool HALF = false>
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(SM_THREADS, ((MODE == SM_SIGNAL || !HALF) ? 6 : 5))
           ira::cmul(r[c * LD + ((IRA_ABL(P.ablate & 128)) ? k1 : dif_slot(k1, P.p1))], ira::cmul(th[u], tl[u]));
     }
   }
-  if (P.stamp) {
+  if (IRA_ABL(P.stamp)) {
     SM_STAMP(s3);
     if (tid == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2)
       printf("SMOOTH cols<%d> N1 %d C %d: input %llu  fft %llu  twiddle+store %llu cycles\n", MODE, N1, C, s1 - s0, s2 - s1, s3 - s2);
@@ -774,7 +774,7 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_rows_kernel(SmoothPlan P, S
       if (out2 >= 0) J.y[out2 + ko] = (float)(-v.im * sc);
     }
   }
-  if (P.stamp) {
+  if (IRA_ABL(P.stamp)) {
     SM_STAMP(s3);
     if (tid == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2)
       printf("SMOOTH rows<%d> N2 %d C %d: load %llu  fft %llu  output %llu cycles\n", OUT, N2, C, s1 - s0, s2 - s1, s3 - s2);
