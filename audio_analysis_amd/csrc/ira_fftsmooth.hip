@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
+#include <type_traits>
 
 #include "ira_bandmask.h"
 #include "ira_fft_reg.h"
@@ -324,8 +325,12 @@ __device__ __forceinline__ double hann_s(long long i, long long L) {
 // pass-1 input phase of the band inverses took 47 k cycles of a 69 k-cycle tile)
 struct SCtx {
   long long o1, o2;                 // SM_SIGNAL: sample offsets (o2 < 0: one signal); SM_SPECTRUM: spectrum offsets
-  long long st;                     // SM_SIGNAL: sample stride (2 = even / odd samples of one real signal)
-  long long nd1, nd2, lw1, lw2;     // SM_SIGNAL: samples actually read / Hann window lengths of the two signals
+  // What the SM_SPECTRUM tile loops index with is 32-bit (n <= 2^20) on wave-uniform 64-bit BASES: ~6 % fewer instructions in
+  // the input stage of the inverse pass 1 (VALU 90 % busy in the third-octave bank, profiles/r04_block_counters.txt); the A/B
+  // on one box is within its noise (1.33 vs 1.34 ms per 256 two-band jobs).
+  int st;                           // SM_SIGNAL: sample stride (2 = even / odd samples of one real signal)
+  int nd1, nd2, lw1, lw2;           // SM_SIGNAL: samples actually read / Hann window lengths of the two signals
+  const cd* sp1; const cd* sp2;     // SM_SPECTRUM: the two spectra
   bool two;                         // SM_SPECTRUM: the two bands come from two different spectra
   BandMaskS b1, b2;
   ira::MaskCuts k1, k2;             // first bins past each mask edge (ira_bandmask.h)
@@ -345,7 +350,7 @@ __device__ __forceinline__ BandMaskS uniform_band(const BandMaskS& p) {
 template <int MODE>
 __device__ __forceinline__ SCtx smooth_ctx(const SmoothPlan& P, const SJobs& J, int e) {
   SCtx c{};
-  const long long n = P.n;
+  const int n = P.n;
   if (MODE == SM_SIGNAL) {
     const long long o1 = J.xoff[e];
     const long long o2 = J.x2off ? (long long)J.x2off[e] : -1ll;
@@ -355,19 +360,21 @@ __device__ __forceinline__ SCtx smooth_ctx(const SmoothPlan& P, const SJobs& J, 
     c.o2 = ira::uniform(o2);
     c.st = 1;
     c.nd1 = ira::uniform(nd1);
-    c.nd2 = J.data_len2 ? (long long)ira::uniform(nd2) : c.nd1;
+    c.nd2 = J.data_len2 ? ira::uniform(nd2) : c.nd1;
     c.lw1 = ira::uniform(lw1);
-    c.lw2 = J.win_len2 ? (long long)ira::uniform(lw2) : c.lw1;
+    c.lw2 = J.win_len2 ? ira::uniform(lw2) : c.lw1;
     if (J.interleave) {
       // one real signal of 2 n samples (data_len / win_len, when given, count REAL samples): element i of the transform
       // is x[2 i] + i x[2 i + 1]
-      const long long real_nd = J.data_len ? c.nd1 : 2 * n, real_lw = J.win_len ? c.lw1 : 2 * n;
+      const int real_nd = J.data_len ? c.nd1 : 2 * n, real_lw = J.win_len ? c.lw1 : 2 * n;
       c.st = 2;
       c.o2 = c.o1 + 1;
       c.nd1 = (real_nd + 1) / 2;          // even samples available
       c.nd2 = real_nd / 2;                // odd samples available
       c.lw1 = c.lw2 = real_lw;
     }
+    c.nd1 = c.nd1 > 0 ? c.nd1 : 0;
+    c.nd2 = (c.o2 >= 0 && c.nd2 > 0) ? c.nd2 : 0;          // no second signal: nothing of it is ever read
   } else {
     const long long o1 = J.sp_off[e];
     const long long o2 = J.sp_off2 ? (long long)J.sp_off2[e] : -1ll;
@@ -382,6 +389,8 @@ __device__ __forceinline__ SCtx smooth_ctx(const SmoothPlan& P, const SJobs& J, 
     ira::band_cuts(c.b1, c.b2, c.fv, J.half_out ? (int)n : (int)(n / 2), c.k1, c.k2);   // highest bin of the half spectrum
     ira::band_support(c.b1, c.k1, c.s1_lo, c.s1_hi);
     ira::band_support(c.b2, c.k2, c.s2_lo, c.s2_hi);
+    c.sp1 = J.spec + c.o1;
+    c.sp2 = J.spec + c.o2;
   }
   return c;
 }
@@ -393,36 +402,38 @@ __device__ __forceinline__ SCtx smooth_ctx(const SmoothPlan& P, const SJobs& J, 
 // once, which made the forward pass-1 input phase ten serial round trips.)
 struct RawIn { double a, b, c, d; float fa, fb; };
 // (half-size inverse) bins ka and kb of ONE spectrum; a bin outside the band's support reads bin 0 (multiplied by 0 later)
-__device__ __forceinline__ void r_load2(const SJobs& J, const SCtx& c, long long ka, long long kb, RawIn& r) {
-  const cd xa = J.spec[c.o1 + ((ka >= c.s1_lo && ka < c.s1_hi) ? ka : 0)];
-  const cd xb = J.spec[c.o1 + ((kb >= c.s1_lo && kb < c.s1_hi) ? kb : 0)];
+__device__ __forceinline__ void r_load2(const SCtx& c, int ka, int kb, RawIn& r) {
+  const cd xa = c.sp1[(ka >= c.s1_lo && ka < c.s1_hi) ? ka : 0];
+  const cd xb = c.sp1[(kb >= c.s1_lo && kb < c.s1_hi) ? kb : 0];
   r.a = xa.re; r.b = xa.im; r.c = xb.re; r.d = xb.im;
 }
 
 template <int MODE, bool HALF>
-__device__ __forceinline__ RawIn smooth_fetch(const SmoothPlan& P, const SJobs& J, const SCtx& c, long long i) {
+__device__ __forceinline__ RawIn smooth_fetch(const SmoothPlan& P, const SJobs& J, const SCtx& c, int i) {
   RawIn r{0.0, 0.0, 0.0, 0.0, 0.0f, 0.0f};
-  const long long n = P.n;
+  const int n = P.n;
   if (MODE == SM_SIGNAL) {
-    r.fa = *(i < c.nd1 ? J.x + c.o1 + c.st * i : J.x);
-    r.fb = *((c.o2 >= 0 && i < c.nd2) ? J.x + c.o2 + c.st * i : J.x);       // no branch around it either (same reason)
+    // (64-bit element indices in SM_SIGNAL mode, index_of() included: with 32-bit ones hipcc's allocation of the forward
+    // kernels tips over their 80-register bound and spills 28 bytes per lane)
+    const long long li = i;
+    r.fa = *(li < c.nd1 ? J.x + c.o1 + c.st * li : J.x);
+    r.fb = *((c.o2 >= 0 && li < c.nd2) ? J.x + c.o2 + c.st * li : J.x);       // no branch around it either (same reason)
   } else if (HALF) {
     // half-size inverse of ONE band: element i needs the masked bins i and n - i of the (n + 1)-bin half spectrum
-    const long long k2 = n - i;
-    r_load2(J, c, i, k2, r);
+    r_load2(c, i, n - i, r);
   } else {
-    const long long k = i > n / 2 ? n - i : i;
+    const int k = i > n / 2 ? n - i : i;
     // A bin whose mask is zero for certain reads bin 0 instead (its value is multiplied by 0 either way): the low and mid
     // bands are empty above 2.2 kHz, i.e. 98 % / 91 % of their pass-1 reads hit one cached line instead of HBM.
     // (Unconditional loads on purpose: see RawIn.)
     if (!c.two) {
       const bool need = (k >= c.s1_lo && k < c.s1_hi) || (k >= c.s2_lo && k < c.s2_hi);
-      const cd x1 = J.spec[c.o1 + (need ? k : 0)];
+      const cd x1 = c.sp1[need ? k : 0];
       r.a = x1.re; r.b = x1.im;
     } else {
-      const cd x1 = J.spec[c.o1 + ((k >= c.s1_lo && k < c.s1_hi) ? k : 0)];
+      const cd x1 = c.sp1[(k >= c.s1_lo && k < c.s1_hi) ? k : 0];
       r.a = x1.re; r.b = x1.im;
-      const cd x2 = J.spec[c.o2 + ((k >= c.s2_lo && k < c.s2_hi) ? k : 0)];
+      const cd x2 = c.sp2[(k >= c.s2_lo && k < c.s2_hi) ? k : 0];
       r.c = x2.re; r.d = x2.im;
     }
   }
@@ -433,22 +444,23 @@ __device__ __forceinline__ RawIn smooth_fetch(const SmoothPlan& P, const SJobs& 
 // instead of a sincospi per element, which was most of the half-size pass-1 input stage: 256 half-size jobs took as long
 // as 256 full-size ones)
 template <int MODE, bool HALF>
-__device__ __forceinline__ cd smooth_value(const SmoothPlan& P, const SJobs& J, const SCtx& c, long long i, const RawIn& r,
+__device__ __forceinline__ cd smooth_value(const SmoothPlan& P, const SJobs& J, const SCtx& c, int i, const RawIn& r,
                                            double cs, double sn) {
-  const long long n = P.n;
+  const int n = P.n;
   if (MODE == SM_SIGNAL) {
-    double v = i < c.nd1 ? (double)r.fa : 0.0, v2 = (c.o2 >= 0 && i < c.nd2) ? (double)r.fb : 0.0;
+    const long long li = i;
+    double v = li < c.nd1 ? (double)r.fa : 0.0, v2 = (c.o2 >= 0 && li < c.nd2) ? (double)r.fb : 0.0;
     if (J.use_hann) {
-      v *= hann_s(c.st * i, c.lw1);
-      if (c.o2 >= 0) v2 *= hann_s(c.st * i + (c.st - 1), c.lw2);
+      v *= hann_s(c.st * li, c.lw1);
+      if (c.o2 >= 0) v2 *= hann_s(c.st * li + (c.st - 1), c.lw2);
     }
     return {v, v2};
   } else if (HALF) {
     // One band y of 2 n real samples from an n-point transform: with Xm = X * mask (n + 1 bins),
     //   E[i] = (Xm[i] + conj Xm[n-i]) / 2,  O[i] = W_2n^(-i) (Xm[i] - conj Xm[n-i]) / 2,  Z = E + i O,
     //   y[2 m] + i y[2 m + 1] = IDFT_n(Z)[m]        (inverse = conj(DFT(conj .)) / n: feed conj(Z))
-    const double ma = (double)ira::mask_cut(c.b1, c.k1, (int)i, c.fv);
-    const double mb = (double)ira::mask_cut(c.b1, c.k1, (int)(n - i), c.fv);
+    const double ma = (double)ira::mask_cut(c.b1, c.k1, i, c.fv);
+    const double mb = (double)ira::mask_cut(c.b1, c.k1, n - i, c.fv);
     const cd xa = {r.a * ma, r.b * ma}, xb = {r.c * mb, -r.d * mb};            // Xm[i], conj Xm[n - i]
     const cd e = {0.5 * (xa.re + xb.re), 0.5 * (xa.im + xb.im)};
     const cd d = {0.5 * (xa.re - xb.re), 0.5 * (xa.im - xb.im)};
@@ -458,10 +470,10 @@ __device__ __forceinline__ cd smooth_value(const SmoothPlan& P, const SJobs& J, 
   } else {
     // conj of the Hermitian extension of X1 m1 + i X2 m2  (inverse = conj(DFT(conj .)) / n)
     const bool upper = i > n / 2;
-    const long long k = upper ? n - i : i;
+    const int k = upper ? n - i : i;
     cd x1 = {r.a, upper ? -r.b : r.b};
-    const double m1 = (double)ira::mask_cut(c.b1, c.k1, (int)k, c.fv);
-    const double m2 = (double)ira::mask_cut(c.b2, c.k2, (int)k, c.fv);
+    const double m1 = (double)ira::mask_cut(c.b1, c.k1, k, c.fv);
+    const double m2 = (double)ira::mask_cut(c.b2, c.k2, k, c.fv);
     cd w;
     if (!c.two) {
       w = ira::cmul(x1, cd{m1, m2});
@@ -475,16 +487,15 @@ __device__ __forceinline__ cd smooth_value(const SmoothPlan& P, const SJobs& J, 
 
 // SM_SPECTRUM: can element i of the transform be non-zero at all (is one of the bins it reads inside a band's support)?
 template <bool HALF>
-__device__ __forceinline__ bool smooth_nonzero(const SmoothPlan& P, const SCtx& c, long long i) {
-  const long long n = P.n;
+__device__ __forceinline__ bool smooth_nonzero(const SmoothPlan& P, const SCtx& c, int i) {
+  const int n = P.n;
   if (HALF) {
-    const long long k2 = n - i;
+    const int k2 = n - i;
     return (i >= c.s1_lo && i < c.s1_hi) || (k2 >= c.s1_lo && k2 < c.s1_hi);
   }
-  const long long k = i > n / 2 ? n - i : i;
+  const int k = i > n / 2 ? n - i : i;
   return (k >= c.s1_lo && k < c.s1_hi) || (k >= c.s2_lo && k < c.s2_hi);
 }
-
 
 // ---- narrow-band path, step 1: classify the job and compact its non-zero input.  grid (ceil(sparse_q n2 / 256), jobs) -----
 // work[e n + t] = x[lo + t], work[e n + wp + t] = x[n - (lo + t)] (0 where lo + t = 0: index n does not exist), t < w, with
@@ -516,7 +527,7 @@ __global__ __launch_bounds__(256) void band_compact_kernel(SmoothPlan P, SJobs J
     z[wp + t] = cd{0.0, 0.0};
     return;
   }
-  const long long i = lo + t, i2 = (long long)n - i;
+  const int i = lo + t, i2 = n - i;
   const bool has2 = i > 0;
   const RawIn r1 = smooth_fetch<SM_SPECTRUM, HALF>(P, J, ctx, i);
   const RawIn r2 = smooth_fetch<SM_SPECTRUM, HALF>(P, J, ctx, has2 ? i2 : i);
@@ -565,12 +576,13 @@ __global__ __launch_bounds__(SM_THREADS, ((MODE == SM_SIGNAL || !HALF) ? 6 : 5))
   const int total1 = N1 * C;
   for (int base = 0; base < total1; base += SM_THREADS * SM_UC) {
     RawIn raw[SM_UC];
-    auto index_of = [&](int u) -> long long {               // recomputed, not kept: registers are what limits occupancy
+    using idx_t = typename std::conditional<MODE == SM_SIGNAL, long long, int>::type;
+    auto index_of = [&](int u) -> idx_t {                   // recomputed, not kept: registers are what limits occupancy
       int i = base + tid + SM_THREADS * u;
       i = i < total1 ? i : total1 - 1;                      // clamp: every fetch is unconditional (stays in registers)
-      if (IRA_ABL(P.ablate & 4)) return (long long)bx * total1 + i;
+      if (IRA_ABL(P.ablate & 4)) return (int)(((long long)bx * total1 + i) % P.n);
       const int row = (int)fdiv((unsigned)i, P.dc1);
-      return (long long)row * N2 + n2_0 + (i - row * C);
+      return (idx_t)row * N2 + n2_0 + (i - row * C);
     };
 #pragma unroll
     for (int u = 0; u < SM_UC; ++u) raw[u] = smooth_fetch<MODE, HALF>(P, J, ctx, index_of(u));
