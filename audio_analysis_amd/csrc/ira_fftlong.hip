@@ -148,6 +148,7 @@ using ira::mask_at;
 
 // ---- per-element job description (device arrays, one entry per batch element) ----------------------------------
 struct Jobs {
+  int e0;                   // first element of this launch (run_convolution may launch the three passes over sub-ranges of jobs)
   const int32_t* L;         // transform length of element e
   // signal input
   const float* x;
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   cd* lds = reinterpret_cast<cd*>(smem_raw);
   unsigned bx, by;
   remap_xcd(bx, by);
-  const int e = by;
+  const int e = (int)by + J.e0;
   const Ctx ctx = job_ctx<MODE>(J, e);
   const long long L = ctx.L;
   const unsigned N1 = (unsigned)g.n1, N2 = 1u << g.log2n2;
@@ -523,7 +524,7 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   cd* lds = reinterpret_cast<cd*>(smem_raw);
   unsigned bx, by;
   remap_xcd(bx, by);
-  const int e = by;
+  const int e = (int)by + J.e0;
   const unsigned N2 = 1u << g.log2n2;
   const long long M = g.m;
   const unsigned r0 = bx * R;
@@ -605,7 +606,7 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   cd* lds = reinterpret_cast<cd*>(smem_raw);
   unsigned bx, by;
   remap_xcd(bx, by);
-  const int e = by;
+  const int e = (int)by + J.e0;
   // the job's length and output offsets, once (scalar registers; see Ctx)
   long long L, out1, out2 = -1;
   bool paired = false;
@@ -815,9 +816,18 @@ int32_t run_convolution(const Plan& p, const Jobs& J, cd* work, int nb, hipStrea
   IRA_TRY_HIP(allow_lds(cols_fwd_kernel<IN>, p.lds_cols));
   IRA_TRY_HIP(allow_lds(rows_kernel<ROW_CONV>, p.lds_rows));
   IRA_TRY_HIP(allow_lds(cols_inv_kernel<OUT>, p.lds_cols3));
-  cols_fwd_kernel<IN><<<dim3(N2 / p.C, nb), FL_THREADS, p.lds_cols, st>>>(p.g, J, work, p.C);
-  rows_kernel<ROW_CONV><<<dim3(N1 / p.R, nb), FL_THREADS, p.lds_rows, st>>>(p.g, J, work, p.R);
-  cols_inv_kernel<OUT><<<dim3(N2 / p.C3, nb), FL_THREADS, p.lds_cols3, st>>>(p.g, J, work, p.C3);
+  // IRA_FFT_CHUNK (tuning): the three passes over sub-ranges of the jobs, so that a sub-range's work arrays (16 M bytes per
+  // job, written by one pass and read by the next) may stay in the 256 MB Infinity Cache.  0 = one launch per pass.
+  int chunk = ira_tune_int("IRA_FFT_CHUNK", 0);
+  if (chunk <= 0 || chunk > nb) chunk = nb;
+  Jobs Jc = J;
+  for (int j0 = 0; j0 < nb; j0 += chunk) {
+    const int cnt = nb - j0 < chunk ? nb - j0 : chunk;
+    Jc.e0 = j0;
+    cols_fwd_kernel<IN><<<dim3(N2 / p.C, cnt), FL_THREADS, p.lds_cols, st>>>(p.g, Jc, work, p.C);
+    rows_kernel<ROW_CONV><<<dim3(N1 / p.R, cnt), FL_THREADS, p.lds_rows, st>>>(p.g, Jc, work, p.R);
+    cols_inv_kernel<OUT><<<dim3(N2 / p.C3, cnt), FL_THREADS, p.lds_cols3, st>>>(p.g, Jc, work, p.C3);
+  }
   IRA_RETURN_LAUNCH();
 }
 
