@@ -16,10 +16,16 @@ ap.add_argument("--block", default="modal")
 ap.add_argument("--batch", type=int, default=64); ap.add_argument("--seconds", type=float, default=10.0)
 ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--no-fused-split", action="store_true")
+ap.add_argument("--no-band-pairs", action="store_true", help="every band a half-length inverse of its own (A/B)")
+ap.add_argument("--no-sparse-bands", action="store_true")
 a = ap.parse_args()
 eng = Engine("cuda:0")
 eng.num_lanes = 1
 eng.fuse_half_split = not a.no_fused_split
+if a.no_band_pairs:
+    eng.pair_real_ffts = False
+if a.no_sparse_bands:
+    eng.sparse_bands = False
 n = int(a.seconds * 48000)
 host = np.stack([synth_ir(i, 0, n) for i in range(a.batch)])
 b = eng.wrap(eng.to_dev(host.reshape(-1)), np.arange(a.batch, dtype=np.int64) * n, np.full(a.batch, n, np.int64))
