@@ -288,7 +288,10 @@ class Engine:
         if self.num_lanes <= 1:
             return None
         if self._lanes is None or len(self._lanes) != self.num_lanes:
-            self._lanes = tuple(self.torch.cuda.Stream(device=self.device) for _ in range(self.num_lanes))
+            # IRA_LANE_PRIO (A/B only), e.g. "-1,0": HIP stream priorities of the lanes (lower = served first)
+            prio = [int(v) for v in os.environ.get("IRA_LANE_PRIO", "").split(",") if v.strip()]
+            self._lanes = tuple(self.torch.cuda.Stream(device=self.device, priority=(prio[i] if i < len(prio) else 0))
+                                for i in range(self.num_lanes))
         return self._lanes
 
     def upload(self, channels: Sequence[np.ndarray]) -> ChannelBatch:
