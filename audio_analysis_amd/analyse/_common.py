@@ -27,6 +27,24 @@ def segment_bounds(n: int, peak: int, sample_rate_hz: int, trim_to_peak: bool, i
     return start, length
 
 
+def segment_bounds_batch(n: np.ndarray, peak: np.ndarray, sample_rate_hz: int, trim_to_peak: bool,
+                         ignore_leading_seconds: float, duration_seconds: Optional[float]) -> Tuple[np.ndarray, np.ndarray]:
+    """segment_bounds for arrays of lengths and peak indices (int64 in, int64 out): the same integer arithmetic, without a
+    Python call per channel (the metrics pipeline asks for 256 channels per step, several times)."""
+    n = np.asarray(n, dtype=np.int64)
+    peak = np.asarray(peak, dtype=np.int64)
+    start = peak.copy() if trim_to_peak else np.zeros_like(n)
+    length = n - peak if trim_to_peak else n.copy()
+    if ignore_leading_seconds > 0.0:
+        skip = int(round(float(ignore_leading_seconds) * float(sample_rate_hz)))
+        sk = np.maximum(0, np.minimum(skip, length))
+        start, length = start + sk, length - sk
+    if duration_seconds is not None:
+        keep = int(round(float(duration_seconds) * float(sample_rate_hz)))
+        length = np.maximum(0, np.minimum(keep, length))
+    return start, length
+
+
 def as_batch(channels: Sequence[np.ndarray]) -> Tuple[Engine, ChannelBatch]:
     eng = get_engine()
     return eng, eng.upload(list(channels))

@@ -151,18 +151,36 @@ def run_bundle_metrics(bundle_root: str | Path, settings=None, use_mono_downmix_
     pending = None                                   # group k-2: submitted step
     with ThreadPoolExecutor(max_workers=1, thread_name_prefix="ira-prefetch") as ahead:
         nxt_set = ahead.submit(host_half, groups[0]) if groups else None
+        import os as _os, time as _time
+        _tm = {} if _os.environ.get("IRA_BUNDLE_TIMING") else None      # diagnostics: host seconds per phase of the loop
+
+        def _lap(key, t0):
+            if _tm is not None:
+                _tm[key] = _tm.get(key, 0.0) + (_time.perf_counter() - t0)
+            return _time.perf_counter()
+
         for gi, names in enumerate(groups):
+            t0 = _time.perf_counter()
             tapset = nxt_set.result()
+            t0 = _lap("wait for the reader thread", t0)
             nxt_set = ahead.submit(host_half, groups[gi + 1]) if gi + 1 < len(groups) else None
             batch, lab = tapset.view(use_mono_downmix_for_stereo)
             labels += [(names[i], ch) for i, ch in lab]
+            t0 = _lap("view (upload + conversion enqueued)", t0)
             fr.prepare(batch)
+            t0 = _lap("prepare (peak pick started)", t0)
             if uploaded is not None:
                 handle = fr.submit(uploaded)
+                t0 = _lap("submit", t0)
                 if pending is not None:
                     rows.append(fr.finish(pending))
+                    t0 = _lap("finish", t0)
                 pending = handle
             uploaded = batch
+        if _tm is not None and groups:
+            import sys as _sys
+            print("[bundle] host ms per group: " + ", ".join(f"{k} {1e3 * v / len(groups):.2f}" for k, v in _tm.items()),
+                  file=_sys.stderr)
     if uploaded is not None:
         handle = fr.submit(uploaded)
         if pending is not None:

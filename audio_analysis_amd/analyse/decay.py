@@ -14,7 +14,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from ..engine import get_engine
-from ._common import segment_bounds, wav_channels
+from ._common import segment_bounds, segment_bounds_batch, wav_channels
 
 
 @dataclass(frozen=True)
@@ -93,11 +93,7 @@ def _decay_bounds(eng, batch, sample_rate_hz: int, settings: DecayAnalysisSettin
     """Time selection of decay.py:135-147 for every channel of the batch -> (starts, lens)."""
     n = batch.length
     peaks = eng.peaks(batch) if settings.trim_to_peak else np.zeros(batch.count, dtype=np.int64)
-    starts = np.empty(batch.count, dtype=np.int64)
-    lens = np.empty(batch.count, dtype=np.int64)
-    for i in range(batch.count):
-        starts[i], lens[i] = segment_bounds(int(n[i]), int(peaks[i]), sample_rate_hz, settings.trim_to_peak,
-                                            settings.ignore_leading_seconds, None)
+    starts, lens = segment_bounds_batch(n, peaks, sample_rate_hz, settings.trim_to_peak, settings.ignore_leading_seconds, None)
     if np.any(lens < 4):
         raise ValueError("Not enough samples after trimming/ignoring to compute EDC.")
     return starts, lens

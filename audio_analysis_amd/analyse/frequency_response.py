@@ -17,7 +17,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 from ..engine import get_engine
-from ._common import segment_bounds, wav_channels
+from ._common import segment_bounds, segment_bounds_batch, wav_channels
 
 
 @dataclass(frozen=True)
@@ -109,12 +109,8 @@ def selected_bin_range(nbins: int, step: float, lo_hz: float, hi_hz: float):
 def spectrum_segments(eng, batch, sample_rate_hz: int, settings, what: str):
     """Time selection for fr / filter -> (starts, lens)."""
     peaks = eng.peaks(batch) if settings.trim_to_peak else np.zeros(batch.count, dtype=np.int64)
-    starts = np.empty(batch.count, dtype=np.int64)
-    lens = np.empty(batch.count, dtype=np.int64)
-    for i in range(batch.count):
-        starts[i], lens[i] = segment_bounds(int(batch.length[i]), int(peaks[i]), sample_rate_hz,
-                                            settings.trim_to_peak, settings.ignore_leading_seconds,
-                                            settings.analysis_duration_seconds)
+    starts, lens = segment_bounds_batch(batch.length, peaks, sample_rate_hz, settings.trim_to_peak,
+                                        settings.ignore_leading_seconds, settings.analysis_duration_seconds)
     if np.any(lens < 32):
         raise ValueError(f"Not enough samples after trimming/selection to analyse {what}.")
     return starts, lens

@@ -161,8 +161,9 @@ def modal_cloud_device(eng, batch, sample_rate_hz: int, settings: ModalCloudAnal
                                              frame_major=tf)
         curves, cur_off = eng.logbin_aggregate(mag, mag_off, cols, k_base, first, count,
                                                frame_major_rows=(n_fft // 2 + 1) if tf else 0)
-    c_off = np.concatenate([cur_off[i] + np.arange(nbins, dtype=np.int64) * int(cols[i]) for i in range(batch.count)])
-    c_len = np.concatenate([np.full(nbins, int(cols[i]), dtype=np.int64) for i in range(batch.count)])
+    cols64 = np.asarray(cols, dtype=np.int64)
+    c_off = (np.asarray(cur_off, dtype=np.int64)[:, None] + np.arange(nbins, dtype=np.int64)[None, :] * cols64[:, None]).reshape(-1)
+    c_len = np.repeat(cols64, nbins)
     fits, _ = eng.curve_fits(curves, c_off, c_len, float(hop), float(sample_rate_hz),
                              [(hi_db, max(lo_db, float(settings.fit_lower_limit_db)))], int(settings.min_fit_points),
                              rel_to_peak=True, floor_db=float(settings.floor_db),

@@ -238,37 +238,32 @@ def rt60_bands_device(eng, batch, sample_rate_hz: int, settings: Rt60BandsAnalys
     # forward spectra of the full files
     spec, spec_off = eng.rfft_any(batch.x, batch.off, n_all, use_hann=False)
 
-    # band signals: y[c][b] has n_c float32 samples
-    y_off = np.zeros((nch, max(nb, 1)), dtype=np.int64)
-    pos = 0
-    for c in range(nch):
-        for b in range(nb):
-            y_off[c, b] = pos
-            pos += int(n_all[c])
+    # band signals: y[c][b] has n_c float32 samples, channel after channel, band after band
+    # (array arithmetic instead of nested Python loops over 256 channels x bands: the loops were ~2 ms of the host's ~6 ms
+    # per report step, which is what bounds the bundle configuration -- its kernels take less time than its host code)
+    n64 = n_all.astype(np.int64)
+    per_entry = np.repeat(n64, nb)
+    y_off = (np.cumsum(per_entry) - per_entry).reshape(nch, nb) if nb else np.zeros((nch, 1), dtype=np.int64)
+    pos = int(per_entry.sum())
     y = eng.empty(pos, t.float32)
     if nb:
         # one entry per (channel, band); the engine pairs entries of equal length two per inverse transform
-        el_spec, el_len, el_par, el_fv, el_y = [], [], [], [], []
-        for c in range(nch):
-            fv = rfft_bin_step(int(n_all[c]), sample_rate_hz)
-            for b in range(nb):
-                el_spec.append(spec_off[c]); el_len.append(int(n_all[c])); el_fv.append(fv)
-                el_par.append(records[b]); el_y.append(y_off[c, b])
-        eng.band_irfft(spec, np.array(el_spec, np.int64), np.array(el_len, np.int32), np.stack(el_par),
-                       np.array(el_fv, np.float64), y, np.array(el_y, np.int64))
+        fv_of = {int(v): rfft_bin_step(int(v), sample_rate_hz) for v in np.unique(n64)}
+        fv = np.array([fv_of[int(v)] for v in n64], dtype=np.float64)
+        eng.band_irfft(spec, np.repeat(np.asarray(spec_off, dtype=np.int64), nb), np.repeat(n64, nb).astype(np.int32),
+                       np.tile(records, (nch, 1)), np.repeat(fv, nb), y, y_off.reshape(-1))
 
     # Schroeder EDC + fits on every (channel, band) tail with at least 8 samples
-    seg_c, seg_b, seg_off, seg_len = [], [], [], []
-    for c in range(nch):
-        tail = int(n_all[c] - start[c])
-        if tail < 8:
-            continue
-        for b in range(nb):
-            seg_c.append(c); seg_b.append(b); seg_off.append(y_off[c, b] + int(start[c])); seg_len.append(tail)
+    tail_c = n64 - start.astype(np.int64)
+    keep = np.nonzero(tail_c >= 8)[0]
+    seg_c = np.repeat(keep, nb)
+    seg_b = np.tile(np.arange(nb, dtype=np.int64), keep.size)
+    seg_off = (y_off[seg_c, seg_b] + start.astype(np.int64)[seg_c]) if seg_c.size else np.zeros(0, np.int64)
+    seg_len = tail_c[seg_c]
     values = np.full((nch, max(nb, 1), 3), np.nan)
     have = np.zeros((nch, max(nb, 1)), dtype=bool)
-    if seg_c:
-        seg_off_a, seg_len_a = np.array(seg_off, np.int64), np.array(seg_len, np.int64)
+    if seg_c.size:
+        seg_off_a, seg_len_a = np.asarray(seg_off, np.int64), np.asarray(seg_len, np.int64)
         if np.any(seg_len_a < 4):
             raise ValueError("Not enough samples after trimming/ignoring to compute EDC.")
         if smooth > 1:
@@ -284,7 +279,7 @@ def rt60_bands_device(eng, batch, sample_rate_hz: int, settings: Rt60BandsAnalys
             # rt60bands.py:272-321), so it is never written
             fit_dev, _, _, _ = eng.edc_fits(y, seg_off_a, seg_len_a, dec.edc_epsilon, dec.edc_floor_db, 1.0,
                                             float(sample_rate_hz), ranges, 8)
-        ci, bi = np.array(seg_c), np.array(seg_b)
+        ci, bi = seg_c, seg_b
         have[ci, bi] = True
 
         fut = eng.fetch(fit_dev) if defer else None

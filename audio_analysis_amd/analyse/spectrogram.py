@@ -15,7 +15,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 from ..engine import get_engine
-from ._common import frame_time_axis, segment_bounds, wav_channels
+from ._common import frame_time_axis, segment_bounds, segment_bounds_batch, wav_channels
 
 
 @dataclass(frozen=True)
@@ -62,12 +62,8 @@ def select_stft_segments(eng, batch, sample_rate_hz: int, settings, what: str):
     # any positive frame size, like the reference (numpy.fft.rfft): powers of two in [64, 16384] run on the STFT kernels,
     # everything else on the arbitrary-length transforms (Engine._stft_generic)
     peaks = eng.peaks(batch) if settings.trim_to_peak else np.zeros(batch.count, dtype=np.int64)
-    starts = np.empty(batch.count, dtype=np.int64)
-    lens = np.empty(batch.count, dtype=np.int64)
-    for i in range(batch.count):
-        starts[i], lens[i] = segment_bounds(int(batch.length[i]), int(peaks[i]), sample_rate_hz,
-                                            settings.trim_to_peak, settings.ignore_leading_seconds,
-                                            settings.analysis_duration_seconds)
+    starts, lens = segment_bounds_batch(batch.length, peaks, sample_rate_hz, settings.trim_to_peak,
+                                        settings.ignore_leading_seconds, settings.analysis_duration_seconds)
     if np.any(lens < n_fft):
         raise ValueError(f"Not enough samples after trimming/selection for {what} (need at least n_fft).")
     nframes = (1 + (lens - n_fft) // hop).astype(np.int32)

@@ -60,7 +60,10 @@ def _to_complex(roots_dev, counts_dev) -> List[np.ndarray]:
     """roots/counts: device tensors, or HostFutures from Engine.fetch (deferred path)."""
     r = roots_dev.get() if hasattr(roots_dev, "get") else roots_dev.cpu().numpy()
     c = counts_dev.get() if hasattr(counts_dev, "get") else counts_dev.cpu().numpy()
-    return [(r[i, : c[i], 0] + 1j * r[i, : c[i], 1]).astype(np.complex128) for i in range(r.shape[0])]
+    z = np.empty(r.shape[:2], dtype=np.complex128)                     # one pass over the record, then views per element
+    z.real = r[:, :, 0]
+    z.imag = r[:, :, 1]
+    return [z[i, : c[i]] for i in range(r.shape[0])]
 
 
 def _fit_ar_least_squares(x: np.ndarray, order: int, ridge_lambda: float = 0.0) -> np.ndarray:

@@ -788,23 +788,50 @@ class Engine:
 
     @staticmethod
     def _pair_by_key(idx: np.ndarray, keys: np.ndarray):
-        """Pairs of entries of idx whose keys are equal; leftovers are paired with -1.  Order-stable."""
-        first, second = [], []
+        """Pairs of entries of idx whose keys are equal; leftovers are paired with -1.  Order-stable.
+        (Array arithmetic: run lengths of the sorted keys, even positions of a run lead a pair -- the metrics pipeline calls
+        this for 256 channels per step, and a Python loop per entry was part of what bounds the bundle configuration.)"""
+        idx = np.asarray(idx, dtype=np.int64)
+        if idx.size == 0:
+            return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
         order = idx[np.argsort(keys[idx], kind="stable")]
-        i = 0
-        while i < order.size:
-            if i + 1 < order.size and keys[order[i]] == keys[order[i + 1]]:
-                first.append(order[i]); second.append(order[i + 1]); i += 2
-            else:
-                first.append(order[i]); second.append(-1); i += 1
-        return np.asarray(first, dtype=np.int64), np.asarray(second, dtype=np.int64)
+        sk = keys[order]
+        new_run = np.r_[True, sk[1:] != sk[:-1]]
+        run_start = np.flatnonzero(new_run)
+        run_id = np.cumsum(new_run) - 1
+        pos = np.arange(order.size) - run_start[run_id]                  # position inside the run
+        run_len = np.diff(np.r_[run_start, order.size])[run_id]
+        lead = (pos % 2) == 0
+        has_partner = lead & (pos + 1 < run_len)
+        first = order[lead]
+        nxt = np.r_[order[1:], -1]
+        second = np.where(has_partner, nxt, -1)[lead]
+        return first.astype(np.int64), second.astype(np.int64)
 
     @staticmethod
     def _pair_bands(keys: np.ndarray, width: np.ndarray):
         """Like _pair_by_key over all entries, but a group of odd size leaves its entry of smallest `width` alone (the first
         of them on a tie) and pairs the others in order."""
-        first, second = [], []
         order = np.argsort(keys, kind="stable")
+        sk = keys[order]
+        starts = np.flatnonzero(np.r_[True, sk[1:] != sk[:-1]]) if order.size else np.zeros(0, dtype=np.int64)
+        sizes = np.diff(np.r_[starts, order.size])
+        if order.size and np.all(sizes == sizes[0]):
+            # every group has the same size (every channel of a report has the same bands): array arithmetic, same output
+            # order as the loop below (a group's pairs, then its lone entry)
+            g, sz = int(starts.size), int(sizes[0])
+            grp = order.reshape(g, sz)
+            if sz % 2 == 0:
+                return grp[:, 0::2].reshape(-1).astype(np.int64), grp[:, 1::2].reshape(-1).astype(np.int64)
+            lone_pos = np.argmin(width[grp], axis=1)                     # the first minimum, like argmin over the group
+            keep = np.ones((g, sz), dtype=bool)
+            keep[np.arange(g), lone_pos] = False
+            rest = grp[keep].reshape(g, sz - 1)
+            lone = grp[np.arange(g), lone_pos][:, None]
+            first = np.concatenate([rest[:, 0::2], lone], axis=1).reshape(-1)
+            second = np.concatenate([rest[:, 1::2], np.full((g, 1), -1, dtype=order.dtype)], axis=1).reshape(-1)
+            return first.astype(np.int64), second.astype(np.int64)
+        first, second = [], []
         i = 0
         while i < order.size:
             j = i
