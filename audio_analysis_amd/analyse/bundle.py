@@ -137,8 +137,14 @@ def run_bundle_metrics(bundle_root: str | Path, settings=None, use_mono_downmix_
     rate = int(meta.get("sample_rate_hz", 48_000) or 48_000)
     groups = [mine[a : a + step] for a in range(0, len(mine), step)]
 
+    _rd = [0.0]
+
     def host_half(names):                            # headers + payload reads into pinned staging: no GPU call in here
-        return TapSet(eng, [root / "taps" / f"{t}.wav" for t in names], rate, upload=False)
+        import time as _t
+        t0 = _t.perf_counter()
+        ts = TapSet(eng, [root / "taps" / f"{t}.wav" for t in names], rate, upload=False)
+        _rd[0] += _t.perf_counter() - t0             # (diagnostics: IRA_BUNDLE_TIMING)
+        return ts
 
     # Three groups in flight.  While this thread works on groups k, k-1 and k-2, a worker thread reads group k+1 from
     # disk (the readers inside libira release the GIL); every GPU call stays on this thread:
@@ -179,8 +185,8 @@ def run_bundle_metrics(bundle_root: str | Path, settings=None, use_mono_downmix_
             uploaded = batch
         if _tm is not None and groups:
             import sys as _sys
-            print("[bundle] host ms per group: " + ", ".join(f"{k} {1e3 * v / len(groups):.2f}" for k, v in _tm.items()),
-                  file=_sys.stderr)
+            print("[bundle] host ms per group: " + ", ".join(f"{k} {1e3 * v / len(groups):.2f}" for k, v in _tm.items())
+                  + f"; reader thread busy {1e3 * _rd[0] / len(groups):.2f}", file=_sys.stderr)
     if uploaded is not None:
         handle = fr.submit(uploaded)
         if pending is not None:
