@@ -744,6 +744,7 @@ def main():
                     help="launch check without a GPU: every rank joins a gloo group, rank 0 prints the ranks it gathered "
                          "(tests/test_host_cpu.py runs `bench.py --gpus 2 --spawn-probe`)")
     a = ap.parse_args()
+    a.roofline_steps = max(1, a.roofline_steps)      # the bench line needs the serialised pass (roofline, per-call times)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a.gpus))
     if a.spawn_probe:
