@@ -9,6 +9,7 @@ torch.distributed initialised (one process per GPU) each rank analyses a contigu
 from __future__ import annotations
 
 import json
+import os
 from dataclasses import dataclass
 from pathlib import Path
 from typing import List, Optional
@@ -154,7 +155,10 @@ def run_bundle_metrics(bundle_root: str | Path, settings=None, use_mono_downmix_
     # so the GPU always holds one enqueued step while the host finishes another, and uploads overlap compute.
     from concurrent.futures import ThreadPoolExecutor
     uploaded = None                                  # group k-1: batch waiting for its peaks
-    pending = None                                   # group k-2: submitted step
+    pending = []                                     # group k-2 (and older): submitted steps whose records are on their way
+    # (IRA_BUNDLE_DEPTH submitted steps in flight before the oldest is read back: 2 or 3 were measured against 1 at the end
+    # of round 4 -- no gain, the loop is bound by the host's ~10 ms of work per 256 channels either way)
+    depth = max(1, int(os.environ.get("IRA_BUNDLE_DEPTH", "1")))
     with ThreadPoolExecutor(max_workers=1, thread_name_prefix="ira-prefetch") as ahead:
         nxt_set = ahead.submit(host_half, groups[0]) if groups else None
         import os as _os, time as _time
@@ -176,24 +180,20 @@ def run_bundle_metrics(bundle_root: str | Path, settings=None, use_mono_downmix_
             fr.prepare(batch)
             t0 = _lap("prepare (peak pick started)", t0)
             if uploaded is not None:
-                handle = fr.submit(uploaded)
+                pending.append(fr.submit(uploaded))
                 t0 = _lap("submit", t0)
-                if pending is not None:
-                    rows.append(fr.finish(pending))
+                if len(pending) > depth:
+                    rows.append(fr.finish(pending.pop(0)))
                     t0 = _lap("finish", t0)
-                pending = handle
             uploaded = batch
         if _tm is not None and groups:
             import sys as _sys
             print("[bundle] host ms per group: " + ", ".join(f"{k} {1e3 * v / len(groups):.2f}" for k, v in _tm.items())
                   + f"; reader thread busy {1e3 * _rd[0] / len(groups):.2f}", file=_sys.stderr)
     if uploaded is not None:
-        handle = fr.submit(uploaded)
-        if pending is not None:
-            rows.append(fr.finish(pending))
-        pending = handle
-    if pending is not None:
-        rows.append(fr.finish(pending))
+        pending.append(fr.submit(uploaded))
+    for handle in pending:
+        rows.append(fr.finish(handle))
     local = np.concatenate(rows, axis=0) if rows else np.zeros((0, METRICS_WIDTH))
     if not gather:                                   # this rank's (labels, records) only; the caller gathers
         return labels, local
