@@ -220,4 +220,101 @@ __device__ __forceinline__ void lds_fft_dit(cplx<T>* buf, int log2m, const cplx<
   }
 }
 
+// ---- the same decimation-in-time transform on an INTERLEAVED tile -------------------------------------------------------------
+// Layout [block][row][column]: nblk * 2^lc transforms of M points, element i of transform (blk, c) at
+// buf[((blk << log2m) + i) << lc | c] -- the order in which a tile of 2^lc adjacent columns ARRIVES when its rows are
+// fetched as contiguous pieces (LDS-DMA writes 64 lanes x 16 bytes contiguously, so a tile loaded by global_load_lds keeps
+// its arrival order; ira_fftlong.hip, cols_inv_glds_kernel).  Neighbouring lanes take neighbouring columns of the same
+// butterfly (contiguous 16-byte accesses).  Barriers are `lds_barrier()`: s_waitcnt lgkmcnt(0) + s_barrier, WITHOUT the
+// vmcnt(0) of __syncthreads(), so that LDS-DMA loads of the next tile stay in flight across the passes.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <typename T, int LR = 4, bool SPLIT = false>
+__device__ __forceinline__ void lds_fft_dit_rc(cplx<T>* buf, int log2m, const cplx<T>* __restrict__ tw, unsigned tw_per_m,
+                                               bool conj_tw, int tid, int nt, int nblk, int lc) {
+  constexpr int R = 1 << LR;
+  const unsigned M = 1u << log2m;
+  const unsigned half = (M * tw_per_m) >> 1;
+  const unsigned cm = (1u << lc) - 1u;
+  const int rem = log2m % LR;
+  int s = 0;
+  if (rem & 1) {
+    const unsigned per = M >> 1;
+    for (unsigned g = tid; g < ((per * (unsigned)nblk) << lc); g += nt) {
+      const unsigned c = g & cm, h = g >> lc, which = h >> (log2m - 1), b = h & (per - 1);
+      cplx<T>* p = buf + ((which << log2m) << lc) + c;
+      const cplx<T> a0 = p[(2 * b) << lc], a1 = p[(2 * b + 1) << lc];
+      p[(2 * b) << lc] = cadd(a0, a1);
+      p[(2 * b + 1) << lc] = csub(a0, a1);
+    }
+    lds_barrier();
+    s = 1;
+  }
+  while (s < rem) {
+    const unsigned q = 1u << s;
+    const int sS = s + 2;
+    const unsigned step = tw_per_m << (log2m - sS);
+    const unsigned per = M >> 2;
+    for (unsigned g = tid; g < ((per * (unsigned)nblk) << lc); g += nt) {
+      const unsigned c = g & cm, h = g >> lc, which = h >> (log2m - 2), b = h & (per - 1);
+      cplx<T>* p = buf + ((which << log2m) << lc) + c;
+      const unsigned j = b & (q - 1);
+      const unsigned base = ((b >> s) << sS) + j;
+      const cplx<T> a0 = p[base << lc];
+      cplx<T> t1 = p[(base + q) << lc], t2 = p[(base + 2 * q) << lc], t3 = p[(base + 3 * q) << lc];
+      if (j != 0) {
+        cplx<T> w1 = tw_get<T, SPLIT>(tw, j * step);
+        cplx<T> w2 = tw_get<T, SPLIT>(tw, 2 * j * step);
+        cplx<T> w3 = tw_lookup<T, SPLIT>(tw, 3 * j * step, half);
+        if (conj_tw) { w1.im = -w1.im; w2.im = -w2.im; w3.im = -w3.im; }
+        t1 = cmul(t1, w2);
+        t2 = cmul(t2, w1);
+        t3 = cmul(t3, w3);
+      }
+      const cplx<T> s01 = cadd(a0, t1), d01 = csub(a0, t1);
+      const cplx<T> s23 = cadd(t2, t3);
+      const cplx<T> d23 = conj_tw ? cmul_pi(csub(t2, t3)) : cmul_mi(csub(t2, t3));
+      p[base << lc] = cadd(s01, s23);
+      p[(base + q) << lc] = cadd(d01, d23);
+      p[(base + 2 * q) << lc] = csub(s01, s23);
+      p[(base + 3 * q) << lc] = csub(d01, d23);
+    }
+    lds_barrier();
+    s = sS;
+  }
+  while (s < log2m) {
+    const unsigned q = 1u << s;
+    const int sS = s + LR;
+    const unsigned step = tw_per_m << (log2m - sS);
+    const unsigned per = M >> LR;
+    for (unsigned g = tid; g < ((per * (unsigned)nblk) << lc); g += nt) {
+      const unsigned c = g & cm, h = g >> lc, which = h >> (log2m - LR), b = h & (per - 1);
+      cplx<T>* p = buf + ((which << log2m) << lc) + c;
+      const unsigned j = b & (q - 1);
+      const unsigned base = ((b >> s) << sS) + j;
+      cplx<T> u[R];
+#pragma unroll
+      for (int k = 0; k < R; ++k) u[k] = p[(base + brev_bits(k, LR) * q) << lc];
+      if (j != 0) {
+        cplx<T> w = tw_get<T, SPLIT>(tw, j * step);
+        if (conj_tw) w.im = -w.im;
+        twiddle_r<T, LR, false>(u, w);
+      }
+      if (conj_tw) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) u[k].im = -u[k].im;
+        dft_dif<T, R>(u);
+#pragma unroll
+        for (int n = 0; n < R; ++n) { cplx<T> r = u[brev_bits(n, LR)]; r.im = -r.im; p[(base + n * q) << lc] = r; }
+      } else {
+        dft_dif<T, R>(u);
+#pragma unroll
+        for (int n = 0; n < R; ++n) p[(base + n * q) << lc] = u[brev_bits(n, LR)];
+      }
+    }
+    lds_barrier();
+    s = sS;
+  }
+}
+
 }  // namespace ira

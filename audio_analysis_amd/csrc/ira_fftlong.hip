@@ -47,7 +47,7 @@ struct Geom {
   const cd* t2;  // exp(-2 pi i k / N2), k < N2
   const cd* tf;  // exp(-2 pi i k / M),  k < N2
   int ablate;    // diagnostics (IRA_FFT_ABLATE): 1 K1 plain input, 2 K1 no FFT, 4 K1 no store, 8 K2 no FFTs,
-                 // 16 K2 no filter multiply, 32 K3 no FFT, 64 K3 plain epilogue, 128 K2 no store, 256 K3 no load
+                 // 16 K2 no filter multiply, 32 K3 no FFT, 64 K3 plain epilogue, 128 K2 no store, 256 K3 no load, 512 K3 (LDS-DMA) no store
 };
 
 // LDS slot (inside one column) of column element / work-array row `r` < N1, and the column frequency k1 that row r of the
@@ -692,6 +692,170 @@ __global__ __launch_bounds__(FL_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// K3 with the register hop taken out of its memory phase (round 5): persistent workgroups, two LDS buffers, tiles fetched by
+// LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane straight into LDS, no data VGPRs, counted by vmcnt).  A workgroup walks
+// its share of the launch's (job, column tile) pairs; while tile t is transformed and written out, tile t + 1 lands in the
+// other buffer.  An LDS-DMA instruction writes its 64 x 16 bytes CONTIGUOUSLY, so the tile keeps its arrival order
+// [row][column] (rows of C adjacent columns = the contiguous pieces of the work array) and the transform runs on that
+// layout (lds_fft_dit_rc); no column padding.  Barriers inside the walk are lds_barrier() -- __syncthreads() would drain the
+// DMA.  Everything the compiler cannot see (the DMA and its waits) is inline assembly with a memory clobber.
+//   per tile:  s_waitcnt vmcnt(0) + barrier  (tile t landed, stores of tile t - 1 retired, every wave done with the other buffer)
+//              -> issue tile t + 1 -> inverse column transforms of tile t -> output chirp, epilogue, stores
+// grid: a multiple of 8 workgroups (XCD x owns a contiguous range of tiles, its workgroups walk it side by side).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ unsigned lds_address(const void* p) {
+  return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
+}
+
+template <bool INVERSE>
+__device__ __forceinline__ void radix3_stage_rc(const Geom& g, cd* buf, const cd* twl, int lc, int tid) {
+  const unsigned Q = 1u << g.log2q, half = (unsigned)g.n1 >> 1, cm = (1u << lc) - 1u, bs = Q << lc;
+  for (unsigned idx = tid; idx < (Q << lc); idx += FL_THREADS) {
+    const unsigned c = idx & cm, j = idx >> lc;
+    cd* p = buf + (j << lc) + c;
+    cd a0 = p[0], a1 = p[bs], a2 = p[2 * bs];
+    cd w1 = ira::tw_get<double, true>(twl, j);
+    cd w2 = ira::tw_lookup<double, true>(twl, 2u * j, half);
+    if (INVERSE) {
+      w1.im = -w1.im; w2.im = -w2.im;
+      a1 = ira::cmul(a1, w1);
+      a2 = ira::cmul(a2, w2);
+      a0.im = -a0.im; a1.im = -a1.im; a2.im = -a2.im;
+      bfly3(a0, a1, a2);
+      a0.im = -a0.im; a1.im = -a1.im; a2.im = -a2.im;
+    } else {
+      bfly3(a0, a1, a2);
+      if (j != 0) {
+        a1 = ira::cmul(a1, w1);
+        a2 = ira::cmul(a2, w2);
+      }
+    }
+    p[0] = a0; p[bs] = a1; p[2 * bs] = a2;
+  }
+  ira::lds_barrier();
+}
+
+struct K3Raw { int l; long long a, b, c; };          // a job's values as loaded (vector registers), and once uniform
+template <int MODE>
+__device__ __forceinline__ K3Raw k3_fetch(const Jobs& J, int e) {
+  K3Raw r;
+  r.l = J.L[e];
+  if (MODE == OUT_SPECTRUM) {
+    r.a = J.x2off ? (long long)J.x2off[e] : -1ll;
+    r.b = J.x2off ? (long long)J.zpair_off[e] : 0ll;
+    r.c = J.spec_out_off[e];
+  } else {
+    r.a = J.y1_off[e];
+    r.b = J.y2_off[e];
+    r.c = 0;
+  }
+  return r;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(FL_THREADS) void cols_inv_glds_kernel(Geom g, Jobs J, const cd* __restrict__ work, int lc,
+                                                                   unsigned tiles_per_job, unsigned total_tiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  cd* lds = reinterpret_cast<cd*>(smem_raw);
+  const unsigned N1 = (unsigned)g.n1, N2 = 1u << g.log2n2;
+  const long long M = g.m;
+  const unsigned cm = (1u << lc) - 1u;
+  const unsigned tile = N1 << lc;                                       // complex values per tile, a multiple of FL_THREADS
+  const int tid = threadIdx.x;
+  const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6), lane = (unsigned)tid & 63u;
+  cd* twl = lds + 2 * (size_t)tile;                                     // both DMA buffers below it (low LDS addresses)
+  const cd twv = ira::tw_split_fetch<double>(g.t1, N1 >> 1, tid);
+  // my tiles: XCD x = blockIdx % 8 owns tiles [t0, t0 + cnt), its workgroups take them round robin
+  const unsigned nx = gridDim.x >> 3, xcd = blockIdx.x & 7u, lw = blockIdx.x >> 3;
+  const unsigned tq = total_tiles >> 3, tr = total_tiles & 7u;
+  const unsigned t0 = xcd < tr ? xcd * (tq + 1u) : tr * (tq + 1u) + (xcd - tr) * tq, cnt = xcd < tr ? tq + 1u : tq;
+  const unsigned chunks = (tile >> 6) / 4u;                             // DMA instructions per wave and tile
+  const unsigned lds0 = lds_address(lds);
+  auto issue = [&](unsigned t, unsigned which) __attribute__((always_inline)) {
+    const unsigned e = t / tiles_per_job, bx = t - e * tiles_per_job;
+    const cd* src = work + (long long)e * M + (bx << lc) + (long long)((wave * 64u + lane) >> lc) * N2 + (lane & cm);
+    const long long step = (long long)(256u >> lc) * N2;                // rows between a wave's consecutive pieces
+    unsigned dst = lds0 + which * tile * 16u + wave * 1024u;
+    if (IRA_ABL(g.ablate & 256)) return;
+    for (unsigned u = 0; u < chunks; ++u) {
+      glds16(src, dst);
+      src += step;
+      dst += 4096u;
+    }
+  };
+  ira::tw_split_put(twl, twv, tid);
+  K3Raw raw{};
+  if (lw < cnt) {
+    issue(t0 + lw, 0u);
+    raw = k3_fetch<MODE>(J, (int)((t0 + lw) / tiles_per_job) + J.e0);
+  }
+  const double inv_m = 1.0 / (double)M;
+  unsigned which = 0;
+  for (unsigned s = lw; s < cnt; s += nx, which ^= 1u) {
+    const unsigned t = t0 + s;
+    const unsigned e_rel = t / tiles_per_job, bx = t - e_rel * tiles_per_job;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");        // tile t has landed; the other buffer is free
+    asm volatile("" : "+v"(raw.l), "+v"(raw.a), "+v"(raw.b), "+v"(raw.c));      // first use of the job's values: after the wait
+    const long long L = ira::uniform(raw.l);
+    long long out1, out2 = -1;
+    bool paired = false;
+    if (MODE == OUT_SPECTRUM) {
+      paired = ira::uniform(raw.a) >= 0;
+      out1 = paired ? ira::uniform(raw.b) : ira::uniform(raw.c);
+    } else {
+      out1 = ira::uniform(raw.a);
+      out2 = ira::uniform(raw.b);
+    }
+    if (s + nx < cnt) {
+      issue(t + nx, which ^ 1u);
+      raw = k3_fetch<MODE>(J, (int)((t + nx) / tiles_per_job) + J.e0);
+    }
+    cd* buf = lds + (size_t)which * tile;
+    if (!(IRA_ABL(g.ablate & 32))) {
+      ira::lds_fft_dit_rc<double, FL_LR, true>(buf, g.log2q, twl, (unsigned)g.rad, true, tid, FL_THREADS, g.rad, lc);
+      if (g.rad == 3) radix3_stage_rc<true>(g, buf, twl, lc, tid);
+    }
+    const unsigned n2_0 = bx << lc;
+    const long long n_need = (MODE == OUT_SPECTRUM && !paired) ? L / 2 + 1 : L;
+    const long long dn = (long long)(FL_THREADS >> lc) * N2;
+    const long long n0 = (long long)((unsigned)tid >> lc) * N2 + n2_0 + ((unsigned)tid & cm);
+    const ChirpScale cs = chirp_scale(L);
+    const double n0d = (double)n0, dnd = (double)dn;
+    cd cw = unit_q(n0d * n0d, cs), cdl = unit_q(2.0 * n0d * dnd + dnd * dnd, cs);
+    const cd ce2 = unit_q(2.0 * dnd * dnd, cs);
+    for (unsigned i = tid; i < tile; i += FL_THREADS) {
+      const long long n = (long long)(i >> lc) * N2 + n2_0 + (i & cm);
+      const cd wn = cw;
+      cw = ira::cmul(cw, cdl);
+      cdl = ira::cmul(cdl, ce2);
+      if (n >= n_need) continue;
+      cd v = buf[i];
+      if (!(IRA_ABL(g.ablate & 64))) v = ira::cmul(v, wn);
+      if ((IRA_ABL(g.ablate & 512)) && v.re != 12345.678) continue;
+      if (MODE == OUT_SPECTRUM) {
+        v.re *= inv_m; v.im *= inv_m;
+        if (paired) {
+          J.zpair[out1 + n] = v;
+        } else {
+          if (n == 0 || (2 * n == L)) v.im = 0.0;
+          J.spec_out[out1 + n] = v;
+        }
+      } else {
+        const double sc = inv_m / (double)L;
+        J.y[out1 + n] = (float)(v.re * sc);
+        if (out2 >= 0) J.y[out2 + n] = (float)(-v.im * sc);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // Two real signals per transform: with Z = DFT(x1 + i x2),
 //   X1[k] = (Z[k] + conj Z[L-k]) / 2,   X2[k] = (Z[k] - conj Z[L-k]) / (2i),   k = 0 .. L/2.
 // k = 0 and k = L/2 pair a bin with itself, so their imaginary parts come out exactly zero like numpy's rfft.
@@ -751,6 +915,7 @@ bool split_of(long long m, Split* out) {
   } else {
     if (log2p < 5) return false;                // M >= 96
     lq = (log2p - 1) / 2;                       // N1 = 3 * 2^lq just below N2: 768 x 1024 at M = 3 * 2^18
+    { const int forced = ira_tune_int("IRA_FFT_SPLIT3", 0); if (forced >= 2 && forced <= log2p - 2) lq = forced; }
     if (log2p - lq > 13) lq = log2p - 13;
   }
   out->rad = rad; out->log2q = lq; out->log2n2 = log2p - lq;
@@ -762,6 +927,7 @@ struct Plan {
   int C, R;
   size_t lds_cols, lds_rows;
   int C3; size_t lds_cols3;          // the inverse column pass may take its own tile width (tuning: IRA_FFT_C3)
+  int glds_lc; size_t lds_glds;      // K3 by LDS-DMA (cols_inv_glds_kernel): log2 of its tile width, or -1 where it does not apply
 };
 
 int32_t make_plan(int32_t m, const void* t1, const void* t2, const void* tf, Plan* p) {
@@ -794,6 +960,22 @@ int32_t make_plan(int32_t m, const void* t1, const void* t2, const void* tf, Pla
   { const int v = ira_tune_int("IRA_FFT_C3", 0); if (v >= 1 && v <= N2 && v <= 64 && (v & (v - 1)) == 0) p->C3 = v; }
   p->lds_cols3 = ((size_t)p->C3 * col + ira::TW_SPLIT_ENTRIES) * sizeof(cd);
   p->lds_rows = ((size_t)R * N2 + ira::TW_SPLIT_ENTRIES) * sizeof(cd);
+  // K3 by LDS-DMA: two unpadded buffers of N1 x C values below 64 KB of LDS (the DMA's destination register), whole
+  // 1 KB pieces per wave (tile a multiple of FL_THREADS values), a radix the in-LDS transform can split (log2q >= 2)
+  p->glds_lc = -1; p->lds_glds = 0;
+  {
+    int c = C;
+    { const int v = ira_tune_int("IRA_FFT_CG", 0); if (v >= 1 && v <= N2 && v <= 64 && (v & (v - 1)) == 0) c = v; }
+    while (c > 1 && 2 * (size_t)c * N1 * sizeof(cd) > 64 * 1024) c >>= 1;
+    const size_t tile = (size_t)c * N1;
+    if (ira_tune_int("IRA_FFT_GLDS", 0) != 0 && 2 * tile * sizeof(cd) <= 64 * 1024 && tile % FL_THREADS == 0 && N2 % c == 0 &&
+        sp.log2q >= 2) {
+      int lc = 0;
+      while ((1 << lc) < c) ++lc;
+      p->glds_lc = lc;
+      p->lds_glds = (2 * tile + ira::TW_SPLIT_ENTRIES) * sizeof(cd);
+    }
+  }
   return IRA_OK;
 }
 
@@ -816,6 +998,17 @@ int32_t run_convolution(const Plan& p, const Jobs& J, cd* work, int nb, hipStrea
   IRA_TRY_HIP(allow_lds(cols_fwd_kernel<IN>, p.lds_cols));
   IRA_TRY_HIP(allow_lds(rows_kernel<ROW_CONV>, p.lds_rows));
   IRA_TRY_HIP(allow_lds(cols_inv_kernel<OUT>, p.lds_cols3));
+  int cus = 256, per_cu = 2;
+  if (p.glds_lc >= 0) {
+    // persistent grid: as many workgroups as are resident at once (no state kept: asked of the runtime on every call)
+    IRA_TRY_HIP(allow_lds(cols_inv_glds_kernel<OUT>, p.lds_glds));
+    int dev = 0;
+    IRA_TRY_HIP(hipGetDevice(&dev));
+    IRA_TRY_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    IRA_TRY_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cols_inv_glds_kernel<OUT>, FL_THREADS, p.lds_glds));
+    { const int v = ira_tune_int("IRA_FFT_GLDS_WG", 0); if (v >= 1 && v < per_cu) per_cu = v; }
+    if (per_cu < 1) per_cu = 1;
+  }
   // IRA_FFT_CHUNK (tuning): the three passes over sub-ranges of the jobs, so that a sub-range's work arrays (16 M bytes per
   // job, written by one pass and read by the next) may stay in the 256 MB Infinity Cache.  0 = one launch per pass.
   int chunk = ira_tune_int("IRA_FFT_CHUNK", 0);
@@ -826,7 +1019,14 @@ int32_t run_convolution(const Plan& p, const Jobs& J, cd* work, int nb, hipStrea
     Jc.e0 = j0;
     cols_fwd_kernel<IN><<<dim3(N2 / p.C, cnt), FL_THREADS, p.lds_cols, st>>>(p.g, Jc, work, p.C);
     rows_kernel<ROW_CONV><<<dim3(N1 / p.R, cnt), FL_THREADS, p.lds_rows, st>>>(p.g, Jc, work, p.R);
-    cols_inv_kernel<OUT><<<dim3(N2 / p.C3, cnt), FL_THREADS, p.lds_cols3, st>>>(p.g, Jc, work, p.C3);
+    if (p.glds_lc >= 0) {
+      const unsigned tiles_per_job = (unsigned)(N2 >> p.glds_lc), total = tiles_per_job * (unsigned)cnt;
+      unsigned grid = (unsigned)(cus * per_cu) & ~7u;
+      if (grid > ((total + 7u) & ~7u)) grid = (total + 7u) & ~7u;
+      cols_inv_glds_kernel<OUT><<<dim3(grid), FL_THREADS, p.lds_glds, st>>>(p.g, Jc, work, p.glds_lc, tiles_per_job, total);
+    } else {
+      cols_inv_kernel<OUT><<<dim3(N2 / p.C3, cnt), FL_THREADS, p.lds_cols3, st>>>(p.g, Jc, work, p.C3);
+    }
   }
   IRA_RETURN_LAUNCH();
 }

@@ -59,7 +59,7 @@ int main(int argc, char** argv) {
   printf("rows %d cols %d jobs %d: %.2f GB each way\n", rows, cols, jobs, n * 16 / 1e9);
   for (int mode = 0; mode < 3; ++mode)
     for (int lds_kb : {0, 20, 32, 48})
-      for (int C : {1, 2, 5, 10, 25}) {
+      for (int C : {1, 2, 4, 8, 5, 10, 25}) {
         if (cols % C) continue;
         for (int remap = 0; remap < 2; ++remap) {
           dim3 grid(cols / C, jobs);
