@@ -72,17 +72,24 @@ class HostBatch:
 
 class DeviceFeed:
     def __init__(self, eng: Engine, max_samples: int, depth: int = 4, pull: bool = False, pull_workgroups: int = 8,
-                 copy_streams: int = 2):
+                 copy_streams: int = 2, high_priority: bool = False):
         t = eng.torch
         self.eng = eng
+        prio = -1 if high_priority else 0
         # copy_streams > 1: a batch crosses PCIe as that many pieces on that many streams (copy engines) at once; the
         # batch's ready event waits for all of them
-        self.side_streams = [t.cuda.Stream(device=eng.device) for _ in range(max(0, int(copy_streams) - 1))]
+        self._prio = prio
+        self._all_side = [t.cuda.Stream(device=eng.device, priority=prio) for _ in range(max(0, int(copy_streams) - 1))]
+        self.side_streams = list(self._all_side)
+        # timing: None, or a list that push() appends (bytes, [(start event, end event) per piece]) to -- HIP events on the
+        # copy streams themselves, so that a bench line can state how long a step's upload took UNDER the kernels of the
+        # step before it, and what the link does alone (upload_times())
+        self.timing = None
         self.split_bytes = 192 << 20                # smaller batches go as one copy (256 x 2 s = 98 MB: 137 k vs 96 k IRs/s)
         self.pull = bool(pull)                     # True: the batch crosses PCIe under ira_host_pull instead of hipMemcpyAsync
         self.pull_workgroups = int(pull_workgroups)
         self.depth = int(depth)
-        self.copy_stream = t.cuda.Stream(device=eng.device)
+        self.copy_stream = t.cuda.Stream(device=eng.device, priority=prio)
         self._x = [eng.empty(max_samples, t.float32) for _ in range(self.depth)]
         self._pcm = None
         self._max = int(max_samples)
@@ -96,11 +103,28 @@ class DeviceFeed:
         slot = self._k % self.depth
         self._k += 1
         x = self._x[slot]
+        marks = [] if self.timing is not None else None
+
+        def timed_copy(dst, src, stream):
+            """one piece: an asynchronous copy on `stream` (current), bracketed by events when the feed is being timed"""
+            if marks is None:
+                dst.copy_(src, non_blocking=True)
+                return
+            e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            dst.copy_(src, non_blocking=True)
+            e1.record(stream)
+            marks.append((e0, e1))
+
         with t.cuda.stream(self.copy_stream):
             done = False
             if self.pull:
                 # pull kernel: reads the pinned batch through the PCIe link itself and converts PCM16 on the way
                 # (ira_host_pull in include/ira.h)
+                ev = None
+                if marks is not None:
+                    ev = (t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True))
+                    ev[0].record(self.copy_stream)
                 rc = eng.lib.ira_host_pull(int(hb.pinned.data_ptr()), int(hb.total), 1 if hb.pcm16 else 0,
                                            int(x.data_ptr()), int(self.pull_workgroups), eng.stream)
                 if rc == -3:                                  # IRA_E_UNSUPPORTED: not mapped host memory
@@ -108,13 +132,16 @@ class DeviceFeed:
                 else:
                     check(rc, "ira_host_pull")
                     done = True
+                    if ev is not None:
+                        ev[1].record(self.copy_stream)
+                        marks.append(ev)
             if done:
                 pass
             elif hb.pcm16:
                 if self._pcm is None:
                     self._pcm = [eng.empty(self._max, t.int16) for _ in range(self.depth)]
                 pcm = self._pcm[slot]
-                pcm[: hb.total].copy_(hb.pinned[: hb.total], non_blocking=True)
+                timed_copy(pcm[: hb.total], hb.pinned[: hb.total], self.copy_stream)
                 # mono channels laid end to end convert like ONE mono file of `total` frames
                 check(eng.lib.ira_pcm16_to_channels(int(pcm.data_ptr()), int(hb.total), 1, 0, int(x.data_ptr()),
                                                     eng.stream), "ira_pcm16_to_channels")
@@ -127,14 +154,85 @@ class DeviceFeed:
                         continue
                     side.wait_stream(self.copy_stream)      # ordered behind whatever used this slot before
                     with t.cuda.stream(side):
-                        x[lo:hi].copy_(hb.pinned[lo:hi], non_blocking=True)
-                x[: min(step, hb.total)].copy_(hb.pinned[: min(step, hb.total)], non_blocking=True)
+                        timed_copy(x[lo:hi], hb.pinned[lo:hi], side)
+                timed_copy(x[: min(step, hb.total)], hb.pinned[: min(step, hb.total)], self.copy_stream)
                 for side in self.side_streams:
                     self.copy_stream.wait_stream(side)
             else:
-                x[: hb.total].copy_(hb.pinned[: hb.total], non_blocking=True)
+                timed_copy(x[: hb.total], hb.pinned[: hb.total], self.copy_stream)
             batch = eng.wrap(x, hb.off, hb.length)          # offsets/lengths + the ready event, all on the copy stream
+        if marks:
+            self.timing.append((hb.nbytes, marks))
         return batch
+
+    def set_mode(self, copy_streams: Optional[int] = None, pull: Optional[bool] = None) -> None:
+        """Change how the next batches cross the link: pieces per batch (copy engines), or the pull kernel."""
+        t = self.eng.torch
+        if pull is not None:
+            self.pull = bool(pull)
+        if copy_streams is not None:
+            want = max(0, int(copy_streams) - 1)
+            while len(self._all_side) < want:
+                self._all_side.append(t.cuda.Stream(device=self.eng.device, priority=self._prio))
+            self.side_streams = self._all_side[:want]
+
+    def mode(self) -> str:
+        return "pull kernel" if self.pull else f"copy engine, {len(self.side_streams) + 1} piece(s)"
+
+    def autotune(self, run_steps: Callable[[int], float], alone_GBps: Optional[float], steps: int = 4,
+                 accept: float = 0.75):
+        """
+        Pick the upload method on THIS box, under THIS job's kernels (untimed warm-up work, like a transform plan).  Why: the
+        same build uploads a 492 MB batch at 55 GB/s under the report's kernels on one MI355X box and at 26 GB/s on another
+        (and at 26 GB/s on the first one as four pieces): whether an asynchronous copy rides a DMA engine or falls back to a
+        copy kernel that queues behind the analysis kernels is the runtime's choice per stream, and it differs between hosts
+        (profiles/r05_upload_ab.txt).  run_steps(n) must run n pipelined steps through this feed and return their wall
+        seconds.  Arms, in order: two pieces (the default), one piece, the pull kernel.  The first copy-engine arm whose
+        rate UNDER the kernels reaches `accept` x the link's rate alone is kept without trying the rest; otherwise the arm
+        with the shortest step wins.  Returns the list of arms tried (mode, ms per step, upload ms, GB/s) for the bench line.
+        """
+        tried = []
+        for streams, pull in ((2, False), (1, False), (2, True)):
+            self.set_mode(copy_streams=streams, pull=pull)
+            run_steps(1)
+            self.eng.sync()
+            self.timing = []
+            dt = run_steps(steps)
+            self.eng.sync()
+            up = self.upload_times()
+            self.timing = None
+            tried.append({"mode": self.mode(), "ms_per_step": 1e3 * dt / steps,
+                          "upload_ms": None if up is None else up["ms_per_upload"],
+                          "upload_GBps": None if up is None else up["GBps"], "_set": (streams, pull)})
+            if up is not None and alone_GBps and up["GBps"] >= accept * alone_GBps:
+                break
+        best = min(tried, key=lambda r: r["ms_per_step"])
+        self.set_mode(copy_streams=best["_set"][0], pull=best["_set"][1])
+        for r in tried:
+            r["chosen"] = r is best
+            r.pop("_set")
+        return tried
+
+    def upload_times(self):
+        """Reduce and clear the timing list (call after a device synchronisation): per upload the time from the start of
+        its first piece to the end of its last (ms) and its bytes; also the span from the first upload's start to the last
+        upload's end, i.e. how much of that stretch the copy engines were busy."""
+        rec, self.timing = self.timing or [], []
+        if not rec:
+            return None
+        first = rec[0][1][0][0]
+        spans, nbytes, t_end = [], [], 0.0
+        for b, marks in rec:
+            starts = [first.elapsed_time(e0) for e0, _ in marks]
+            ends = [first.elapsed_time(e1) for _, e1 in marks]
+            spans.append(max(ends) - min(starts))
+            nbytes.append(b)
+            t_end = max(t_end, max(ends))
+        tot_ms, tot_b = float(sum(spans)), float(sum(nbytes))
+        return {"uploads": len(rec), "pieces_per_upload": len(rec[0][1]), "bytes_per_upload": tot_b / len(rec),
+                "ms_per_upload": tot_ms / len(rec), "ms_per_upload_max": float(max(spans)),
+                "GBps": tot_b / tot_ms / 1e6 if tot_ms > 0 else None,
+                "busy_fraction_of_stretch": tot_ms / t_end if t_end > 0 else None}
 
 
 def run_pipelined(report, feed: DeviceFeed, host_batches: Iterable[HostBatch],

@@ -730,13 +730,17 @@ def main():
     ap.add_argument("--literal-steps", type=int, default=10,
                     help="config report only: extra steps with the reference's default-on group-delay and diffusion "
                          "blocks added (reported as literal_full_report; 0 = skip)")
-    ap.add_argument("--upload", default="copy", choices=["pull", "copy"],
-                    help="pull: the batch crosses PCIe under a pull kernel (ira_host_pull); copy: hipMemcpyAsync on the copy engine")
+    ap.add_argument("--upload", default="auto", choices=["auto", "pull", "copy"],
+                    help="pull: the batch crosses PCIe under a pull kernel (ira_host_pull); copy: hipMemcpyAsync on the copy "
+                         "engines, --upload-streams pieces; auto: copy, unless the warm-up finds the copies starved under the "
+                         "kernels on this box (DeviceFeed.autotune: then one piece or the pull kernel, whichever steps fastest)")
     ap.add_argument("--pull-workgroups", type=int, default=8)
     ap.add_argument("--upload-streams", type=int, default=2,
                     help="float32 / int16 upload as this many pieces on as many copy streams (A/B)")
-    ap.add_argument("--variants", default="all", choices=["all", "value"],
-                    help="'value' skips the int16 / resident variants (profiling runs)")
+    ap.add_argument("--upload-priority", action="store_true", help="copy streams created with high priority (A/B)")
+    ap.add_argument("--variants", default="all", choices=["all", "value", "resident"],
+                    help="'value' skips the int16 / resident variants (profiling runs); 'resident' runs the headline and the "
+                         "resident-input variant only (upload A/B runs)")
     ap.add_argument("--gather", default="final", choices=["final", "step"],
                     help="final: the records of every step stay on their rank and ONE gather to rank 0 closes the timed "
                          "region (north star: a single RCCL gather for the final metrics); step: one gather per step (A/B)")
@@ -836,7 +840,7 @@ def main():
     del chans
     note(f"{K} host batches of {B} x {seconds:g} s synthesised and pinned")
     feed = DeviceFeed(eng, B * n, depth=4, pull=(a.upload == "pull"), pull_workgroups=a.pull_workgroups,
-                      copy_streams=a.upload_streams)
+                      copy_streams=a.upload_streams, high_priority=a.upload_priority)
     last = {}
     kept = []                                          # this rank's records of the steps since the last flush
     counters = {"steps": 0}
@@ -874,15 +878,36 @@ def main():
     run_fed(K, host_f32)
     run_fed(a.warmup, host_f32)
     D.barrier(); torch.cuda.synchronize()
+    # the link alone: three uploads of a batch with nothing else on the GPU, HIP events on the copy streams (DeviceFeed.timing)
+    feed.timing = []
+    for k in range(3):
+        feed.push(host_f32[k % K])
+        torch.cuda.synchronize()
+    upload_alone = feed.upload_times()
+    upload_tuning = None
+    if a.upload == "auto":
+        def tune_steps(c):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_fed(c, host_f32)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+        upload_tuning = feed.autotune(tune_steps, upload_alone["GBps"] if upload_alone else None)
+        note("upload: " + "; ".join(f"{r['mode']} {r['ms_per_step']:.2f} ms/step" + (" (chosen)" if r["chosen"] else "") for r in upload_tuning))
+        flush()
+        D.barrier(); torch.cuda.synchronize()
     eng.events = []
+    feed.timing = []                                   # ... and under the kernels of the timed region
     elapsed = timed(lambda c: run_fed(c, host_f32), steps)
+    upload_timed = feed.upload_times()
+    feed.timing = None
     ev_timed = eng.collect_events()
     eng.events = None
     gathered = last.get("g")
     note(f"timed region: {steps} steps in {elapsed:.3f} s = {B * world * steps / elapsed:.0f} IRs/s")
 
     el_pull = None
-    if a.variants == "all" and a.upload == "copy":
+    if a.variants == "all" and a.upload != "pull" and not feed.pull:
         feed.pull = True                               # A/B: the same steps with the pull-kernel upload (ira_host_pull)
         run_fed(2, host_f32)
         el_pull = timed(lambda c: run_fed(c, host_f32), steps)
@@ -890,9 +915,10 @@ def main():
     # ---- variants: int16 upload; inputs resident in HBM (rotating over the K device-resident batches) ----------------------
     el_i16 = el_res = None
     resident = None
-    if a.variants == "all":
-        run_fed(2, host_i16)
-        el_i16 = timed(lambda c: run_fed(c, host_i16), steps)
+    if a.variants in ("all", "resident"):
+        if a.variants == "all":
+            run_fed(2, host_i16)
+            el_i16 = timed(lambda c: run_fed(c, host_i16), steps)
         resident = []
         for k in range(K):
             resident.append(eng.wrap(eng.to_dev(host_f32[k].pinned.numpy()[: B * n].copy()), host_f32[k].off, host_f32[k].length))
@@ -928,7 +954,7 @@ def main():
         el_cold = timed(lambda c: run_pipelined(report, feed, cold_batches(c), gather), steps)
         ev_cold = eng.collect_events()
         eng.events = None
-    note("variants done" + ("" if el_res is None else f": int16 {B * world * steps / el_i16:.0f}, resident {B * world * steps / el_res:.0f}, "
+    note("variants done" + ("" if el_cold is None else f": int16 {B * world * steps / el_i16:.0f}, resident {B * world * steps / el_res:.0f}, "
                                                       f"new lengths every step {B * world * steps / el_cold:.0f} IRs/s"))
     # ---- per-kernel durations: a short SERIALISED pass (one stream, kernels one at a time) in the same run ---------------
     lanes_used = eng.num_lanes
@@ -1031,12 +1057,15 @@ def main():
         "value_int16": None if el_i16 is None else total_irs / el_i16,
         "value_resident": None if el_res is None else total_irs / el_res,
         "value_pull_kernel": None if el_pull is None else total_irs / el_pull,
-        "upload": "pull kernel (ira_host_pull reads pinned host memory over PCIe)" if feed.pull else "hipMemcpyAsync on a copy stream",
+        "upload": "pull kernel (ira_host_pull reads pinned host memory over PCIe)" if feed.pull else
+                  f"hipMemcpyAsync, {len(feed.side_streams) + 1} piece(s) on as many copy streams",
+        "upload_autotune": upload_tuning,
         "variants": {"value": "float32 upload inside the timed region (SURVEY.md 8d)",
                      "value_int16": "PCM16 upload (2 B/sample) + device conversion inside the timed region",
                      "value_resident": "no upload: the same distinct batches already in HBM (compute-only rate)",
                      "value_pull_kernel": "float32 upload by the pull kernel (ira_host_pull) instead of hipMemcpyAsync (A/B)"},
         "h2d_GBps": B * n * 4.0 * steps / elapsed / 1e9,
+        "h2d_GBps_is": "upload bytes / wall time of the timed region (what the link SUSTAINED, not what a copy ran at: see upload)",
         "roofline": roof(dominant),
         "roofline_kernel": roofline_kernel(a.config, tot, roof, dict(channels=B, n=n, bands=nb_bands(settings),
                                                                     decay=settings.run_decay, mean_len=float(np.mean(L)),
@@ -1052,6 +1081,31 @@ def main():
         "literal_full_report": literal,
     }
     out["affinity"] = affinity
+    # ---- what the upload cost: events around every piece on the copy streams ----------------------------
+    step_ms = 1e3 * elapsed / steps
+    res_ms = None if el_res is None else 1e3 * el_res / steps
+    up = {"pieces": upload_timed["pieces_per_upload"] if upload_timed else None, "copy_streams": len(feed.side_streams) + 1,
+          "high_priority_streams": bool(a.upload_priority),
+          "bytes_per_step": B * n * 4.0,
+          "alone": upload_alone, "under_compute": upload_timed,
+          "measured": "HIP events recorded on the copy streams around every piece (DeviceFeed.timing): ms_per_upload = first "
+                      "piece's start to last piece's end; alone = three uploads with an otherwise idle GPU before the timed "
+                      "region; under_compute = every upload of the timed region"}
+    out["upload_ms_per_step"] = upload_timed["ms_per_upload"] if upload_timed else None
+    out["h2d_alone_GBps"] = upload_alone["GBps"] if upload_alone else None
+    out["h2d_under_compute_GBps"] = upload_timed["GBps"] if upload_timed else None
+    if upload_timed:
+        busy = upload_timed["ms_per_upload"] / step_ms
+        up["copy_engines_busy_fraction_of_step"] = busy
+        if res_ms is not None:
+            up["GBps_needed_for_resident_rate"] = B * n * 4.0 / (res_ms * 1e-3) / 1e9
+            up["resident_ms_per_step"] = res_ms
+        # a step waits for its upload when the copy of one batch takes (nearly) as long as the step itself
+        out["bound"] = "pcie" if busy >= 0.9 else "compute"
+        out["bound_reason"] = (f"one batch's upload takes {upload_timed['ms_per_upload']:.2f} ms under the kernels "
+                               f"({upload_timed['GBps']:.1f} GB/s; {upload_alone['GBps']:.1f} GB/s alone) of a "
+                               f"{step_ms:.2f} ms step" + ("" if res_ms is None else f"; the same steps with resident inputs take {res_ms:.2f} ms"))
+    out["upload_detail"] = up
     if el_cold is not None:
         out["value_new_lengths"] = total_irs / el_cold
         out["variants"]["value_new_lengths"] = ("the same steps with the chirp-filter pools forgotten before every step: every "
