@@ -10,6 +10,8 @@ from __future__ import annotations
 
 import json
 import os
+import sys
+import time
 from dataclasses import dataclass
 from pathlib import Path
 from typing import List, Optional
@@ -138,13 +140,21 @@ def run_bundle_metrics(bundle_root: str | Path, settings=None, use_mono_downmix_
     rate = int(meta.get("sample_rate_hz", 48_000) or 48_000)
     groups = [mine[a : a + step] for a in range(0, len(mine), step)]
 
-    _rd = [0.0]
+    # diagnostics (IRA_BUNDLE_TIMING=1): host seconds per phase of the loop; nothing is timed when the switch is off
+    timing = {} if os.environ.get("IRA_BUNDLE_TIMING") else None
+
+    def lap(key, t0):
+        if timing is None:
+            return 0.0
+        now = time.perf_counter()
+        timing[key] = timing.get(key, 0.0) + (now - t0)
+        return now
 
     def host_half(names):                            # headers + payload reads into pinned staging: no GPU call in here
-        import time as _t
-        t0 = _t.perf_counter()
+        t0 = time.perf_counter() if timing is not None else 0.0
         ts = TapSet(eng, [root / "taps" / f"{t}.wav" for t in names], rate, upload=False)
-        _rd[0] += _t.perf_counter() - t0             # (diagnostics: IRA_BUNDLE_TIMING)
+        if timing is not None:                       # (the reader thread's own total; dict updates are atomic under the GIL)
+            timing["reader thread busy"] = timing.get("reader thread busy", 0.0) + (time.perf_counter() - t0)
         return ts
 
     # Three groups in flight.  While this thread works on groups k, k-1 and k-2, a worker thread reads group k+1 from
@@ -161,35 +171,26 @@ def run_bundle_metrics(bundle_root: str | Path, settings=None, use_mono_downmix_
     depth = max(1, int(os.environ.get("IRA_BUNDLE_DEPTH", "1")))
     with ThreadPoolExecutor(max_workers=1, thread_name_prefix="ira-prefetch") as ahead:
         nxt_set = ahead.submit(host_half, groups[0]) if groups else None
-        import os as _os, time as _time
-        _tm = {} if _os.environ.get("IRA_BUNDLE_TIMING") else None      # diagnostics: host seconds per phase of the loop
-
-        def _lap(key, t0):
-            if _tm is not None:
-                _tm[key] = _tm.get(key, 0.0) + (_time.perf_counter() - t0)
-            return _time.perf_counter()
-
         for gi, names in enumerate(groups):
-            t0 = _time.perf_counter()
+            t0 = time.perf_counter() if timing is not None else 0.0
             tapset = nxt_set.result()
-            t0 = _lap("wait for the reader thread", t0)
+            t0 = lap("wait for the reader thread", t0)
             nxt_set = ahead.submit(host_half, groups[gi + 1]) if gi + 1 < len(groups) else None
             batch, lab = tapset.view(use_mono_downmix_for_stereo)
             labels += [(names[i], ch) for i, ch in lab]
-            t0 = _lap("view (upload + conversion enqueued)", t0)
+            t0 = lap("view (upload + conversion enqueued)", t0)
             fr.prepare(batch)
-            t0 = _lap("prepare (peak pick started)", t0)
+            t0 = lap("prepare (peak pick started)", t0)
             if uploaded is not None:
                 pending.append(fr.submit(uploaded))
-                t0 = _lap("submit", t0)
+                t0 = lap("submit", t0)
                 if len(pending) > depth:
                     rows.append(fr.finish(pending.pop(0)))
-                    t0 = _lap("finish", t0)
+                    t0 = lap("finish", t0)
             uploaded = batch
-        if _tm is not None and groups:
-            import sys as _sys
-            print("[bundle] host ms per group: " + ", ".join(f"{k} {1e3 * v / len(groups):.2f}" for k, v in _tm.items())
-                  + f"; reader thread busy {1e3 * _rd[0] / len(groups):.2f}", file=_sys.stderr)
+        if timing is not None and groups:
+            print("[bundle] host ms per group: " + ", ".join(f"{k} {1e3 * v / len(groups):.2f}" for k, v in timing.items()),
+                  file=sys.stderr)
     if uploaded is not None:
         pending.append(fr.submit(uploaded))
     for handle in pending:

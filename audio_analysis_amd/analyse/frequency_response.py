@@ -124,7 +124,7 @@ def spectrum_device(eng, batch, sample_rate_hz: int, settings, what: str, want_p
     """
     starts, lens = spectrum_segments(eng, batch, sample_rate_hz, settings, what)
     # nothing but the dB / phase kernel reads these spectra: even-length Bluestein elements stay packed (engine.rfft_any)
-    spec, off, packed = eng.rfft_any(batch.x, batch.off + starts, lens, bool(settings.use_hann_window), packed_ok=True)
+    spec, off, packed = eng.rfft_any_packed(batch.x, batch.off + starts, lens, bool(settings.use_hann_window))
     mag, ph = eng.spectrum_mag_phase(spec, off, lens, float(settings.magnitude_floor_db), want_phase=want_phase,
                                      packed=packed)
     phase = eng.phase_unwrap(ph, off, lens, unwrap, degrees) if want_phase else None
@@ -147,7 +147,9 @@ def spectrum_device(eng, batch, sample_rate_hz: int, settings, what: str, want_p
             smoothed = eng.log_smooth(mag, off, np.ones(len(rng), np.int32), k_lo, nsel, steps, bins_w,
                                       int(getattr(settings, "log_bins_per_octave", 96)), through_float32=False)
     stats = eng.spectrum_stats(mag, off, lens, steps, f_lo, f_hi, 1000.0)
-    return dict(spec=spec, off=off, packed=packed, starts=starts, lens=lens, mag=mag, phase=phase, stats=stats, f_lo=f_lo,
+    # with packed elements `spec` holds half-length transforms Z in some slots, not half spectra: nothing may read it as
+    # "the spectra"  -- it travels as spec_packed, and `spec` is only there when every slot is a spectrum
+    return dict(spec=spec if packed is None else None, spec_packed=spec if packed is not None else None, off=off, packed=packed, starts=starts, lens=lens, mag=mag, phase=phase, stats=stats, f_lo=f_lo,
                 f_hi=f_hi, smoothed=smoothed)
 
 

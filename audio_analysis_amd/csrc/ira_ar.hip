@@ -881,6 +881,12 @@ __global__ __launch_bounds__(SV_THREADS) void ar_solve_dd_kernel(const double* _
   // G = A^T A below the SQUARE of that ratio times lambda_max (<= trace): a pivot under that cut means the reference
   // truncates at least one direction, and the element goes to ira_ar_minnorm like every other rank-deficient fit
   // (with 1e-26 alone, singular-value ratios between 1e-13 and eps * rows got a full-rank solution).
+  // This is a SUFFICIENT test, not lstsq's criterion itself: a Cholesky pivot bounds lambda_min only from
+  // above (pivot_k >= lambda_min) and the trace bounds lambda_max only from above (trace <= p lambda_max), so an element whose
+  // lambda_min sits just below the cut while every pivot stays above it keeps the full-rank double-double solution where the
+  // reference truncates one direction.  ira_ar_minnorm's eigen-decomposition applies the exact criterion to every element
+  // that does trip this test; for the others the two solutions differ by the contribution of a direction with
+  // sigma / sigma_max ~ eps * rows, which the double-double arithmetic resolves (cond(G) * 1e-32).
   const double rc = 2.220446049250313e-16 * (double)((N - p) > p ? (N - p) : p);
   const double tiny = fmax(1e-26, rc * rc) * trace_s.hi;
   for (int k = 0; k < p; ++k) {

@@ -1074,6 +1074,11 @@ extern "C" int32_t ira_rfft_any(const float* x_dev, const int64_t* xoff_dev, con
   J.spec_out = reinterpret_cast<cd*>(spec_out_dev); J.spec_out_off = spec_off_dev;
   J.data_len = data_len_dev; J.win_len = win_len_dev; J.data_len2 = data_len2_dev; J.win_len2 = win_len2_dev;
   if (interleave_dev != nullptr && x2off_dev == nullptr) return IRA_E_NULL;
+  // keep_packed leaves the third pass's output Z = DFT(x1 + i x2) where it wrote it: right for INTERLEAVED elements (the
+  // consumer untangles), wrong for a PAIRED one (two signals of two channels), which would silently return two tangled
+  // spectra.  Without the interleave table every second signal is a paired one: refuse.  With it, elements
+  // that are not interleaved must be single (x2off < 0) -- the caller's contract, stated in ira.h.
+  if (keep_packed && x2off_dev != nullptr && interleave_dev == nullptr) return IRA_E_UNSUPPORTED;
   J.interleave = interleave_dev;
   if (x2off_dev != nullptr) {
     if (spec_off2_dev == nullptr || zpair_dev == nullptr || zpair_off_dev == nullptr) return IRA_E_NULL;

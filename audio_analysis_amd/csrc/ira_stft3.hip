@@ -48,10 +48,51 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ float db_of(float re, float im, float floor_pow, float floor_db) {
+// 10 log10((re^2 + im^2) / 4) floored at floor_db.  The quarter belongs to the untangling below, which works on UN-halved
+// sums (32 multiplies by 0.5 fewer per frame); the floor is ONE v_max in the dB domain (numpy.maximum(|X|, 10^(floor/20))
+// before the logarithm, spectrogram.py:152-156: the same value for every bin at or below the floor; a v_max returns the
+// other operand for a NaN like the former `!(p > floor)` compare + select did, and log2(0) = -inf is absorbed too).
+// POLY (tuning build, IRA_STFT6_ABLATE=16): the logarithm without the transcendental unit -- p = m 2^(E-127) taken apart
+// with integer instructions, 10 log10 m as a degree-7 polynomial in m - 3/2 (1.2e-6 dB).  Why it exists and why it is NOT
+// the product path: in tools/micro/stft_epilogue_rate.hip (lock-step waves, no memory) the frame's 33 v_log_f32 cost 1770
+// of 7300 SIMD-cycles and the polynomial form issues 36 % faster; in the kernel, whose waves drift apart, v_log_f32 rides
+// the transcendental pipe BESIDE the other waves' arithmetic and the polynomial's 9 extra full-rate instructions per bin
+// make the kernel 4 % slower (profiles/r05_stft_epilogue.txt).
+template <bool POLY>
+__device__ __forceinline__ float db_quarter(float re, float im, float floor_db) {
   const float p = re * re + im * im;
-  if (!(p > floor_pow)) return floor_db;
-  return 3.0102999566398120f * __log2f(p);   // 10 log10(p) = 20 log10 |X|
+  float db;
+  if (POLY) {
+    const unsigned bits = __float_as_uint(p);
+    const float t = __uint_as_float((bits & 0x007fffffu) | 0x3f800000u) - 1.5f;
+    const float ef = (float)(bits >> 23);
+    float q = 4.3469792483e-02f;
+    q = fmaf(q, t, -7.5589056220e-02f);
+    q = fmaf(q, t, 1.1321877900e-01f);
+    q = fmaf(q, t, -2.1251078291e-01f);
+    q = fmaf(q, t, 4.2899189857e-01f);
+    q = fmaf(q, t, -9.6519812982e-01f);
+    q = fmaf(q, t, 2.8952960832e+00f);
+    q = fmaf(q, t, 1.7609133684e+00f - 129.0f * 3.0102999566398120f);    // - 127 (bias) - 2 (the quarter), in units of 10 log10 2
+    db = fmaf(ef, 3.0102999566398120f, q);
+  } else {
+    db = fmaf(3.0102999566398120f, __log2f(p), -6.0205999132796240f);     // 10 log10(p / 4)
+  }
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(db), "v"(floor_db));        // (fmaxf adds a canonicalising v_max per operand)
+  return r;
+}
+
+// Untangling of one bin pair of the packed real transform + dB:  X[k] = (E + P)/2, X[M-k] = conj((E - P)/2) with
+// E = Zk + conj Zp, P = W_N^k (-i)(Zk - conj Zp); the halves go into db_quarter's constant.  Shared by the (F, T) and the
+// frame-major kernels, which therefore produce the same float32 values (test_frame_major_stft_is_the_exact_transpose).
+template <bool POLY = false>
+__device__ __forceinline__ void untangle_db(float zkr, float zpr, float zki, float zpi, cf wk, float floor_db, float& lo, float& hi) {
+  const cf e = {zkr + zpr, zki - zpi};
+  const cf o = {zki + zpi, zpr - zkr};
+  const cf pp = ira::cmul(wk, o);
+  lo = db_quarter<POLY>(e.re + pp.re, e.im + pp.im, floor_db);
+  hi = db_quarter<POLY>(e.re - pp.re, e.im - pp.im, floor_db);
 }
 
 template <int NT3, bool TF>
@@ -216,21 +257,15 @@ __global__ __launch_bounds__(64 * NT3) void stft3_kernel(
   midi = exf[M3 / 2];
 
   // ---- post: X[k] = E + P, X[M-k] = conj(E - P) with E = (Zk + conj Zp)/2, P = W_N^k (-i)(Zk - conj Zp)/2 ---------------
-  const float floor_pow = floor_lin * floor_lin;
   const cf wlane = tw[q];
   float lo[16], hi[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    const cf e = {0.5f * (zkr[i] + zpr[i]), 0.5f * (zki[i] - zpi[i])};
-    const cf d = {0.5f * (zkr[i] - zpr[i]), 0.5f * (zki[i] + zpi[i])};
-    const cf o = {d.im, -d.re};
     const cf wk = ira::cmul(wlane, tw[64 * i]);          // W_N^k = W_N^q W_N^(64 i); second factor wave-uniform
-    const cf pp = ira::cmul(wk, o);
-    if (IRA_ABL(ablate & 8)) { lo[i] = e.re + pp.re; hi[i] = e.im - pp.im; continue; }
-    lo[i] = db_of(e.re + pp.re, e.im + pp.im, floor_pow, floor_db);
-    hi[i] = db_of(e.re - pp.re, e.im - pp.im, floor_pow, floor_db);
+    if (IRA_ABL(ablate & 8)) { lo[i] = zkr[i] + wk.re * zpr[i]; hi[i] = zki[i] - wk.im * zpi[i]; continue; }
+    untangle_db(zkr[i], zpr[i], zki[i], zpi[i], wk, floor_db, lo[i], hi[i]);
   }
-  float mid = db_of(midr, midi, floor_pow, floor_db);
+  float mid = db_quarter<false>(2.0f * midr, 2.0f * midi, floor_db);
   {
     // A NaN (or infinite) sample anywhere in the frame makes every bin of numpy's rfft NaN (spectrogram.py:150): it shows
     // in Z[0] = sum of the packed inputs, which lane 0 holds as its first pair (0 * NaN at the Hann end points is NaN
@@ -355,7 +390,7 @@ __device__ __forceinline__ T& at32(T* base, unsigned byte_off) {
 //     stored, half 1 before half 0 is transformed.  gfx950 counts loads and stores in ONE in-order counter, so a load
 //     issued after a frame's 33 stores cannot be consumed before those stores are acknowledged; issued before them it can.
 // AB: ablation bits, instantiated only by the tuning build (IRA_STFT6_ABLATE): 1 no sample loads, 2 no window reads,
-//     4 no stores, 8 post-stage twiddles without the scalar table loads.  The product runs AB = 0.
+//     4 no stores, 8 post-stage twiddles without the scalar table loads, 16 polynomial logarithm.  The product runs AB = 0.
 template <int NT, bool PF, int AB>
 __global__ __launch_bounds__(64 * NT) void stft6_kernel(
     const float* __restrict__ x, const int64_t* __restrict__ off, const int32_t* __restrict__ nframes, int hop,
@@ -378,7 +413,6 @@ __global__ __launch_bounds__(64 * NT) void stft6_kernel(
   const unsigned xcd = wg & 7u, lane_wg = wg >> 3, wg_per_xcd = (nwg + 7u - xcd) >> 3;
   const unsigned per = (ntiles + 7u) >> 3;
   const unsigned t_end = (xcd + 1u) * per < ntiles ? (xcd + 1u) * per : ntiles;
-  const float floor_pow = floor_lin * floor_lin;
   const float qn = __uint_as_float(0x7fc00000u);
 
   auto locate = [&](unsigned t, const float*& fxp, float*& fop) -> bool {       // wave-uniform
@@ -428,6 +462,10 @@ __global__ __launch_bounds__(64 * NT) void stft6_kernel(
 #pragma unroll
   for (int i = 0; i < 16; ++i) wuni[i] = tw[64 * i];
 
+  // INVARIANT: the barriers of sync_up_to() are matched by COUNT, not textually -- every wave of the workgroup
+  // must execute exactly n_pos / resync of them over its whole walk, whatever tiles it skips.  No exit path of this loop
+  // (no `return`, `break` or `continue`) may bypass the sync_up_to() at its end or the final sync_up_to(n_pos) behind it:
+  // a wave that left early would leave the other fifteen waiting at a barrier for ever.
   while (have) {
     unsigned tn = t + t_step;
     const float* fxn = fx;
@@ -577,24 +615,29 @@ __global__ __launch_bounds__(64 * NT) void stft6_kernel(
     // in Z[0] = sum of the packed inputs, which lane 0 holds as its first pair -- one flag per frame.  Every result is
     // stored as soon as it exists (nothing of it stays live).
     const float z0 = (zkr[0] - zkr[0]) + (zki[0] - zki[0]);                // 0 if finite, NaN otherwise
-    const bool bad = __shfl(z0, 0, 64) != 0.0f;
-    float sacc = 0.0f;
+    const bool bad = __shfl(z0, 0, 64) != 0.0f;                            // wave-uniform: a branch, not a select per bin
+    // per-lane pointers once per frame: every store below is base + immediate offset (as 32-bit lane offsets added to a
+    // scalar base each store took an integer add of its own: an unsigned offset cannot be folded into the immediate)
+    float* const flo = fo + q;
+    float* const fhi = fo + (M3 - q);
+    if (__builtin_expect(bad, 0)) {
+      if (!(AB & 4)) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const cf e = {0.5f * (zkr[i] + zpr[i]), 0.5f * (zki[i] - zpi[i])};
-      const cf d = {0.5f * (zkr[i] - zpr[i]), 0.5f * (zki[i] + zpi[i])};
-      const cf o = {d.im, -d.re};
-      const cf wk = ira::cmul(wlane, (AB & 8) ? cf{wlane.im * (float)(i + 1), wlane.re} : wuni[i]);
-      const cf pp = ira::cmul(wk, o);
-      const float lo = bad ? qn : db_of(e.re + pp.re, e.im + pp.im, floor_pow, floor_db);
-      const float hi = bad ? qn : db_of(e.re - pp.re, e.im - pp.im, floor_pow, floor_db);
-      if (AB & 4) { sacc += lo + hi; continue; }
-      const unsigned kk = (unsigned)(q + 64 * i);
-      at32(fo, 4u * kk) = lo;
-      at32(fo, 4u * ((unsigned)M3 - kk)) = hi;              // k = 0 -> bin M (Nyquist)
-    }
-    {
-      const float mid = bad ? qn : db_of(midr, midi, floor_pow, floor_db);
+        for (int i = 0; i < 16; ++i) { flo[64 * i] = qn; fhi[-64 * i] = qn; }
+        if (q == 0) fo[M3 / 2] = qn;
+      }
+    } else {
+      float sacc = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const cf wk = ira::cmul(wlane, (AB & 8) ? cf{wlane.im * (float)(i + 1), wlane.re} : wuni[i]);
+        float lo, hi;
+        untangle_db<(AB & 16) != 0>(zkr[i], zpr[i], zki[i], zpi[i], wk, floor_db, lo, hi);
+        if (AB & 4) { sacc += lo + hi; continue; }
+        flo[64 * i] = lo;
+        fhi[-64 * i] = hi;                                    // k = 0 -> bin M (Nyquist)
+      }
+      const float mid = db_quarter<(AB & 16) != 0>(2.0f * midr, 2.0f * midi, floor_db);
       if (AB & 4) { if (sacc + mid == 12345.678f) fo[q] = sacc; }
       else if (q == 0) fo[M3 / 2] = mid;
     }
@@ -641,6 +684,8 @@ int32_t launch6(const float* x, const int64_t* off, const int32_t* nframes, int3
     case 1: IRA_LAUNCH6(1); break;
     case 4: IRA_LAUNCH6(4); break;
     case 7: IRA_LAUNCH6(7); break;
+    case 16: IRA_LAUNCH6(16); break;
+    case 23: IRA_LAUNCH6(23); break;
     default: IRA_LAUNCH6(0); break;
   }
 #else

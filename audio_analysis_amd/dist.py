@@ -83,14 +83,40 @@ def gpu_numa_cpus(sys_root: str = "/sys"):
     return [seen[k] for k in sorted(seen)]
 
 
+def visible_gpus(gpus, env=None):
+    """The sysfs GPU list as HIP will number it: HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES (comma-separated INDICES into the
+    PCI-ordered list; schedulers and containers set them to restrict or reorder the devices a process sees) applied in that
+    order -- ROCR filters first, HIP indexes what ROCR left.  Local rank r then maps to entry r.  A value that is not a plain
+    index list (UUIDs: `GPU-...`) cannot be resolved from sysfs: returns [] and the caller falls back to the even split."""
+    env = os.environ if env is None else env
+    out = list(gpus)
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):
+        val = env.get(var)
+        if val is None or val.strip() == "":
+            continue
+        try:
+            idx = [int(v) for v in val.split(",") if v.strip() != ""]
+        except ValueError:
+            return []
+        sel = []
+        for i in idx:                       # the runtime stops at the first invalid index
+            if i < 0 or i >= len(out):
+                break
+            sel.append(out[i])
+        out = sel
+    return out
+
+
 def rank_cpu_affinity(local_rank: int, local_world: int, allowed=None, gpus=None):
     """
     The CPUs rank `local_rank` of `local_world` ranks on this host should run on (one process per
     GPU; eight ranks on one host share its PCIe root complexes and memory controllers): the cores of ITS GPU's NUMA node
     (sysfs), cut into disjoint, equal slices among the ranks whose GPUs sit on that node -- so that the pinned host
     batches a rank allocates are node-local and no two ranks' worker threads compete for a core.  When sysfs shows no
-    GPU topology (or fewer GPUs than ranks) the allowed CPUs are dealt evenly in order.  Returns (cpus, how) with `how` a
-    short description for the bench line; single rank: (allowed, "unrestricted").
+    GPU topology (or fewer GPUs than ranks) the allowed CPUs are dealt evenly in order.  The GPU list is the one HIP will
+    enumerate: HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES are applied to the sysfs list first (visible_gpus).
+    Returns (cpus, how) with `how` a short description for the bench line (it names the GPU's PCI address, to be compared
+    with the device's own pci_bus_id); single rank: (allowed, "unrestricted").
     """
     if allowed is None:
         try:
@@ -100,7 +126,7 @@ def rank_cpu_affinity(local_rank: int, local_world: int, allowed=None, gpus=None
     allowed = sorted(allowed)
     if local_world <= 1:
         return allowed, "unrestricted (one rank)"
-    gpus = gpu_numa_cpus() if gpus is None else gpus
+    gpus = visible_gpus(gpu_numa_cpus()) if gpus is None else gpus
     if len(gpus) >= local_world:
         # several ranks may rehearse on fewer GPUs (IRA_DIST_BACKEND=gloo): rank r uses GPU r mod #GPUs there too
         mine = gpus[local_rank % len(gpus)]

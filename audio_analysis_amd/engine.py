@@ -849,12 +849,24 @@ class Engine:
         return np.asarray(first, dtype=np.int64), np.asarray(second, dtype=np.int64)
 
     def rfft_any(self, x_dev, xoff: np.ndarray, lengths: np.ndarray, use_hann: bool,
-                 data_len: Optional[np.ndarray] = None, win_len: Optional[np.ndarray] = None, packed_ok: bool = False):
+                 data_len: Optional[np.ndarray] = None, win_len: Optional[np.ndarray] = None):
+        """Half spectra of arbitrary-length segments: (spec, spec_off); see _rfft_any."""
+        spec, spec_off, _ = self._rfft_any(x_dev, xoff, lengths, use_hann, data_len, win_len, False)
+        return spec, spec_off
+
+    def rfft_any_packed(self, x_dev, xoff: np.ndarray, lengths: np.ndarray, use_hann: bool):
+        """The same for a caller whose only consumer is spectrum_mag_phase(packed=...): (spec, spec_off, packed) -- even-length
+        elements that ride a half-length Bluestein transform stay PACKED (see _rfft_any); packed is None when none is."""
+        return self._rfft_any(x_dev, xoff, lengths, use_hann, None, None, True)
+
+    def _rfft_any(self, x_dev, xoff: np.ndarray, lengths: np.ndarray, use_hann: bool,
+                  data_len: Optional[np.ndarray], win_len: Optional[np.ndarray], packed_ok: bool):
         """
         Half spectra (complex f64) of x[xoff[e] : xoff[e]+L[e]] (* hanning) for every element.
         data_len / win_len (optional, per element): numpy.fft.rfft(x[:d] * hanning(w)[:d], n=L) -- d samples are read
         (d < L zero-pads, d > L truncates) under the Hann window of length w (reference group_delay.py:95-109).
-        Returns (spec float64 device viewed as (total_bins, 2), spec_off int64 host in complex elements).
+        Returns (spec float64 device viewed as (total_bins, 2), spec_off int64 host in complex elements, packed) -- always
+        three values; the public wrappers are rfft_any (two) and rfft_any_packed (three).
         packed_ok: the caller's consumer is spectrum_mag_phase(packed=...) -- even-length elements that ride a half-length
         Bluestein transform may then stay PACKED: spec_off[e] holds the L/2 values Z = DFT(x[2m] + i x[2m+1]) instead of
         the L/2 + 1 bins, and the third return value marks them (int32 per element; None when nothing is packed).
@@ -926,7 +938,7 @@ class Engine:
                                                _ptr(d_dl2), _ptr(d_wl2), 1 if half_ok else 0, self.stream), "ira_rfft_smooth")
         packed = np.zeros(n, dtype=np.int32)
         if not rest.any():
-            return (spec, spec_off, None) if packed_ok else (spec, spec_off)
+            return spec, spec_off, None
         rest_idx = np.nonzero(rest)[0]
         # ---- everything else: Bluestein, grouped by the power-of-two convolution size ------------------------------------
         # Jobs: "half" = one real signal of EVEN length carried as x[2m] + i*x[2m+1] (a complex transform of L/2: half
@@ -988,9 +1000,7 @@ class Engine:
                                         _ptr(d_dl), _ptr(d_wl), _ptr(d_dl2), _ptr(d_wl2), _ptr(d_il),
                                         1 if keep_packed else 0, self.stream),
                   "ira_rfft_any")
-        if packed_ok:
-            return spec, spec_off, (packed if packed.any() else None)
-        return spec, spec_off
+        return spec, spec_off, (packed if (packed_ok and packed.any()) else None)
 
     def band_irfft(self, spec_dev, spec_off: np.ndarray, lengths: np.ndarray, band_params: np.ndarray,
                    freq_val: np.ndarray, y_dev, y_off: np.ndarray):

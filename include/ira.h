@@ -193,7 +193,9 @@ int32_t ira_bluestein_filter(const int32_t* L_dev, int32_t nfilt, int32_t m, con
  * the last pass wrote them, zpair_dev + 2*zpair_off_dev[e] (the caller may point that into spec_out_dev: L[e] values fit
  * the element's L[e]+1 bins), and the consumer forms X[k] = E[k] + W^k O[k] as it reads them
  * (ira_spectrum_mag_phase, packed_dev): one read-modify-write pass over every such spectrum less.  Such a call must not
- * carry paired elements (x2off_dev[e] >= 0 only where interleave_dev[e] = 1): no split kernel is launched at all. */
+ * carry paired elements (x2off_dev[e] >= 0 only where interleave_dev[e] = 1): no split kernel is launched at all.
+ * keep_packed with x2off_dev but WITHOUT interleave_dev (every second signal would be a paired one) returns
+ * IRA_E_UNSUPPORTED. */
 int32_t ira_rfft_any(const float* x_dev, const int64_t* xoff_dev, const int32_t* L_dev, int32_t nb,
                      int32_t use_hann, int32_t m, const void* t1_dev, const void* t2_dev,
                      const void* tf_dev, const double* bfilt_dev, const int32_t* bidx_dev,

@@ -156,7 +156,7 @@ def test_untangling_fused_into_the_producing_and_consuming_kernels():
         res = {}
         for fused in (True, False):
             eng.fuse_half_split = fused
-            spec, off, packed = eng.rfft_any(b.x, b.off, lens, True, packed_ok=True)
+            spec, off, packed = eng.rfft_any_packed(b.x, b.off, lens, True)
             assert (packed is not None and list(packed) == [1, 1]) if fused else packed is None
             mag, ph = eng.spectrum_mag_phase(spec, off, lens, -120.0, want_phase=True, packed=packed)
             res[fused] = (mag.cpu().numpy(), ph.cpu().numpy(), off)

@@ -392,6 +392,35 @@ def test_rank_affinity_follows_the_gpu_numa_nodes():
     assert D._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
 
 
+def test_visible_devices_reorder_the_gpu_list_before_ranks_index_it():
+    """local rank r maps to the r-th GPU HIP will ENUMERATE -- ROCR_VISIBLE_DEVICES filters the PCI-ordered sysfs
+    list first, HIP_VISIBLE_DEVICES indexes what is left; an unparsable value (UUIDs) gives no topology (-> even split)."""
+    from audio_analysis_amd import dist as D
+    node0, node1 = list(range(0, 8)), list(range(8, 16))
+    gpus = [(f"0000:{b:02x}:00.0", 0 if i < 2 else 1, node0 if i < 2 else node1) for i, b in enumerate((5, 15, 25, 35))]
+    assert D.visible_gpus(gpus, {}) == gpus
+    assert [g[0] for g in D.visible_gpus(gpus, {"HIP_VISIBLE_DEVICES": "3,0"})] == ["0000:23:00.0", "0000:05:00.0"]
+    assert [g[0] for g in D.visible_gpus(gpus, {"ROCR_VISIBLE_DEVICES": "2,3", "HIP_VISIBLE_DEVICES": "1"})] == ["0000:23:00.0"]
+    assert [g[0] for g in D.visible_gpus(gpus, {"HIP_VISIBLE_DEVICES": "1,7,2"})] == ["0000:0f:00.0"]     # stops at the bad index
+    assert D.visible_gpus(gpus, {"HIP_VISIBLE_DEVICES": "GPU-abcdef"}) == []
+    # rank 0 of two ranks under HIP_VISIBLE_DEVICES=3,0 sits on GPU 3's node (node 1), rank 1 on node 0
+    vis = D.visible_gpus(gpus, {"HIP_VISIBLE_DEVICES": "3,0"})
+    c0, how0 = D.rank_cpu_affinity(0, 2, list(range(16)), vis)
+    c1, _ = D.rank_cpu_affinity(1, 2, list(range(16)), vis)
+    assert set(c0) <= set(node1) and set(c1) <= set(node0) and "0000:23:00.0" in how0
+
+
+def test_keep_packed_without_the_interleave_table_is_refused():
+    """ira_rfft_any(keep_packed=1) leaves Z = DFT(x1 + i x2) as the last pass wrote it -- right for interleaved
+    elements, silently wrong for paired ones.  Argument validation only (no kernel is launched, no pointer dereferenced)."""
+    from audio_analysis_amd import _lib
+    lib = _lib.load()
+    fake = 64                                            # any non-null address: the call returns before touching memory
+    args = [fake, fake, fake, 4, 1, 1 << 19, fake, fake, fake, fake, fake, fake, fake, fake,
+            fake, fake, fake, fake, 1000, None, None, None, None]
+    assert lib.ira_rfft_any(*args, None, 1, None) == -3                   # x2off given, no interleave table, keep_packed
+
+
 def test_bench_parity_report_reads_the_record_layout():
     """bench.py's cpu_baseline workers return the oracle's values for the files they time; rank 0 compares them with the
     gathered records (RT60 and pole radii as max and fraction within 1e-4).  Here: records filled FROM the

@@ -11,8 +11,9 @@ import collections, re, sys
 
 text = open(sys.argv[1]).read()
 out = []
-for var in range(5):
-    m = re.search(r"^(_Z1kILi%d[^:\n]*):[^\n]*\n(.*?)^\.Lfunc_end" % var, text, flags=re.S | re.M)
+NVAR = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+for var in range(NVAR):
+    m = re.search(r"^(_Z1kILi%dE[^:\n]*):[^\n]*\n(.*?)^\.Lfunc_end" % var, text, flags=re.S | re.M)
     if not m:
         out.append(0); continue
     lines = m.group(2).splitlines()
