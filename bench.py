@@ -107,7 +107,7 @@ def _cpu_one(args):
                 v["modal_median"], v["modal_p90"], v["modal_max"] = (float(np.median(rt)), float(np.percentile(rt, 90)),
                                                                      float(np.max(rt)))
         if "zplane" in blocks:
-            z = O.analyse_zplane(x, ar_order=64)
+            z = O.analyse_zplane(x, ar_order=next((int(b.split("=")[1]) for b in blocks if b.startswith("ar_order=")), 64))
             v["ar_max_radius"], v["ar_median_radius"], v["ar_unstable"] = z["max_radius"], z["median_radius"], z["unstable"]
         if "groupdelay" in blocks:
             g = O.analyse_group_delay(x)["gd"]
@@ -326,6 +326,8 @@ def block_names(settings):
                        ("run_diffusion", "diffusion")):
         if getattr(settings, flag):
             out.append(name)
+    if settings.run_zplane and settings.zplane.ar_order != 64:
+        out.append(f"ar_order={settings.zplane.ar_order}")        # read by the cpu_baseline workers (_cpu_one)
     return out
 
 
@@ -744,6 +746,8 @@ def main():
     ap.add_argument("--gather", default="final", choices=["final", "step"],
                     help="final: the records of every step stay on their rank and ONE gather to rank 0 closes the timed "
                          "region (north star: a single RCCL gather for the final metrics); step: one gather per step (A/B)")
+    ap.add_argument("--ar-order", type=int, default=None,
+                    help="AR order of the z-plane block (the configs use 64; the reference's CLI default is 256, cli.py:245)")
     ap.add_argument("--spawn-probe", action="store_true",
                     help="launch check without a GPU: every rank joins a gloo group, rank 0 prints the ranks it gathered "
                          "(tests/test_host_cpu.py runs `bench.py --gpus 2 --spawn-probe`)")
@@ -789,6 +793,13 @@ def main():
 
     cfg = config_table()[a.config]
     settings = cfg["settings"]
+    if a.ar_order is not None and a.ar_order != settings.zplane.ar_order:
+        from dataclasses import replace as _rep
+        settings = _rep(settings, zplane=_rep(settings.zplane, ar_order=int(a.ar_order)))
+        cfg = dict(cfg, settings=settings, metric=cfg["metric"].replace("AR(64)", f"AR({a.ar_order})") + f" [AR order {a.ar_order}]",
+                   what=cfg["what"].replace("order 64", f"order {a.ar_order}"),
+                   # the oracle's SVD least squares costs ~ rows x order^2: 4 s per 10 s channel at order 64
+                   cpu_s=cfg["cpu_s"] + 4.0 * ((a.ar_order / 64.0) ** 2 - 1.0) * (settings.run_zplane))
     B = a.batch or cfg["batch"]
     seconds = a.seconds or cfg["seconds"]
     steps = a.steps or cfg["steps"]
