@@ -188,7 +188,15 @@ class Engine:
         self._ring_np[pos : pos + nbytes] = a.view(np.uint8).reshape(-1)
         self._ring_pos = pos + nbytes
         src = self._ring[pos : pos + nbytes].view(_TORCH_DTYPES(t)[a.dtype.str]).view(a.shape)
+        # (round 5: the same copy as a bare hipMemcpyAsync (ctypes) into a device ring that mirrors this one -- no tensor
+        # allocation, no dispatcher -- was built and measured: the same ~85 us of host time per call, which is the runtime's
+        # own cost of a small asynchronous copy; 11.9-12.1 vs 11.9-12.3 ms per bundle step.  Removed.)
         return src.to(self.device, non_blocking=True)
+
+    def job_tables(self, *arrays):
+        """to_dev_pack under the name that says what the arrays are: the job tables of ONE call (offsets, lengths, indices ...
+        read only by the launches the calling method enqueues before it returns)."""
+        return self.to_dev_pack(*arrays)
 
     def to_dev_pack(self, *arrays):
         """Several small host arrays -> ONE write into the pinned staging ring and ONE asynchronous H2D copy; returns the
@@ -412,7 +420,7 @@ class Engine:
         scratch = self.empty(n * EDC_SCRATCH_DOUBLES, t.float64)
         # NOTE: device temporaries must stay referenced until the call is enqueued (the caching allocator
         # would otherwise hand the same block to the next to_dev()).
-        d_off, d_len, d_eoff = self.to_dev_pack(seg_off, seg_len, edc_off)
+        d_off, d_len, d_eoff = self.job_tables(seg_off, seg_len, edc_off)
         check(self.lib.ira_edc_db(_ptr(x_dev), _ptr(d_off), _ptr(d_len), n, int(seg_len.max()), float(eps),
                                   float(floor_db), _ptr(out),
                                   _ptr(out64), _ptr(d_eoff), _ptr(scratch), self.stream), "ira_edc_db")
@@ -425,7 +433,7 @@ class Engine:
         t = self.torch
         lens = np.ascontiguousarray(lens, dtype=np.int64)
         out = self.empty(int(lens.sum()), t.float32)
-        d_off, d_len = self.to_dev_pack(np.ascontiguousarray(off, np.int64), lens)
+        d_off, d_len = self.job_tables(np.ascontiguousarray(off, np.int64), lens)
         check(self.lib.ira_edc_box_smooth(_ptr(edc64_dev), _ptr(d_off), _ptr(d_len), int(lens.size), int(lens.max()),
                                           int(window), float(floor_db), _ptr(out), self.stream), "ira_edc_box_smooth")
         return out
@@ -451,7 +459,7 @@ class Engine:
         out = self.empty(int(seg_len.sum()), t.float32) if want_edc else None
         scratch = self.empty(n * EDC_SCRATCH_DOUBLES, t.float64)
         flat = [v for r in ranges for v in r]
-        d_off, d_len, d_eoff = self.to_dev_pack(np.ascontiguousarray(seg_off, np.int64), seg_len,
+        d_off, d_len, d_eoff = self.job_tables(np.ascontiguousarray(seg_off, np.int64), seg_len,
                                                 edc_off if want_edc else None)
         check(self.lib.ira_edc_fits(_ptr(x_dev), _ptr(d_off), _ptr(d_len), n, int(seg_len.max()) if n else 0,
                                     float(eps), float(floor_db), float(t_mul), float(t_div), _lib.dbl_array(flat), nr,
@@ -472,7 +480,7 @@ class Engine:
         fit = self.empty(n * max(nr, 1) * FIT_DOUBLES, t.float64)
         cr = self.empty(n * max(nc, 1), t.float64)
         flat = [v for r in ranges for v in r]
-        d_off, d_len = self.to_dev_pack(off, lens)
+        d_off, d_len = self.job_tables(off, lens)
         check(self.lib.ira_curve_fits(_ptr(y_dev), _ptr(d_off), _ptr(d_len), n,
                                       int(lens.max()) if n else 0, float(t_mul), float(t_div), _ptr(t_axis_dev),
                                       _lib.dbl_array(flat), nr,
@@ -504,7 +512,7 @@ class Engine:
             if n > 1:
                 sel_off[1:] = np.cumsum(cols[:-1])
             if cols.sum():
-                sel, sel_off_dev = self.to_dev_pack(np.concatenate(frame_sel).astype(np.int32), sel_off)
+                sel, sel_off_dev = self.job_tables(np.concatenate(frame_sel).astype(np.int32), sel_off)
             else:
                 sel, sel_off_dev = self.empty(1, t.int32), self.to_dev(sel_off)
         else:
@@ -516,7 +524,7 @@ class Engine:
         if n > 1:
             out_off[1:] = np.cumsum(sizes[:-1])
         out = self.empty(int(sizes.sum()), t.float32)
-        d_off, d_cols, d_ooff = self.to_dev_pack(seg_off, cols, out_off)
+        d_off, d_cols, d_ooff = self.job_tables(seg_off, cols, out_off)
         self.event_tag = f"[f{precision},n{n_fft}{',sel' if frame_sel is not None else ''}]"
         fn = self.lib.ira_stft_mag_db_tf if frame_major else self.lib.ira_stft_mag_db
         check(fn(_ptr(x_dev), _ptr(d_off), _ptr(d_cols), n, int(cols.max()) if n else 0, int(n_fft), int(hop),
@@ -538,7 +546,7 @@ class Engine:
         if n > 1:
             out_off[1:] = np.cumsum(sizes[:-1])
         out = self.empty(int(sizes.sum()), t.float32)
-        d_off, d_cols, d_ooff, d_f, d_c = self.to_dev_pack(seg_off, cols, out_off, first.astype(np.int32),
+        d_off, d_cols, d_ooff, d_f, d_c = self.job_tables(seg_off, cols, out_off, first.astype(np.int32),
                                                            count.astype(np.int32))
         self.event_tag = f"[f64,n{n_fft}]"
         check(self.lib.ira_stft_logbin(_ptr(x_dev), _ptr(d_off), _ptr(d_cols), n, int(cols.max()) if n else 0,
@@ -930,7 +938,7 @@ class Engine:
                     a_dl, a_wl = data_len[j1], win_len[j1]
                     if not half_ok:
                         a_dl2, a_wl2 = data_len[safe], win_len[safe]
-                d_xo, d_so, d_x2, d_so2, d_zo, d_dl, d_wl, d_dl2, d_wl2 = self.to_dev_pack(
+                d_xo, d_so, d_x2, d_so2, d_zo, d_dl, d_wl, d_dl2, d_wl2 = self.job_tables(
                     xoff[j1], spec_off[j1], a_x2, a_so2, a_zo, a_dl, a_wl, a_dl2, a_wl2)
                 check(self.lib.ira_rfft_smooth(_ptr(x_dev), _ptr(d_xo), nt, int(j1.size), 1 if use_hann else 0,
                                                _ptr(t1), _ptr(t2), _ptr(tf), _ptr(work), _ptr(spec), _ptr(d_so),
@@ -990,7 +998,7 @@ class Engine:
                 a_dl = jl
                 a_wl = np.where(jh, lengths[j1], jl).astype(np.int32)       # the Hann window belongs to the REAL signal
                 a_il = jh.astype(np.int32)
-            d_xo, d_l, d_bi, d_so, d_x2, d_so2, d_zo, d_dl, d_wl, d_dl2, d_wl2, d_il = self.to_dev_pack(
+            d_xo, d_l, d_bi, d_so, d_x2, d_so2, d_zo, d_dl, d_wl, d_dl2, d_wl2, d_il = self.job_tables(
                 xoff[j1], jl, bidx, spec_off[j1], a_x2, a_so2, a_zo, a_dl, a_wl, a_dl2, a_wl2, a_il)
             if not padded and a_dl is not None:
                 d_dl2, d_wl2 = d_dl, d_wl
@@ -1064,7 +1072,7 @@ class Engine:
                 t1, t2, tf = self.smooth_tables(nt)
                 for sel in self._chunks_of(grp, 16 * nt):
                     work = self.empty(int(sel.size) * 2 * nt, t.float64)
-                    d_so, d_bp, d_fv, d_y1, d_y2, d_so2 = self.to_dev_pack(
+                    d_so, d_bp, d_fv, d_y1, d_y2, d_so2 = self.job_tables(
                         spec_off[j1][sel], np.ascontiguousarray(el_par[sel]), np.ascontiguousarray(freq_val[j1][sel]),
                         np.ascontiguousarray(y_off[j1][sel]), np.ascontiguousarray(el_y2[sel]),
                         None if halves else np.ascontiguousarray(el_so2[sel]))
@@ -1106,7 +1114,7 @@ class Engine:
         total = int((lengths.astype(np.int64) // 2 + 1).sum())
         mag = self.empty(total, t.float32)
         ph = self.empty(total, t.float64) if want_phase else None
-        d_so, d_l, d_pk = self.to_dev_pack(spec_off, lengths, None if packed is None else np.ascontiguousarray(packed, np.int32))
+        d_so, d_l, d_pk = self.job_tables(spec_off, lengths, None if packed is None else np.ascontiguousarray(packed, np.int32))
         check(self.lib.ira_spectrum_mag_phase(_ptr(spec_dev), _ptr(d_so), _ptr(d_l), n, int(lengths.max()),
                                               float(floor_db), _ptr(mag), _ptr(d_so), _ptr(ph), _ptr(d_so), _ptr(d_pk),
                                               self.stream), "ira_spectrum_mag_phase")
@@ -1119,7 +1127,7 @@ class Engine:
         lengths = np.ascontiguousarray(lengths, dtype=np.int32)
         total = int((lengths.astype(np.int64) // 2 + 1).sum())
         out = self.empty(total, t.float64 if as_float64 else t.float32)
-        d_o, d_l = self.to_dev_pack(off, lengths)
+        d_o, d_l = self.job_tables(off, lengths)
         check(self.lib.ira_phase_unwrap(_ptr(phase_dev), _ptr(d_o), _ptr(d_l), int(off.size), 1 if unwrap else 0,
                                         1 if degrees else 0, 0 if as_float64 else _ptr(out), _ptr(d_o),
                                         _ptr(out) if as_float64 else 0, self.stream), "ira_phase_unwrap")
@@ -1144,7 +1152,7 @@ class Engine:
             return True
         if int(count.max()) > 2048 or not np.all(np.isfinite(a)):
             return False
-        d = self.to_dev_pack(np.ascontiguousarray(off, np.int64), np.ascontiguousarray(stride, np.int32), k_lo, nsel, fstep,
+        d = self.job_tables(np.ascontiguousarray(off, np.int64), np.ascontiguousarray(stride, np.int32), k_lo, nsel, fstep,
                              a, b, count)
         check(self.lib.ira_log_smooth_db(_ptr(mag_dev), *[_ptr(x) for x in d], n, int(count.max()), int(window),
                                          1 if through_float32 else 0, self.stream), "ira_log_smooth_db")
@@ -1217,7 +1225,7 @@ class Engine:
                 f = int(d.size > 0 and not bool(np.all(d == d[0])))
                 self._gd_nonuniform[key] = f
             known[i] = f
-        d_o, d_n, d_v, flags = self.to_dev_pack(np.ascontiguousarray(off, np.int64), nbins, bin_step, known)
+        d_o, d_n, d_v, flags = self.job_tables(np.ascontiguousarray(off, np.int64), nbins, bin_step, known)
         check(self.lib.ira_group_delay(_ptr(phase64_dev), _ptr(d_o), _ptr(d_n), n, int(nbins.max()), _ptr(d_v),
                                        float(sample_rate_hz), _ptr(flags), 1, _ptr(gd), self.stream), "ira_group_delay")
         return gd
@@ -1230,7 +1238,7 @@ class Engine:
         n = int(off.size)
         lengths = np.ascontiguousarray(lengths, dtype=np.int32)
         out = self.empty(n * 8, t.float64)
-        d_o, d_l, d_fv = self.to_dev_pack(off, lengths, np.ascontiguousarray(freq_val, np.float64))
+        d_o, d_l, d_fv = self.job_tables(off, lengths, np.ascontiguousarray(freq_val, np.float64))
         check(self.lib.ira_spectrum_stats(_ptr(mag_dev), _ptr(d_o), _ptr(d_l), n, _ptr(d_fv), float(f_min),
                                           float(f_max), float(probe_hz), _ptr(out), self.stream), "ira_spectrum_stats")
         return out[: n * 8].view(n, 8)
@@ -1247,7 +1255,7 @@ class Engine:
         if n > 1:
             out_off[1:] = np.cumsum(sizes[:-1])
         out = self.empty(int(sizes.sum()), t.float32)
-        d_mo, d_ns, d_oo = self.to_dev_pack(mag_off, nslices, out_off)
+        d_mo, d_ns, d_oo = self.job_tables(mag_off, nslices, out_off)
         check(self.lib.ira_waterfall_rel(_ptr(mag_dev), _ptr(d_mo), _ptr(d_ns), n, int(k_lo), int(nsel),
                                          1 if slice_max else 0, float(dyn_db), _ptr(out), _ptr(d_oo), self.stream),
               "ira_waterfall_rel")
@@ -1288,7 +1296,7 @@ class Engine:
         gs = self.empty(n * order * order, t.float64) if order > 128 else None
         coeffs = self.empty(n * (order + 1), t.float64)
         info = self.empty(n * 4, t.float64)
-        d_xo, d_l, d_div = self.to_dev_pack(np.ascontiguousarray(xoff, np.int64), lengths,
+        d_xo, d_l, d_div = self.job_tables(np.ascontiguousarray(xoff, np.int64), lengths,
                                             np.ascontiguousarray(divisor, np.float64) if divisor is not None else None)
         flags = (1 if self.ar_dense_gram else 0) | (2 if self.ar_workgroup_solve else 0)   # IRA_AR_DENSE_GRAM | IRA_AR_WORKGROUP_SOLVE
         check(self.lib.ira_ar_gram(0 if x_is_f64 else _ptr(x_dev), _ptr(x_dev) if x_is_f64 else 0, _ptr(d_xo),

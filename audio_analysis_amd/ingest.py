@@ -253,7 +253,7 @@ class TapSet:
             chans = np.array([infos[i].channels for i in nat], dtype=np.int32)
             modes = np.array([1 if (mono and infos[i].channels == 2) else 0 for i in nat], dtype=np.int32)
             dst_off = np.array([int(off[first_channel[i]]) for i in nat], dtype=np.int64)
-            d_src, d_fr, d_ch, d_mo, d_dst = eng.to_dev_pack(src_off, frames, chans, modes, dst_off)
+            d_src, d_fr, d_ch, d_mo, d_dst = eng.job_tables(src_off, frames, chans, modes, dst_off)
             check(eng.lib.ira_pcm16_to_channels_jobs(int(self._pcm_dev.data_ptr()), int(d_src.data_ptr()),
                                                      int(d_fr.data_ptr()), int(d_ch.data_ptr()), int(d_mo.data_ptr()),
                                                      int(d_dst.data_ptr()), len(nat), int(frames.max()),

@@ -31,6 +31,6 @@ try:
     torch.cuda.synchronize(); pr.disable()
     dt = time.perf_counter() - t0
     print(f"{a.taps} taps in {dt*1e3:.1f} ms = {a.taps/dt:.0f} taps/s, {1e3*dt/(a.taps/a.per_step):.2f} ms per step of {a.per_step}")
-    pstats.Stats(pr).sort_stats("cumulative").print_stats(16)
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(16); pstats.Stats(pr).sort_stats("tottime").print_stats(30)
 finally:
     shutil.rmtree(a.root, ignore_errors=True)
