@@ -414,6 +414,137 @@ __device__ __forceinline__ void chol_solve_inplace(const double* G, double* vec,
   }
 }
 
+// ---- blocked variants for a Gram matrix that lives in GLOBAL scratch (p > SV_LDS_P; round 5) ---------------------------------
+// The column-by-column loops above, run on global memory, cost three workgroup barriers and a read-modify-write of the
+// trailing matrix through L2 per COLUMN (and two barriers + an uncoalesced column read per column of every triangular
+// sweep): 8.1 ms per 256 fits at the reference CLI's default order 256 (cli.py:245), 70 % of config 4's step there.
+// Blocked: a panel of nb columns is factored in LDS (same operations, LDS latency), the trailing matrix is updated ONCE per
+// panel from the LDS copy in 4 x 4 register tiles, and a triangular sweep handles nb unknowns per round (one wave solves the
+// diagonal block with shuffles, the other rows take the block's contribution with one pass over their nb entries).
+__device__ __forceinline__ int sv_block(int p) { return p <= 384 ? 32 : 16; }
+__host__ __device__ inline size_t sv_blocked_lds_doubles(int p) {
+  const int nb = p <= 384 ? 32 : 16;
+  return (size_t)p * (nb + 1) + (size_t)nb * (nb + 1);
+}
+
+__device__ void chol_factor_blocked(double* __restrict__ G, int p, double* pan, int tid, double* piv_s, int* fail_s,
+                                    double& dmax, double& dmin) {
+  const int nb = sv_block(p), ld = nb + 1;
+  for (int kb = 0; kb < p; kb += nb) {
+    const int w = (p - kb) < nb ? (p - kb) : nb, m = p - kb;
+    for (int idx = tid; idx < m * w; idx += SV_THREADS) {
+      const int i = idx / w, c = idx - i * w;
+      pan[i * ld + c] = G[(long long)(kb + i) * p + kb + c];
+    }
+    __syncthreads();
+    for (int c = 0; c < w; ++c) {
+      if (tid == 0) {
+        const double d = pan[c * ld + c];
+        if (!(d > 0.0)) { *fail_s = 1; *piv_s = 1.0; }
+        else *piv_s = sqrt(d);
+      }
+      __syncthreads();
+      const double d = *piv_s;
+      dmax = fmax(dmax, d); dmin = fmin(dmin, d);
+      for (int i = c + tid; i < m; i += SV_THREADS) pan[i * ld + c] = (i == c) ? d : pan[i * ld + c] / d;
+      __syncthreads();
+      const int wc = w - c - 1;                                  // columns of the panel still to update
+      for (int idx = tid; idx < (m - c - 1) * wc; idx += SV_THREADS) {
+        const int ii = idx / wc, jj = idx - ii * wc;
+        const int i = c + 1 + ii, j = c + 1 + jj;
+        if (i >= j) pan[i * ld + j] -= pan[i * ld + c] * pan[j * ld + c];
+      }
+      __syncthreads();
+    }
+    for (int idx = tid; idx < m * w; idx += SV_THREADS) {
+      const int i = idx / w, c = idx - i * w;
+      if (i >= c) G[(long long)(kb + i) * p + kb + c] = pan[i * ld + c];
+    }
+    // trailing matrix (rows and columns >= kb + w, lower triangle): G[i][j] -= sum_c L[i][c] L[j][c], 4 x 4 tiles per thread
+    const int m2 = m - w, nt = (m2 + 3) >> 2;
+    for (int t = tid; t < nt * nt; t += SV_THREADS) {
+      const int ti = t / nt, tj = t - ti * nt;
+      if (tj > ti) continue;
+      const int i0 = w + 4 * ti, j0 = w + 4 * tj;                // panel-row indices
+      double acc[4][4] = {};
+      for (int c = 0; c < w; ++c) {
+        double a[4], b[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          a[r] = pan[(i0 + r < m ? i0 + r : m - 1) * ld + c];
+          b[r] = pan[(j0 + r < m ? j0 + r : m - 1) * ld + c];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[r][q] = fma(a[r], b[q], acc[r][q]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = i0 + r, j = j0 + q;
+          if (i < m && j <= i) G[(long long)(kb + i) * p + kb + j] -= acc[r][q];
+        }
+    }
+    __syncthreads();
+  }
+}
+
+// L y = r, L^T a = y in place on vec (LDS), L in global memory; blk = nb x (nb + 1) doubles of LDS.  All threads call.
+__device__ void chol_solve_blocked(const double* __restrict__ G, double* vec, int p, double* blk, int tid) {
+  const int nb = sv_block(p), ld = nb + 1;
+  for (int kb = 0; kb < p; kb += nb) {
+    const int w = (p - kb) < nb ? (p - kb) : nb;
+    for (int idx = tid; idx < w * w; idx += SV_THREADS) {
+      const int i = idx / w, c = idx - i * w;
+      blk[i * ld + c] = G[(long long)(kb + i) * p + kb + c];
+    }
+    __syncthreads();
+    if (tid < IRA_WAVE) {                                        // one wave: the diagonal block, column by column
+      double v = tid < w ? vec[kb + tid] : 0.0;
+      for (int c = 0; c < w; ++c) {
+        const double yc = __shfl(v, c, IRA_WAVE) / blk[c * ld + c];
+        if (tid == c) v = yc;
+        else if (tid > c && tid < w) v -= blk[tid * ld + c] * yc;
+      }
+      if (tid < w) vec[kb + tid] = v;
+    }
+    __syncthreads();
+    for (int i = kb + w + tid; i < p; i += SV_THREADS) {
+      const double* row = G + (long long)i * p + kb;
+      double sacc = vec[i];
+      for (int c = 0; c < w; ++c) sacc -= row[c] * vec[kb + c];
+      vec[i] = sacc;
+    }
+    __syncthreads();
+  }
+  for (int kb = ((p - 1) / nb) * nb; kb >= 0; kb -= nb) {
+    const int w = (p - kb) < nb ? (p - kb) : nb;
+    for (int idx = tid; idx < w * w; idx += SV_THREADS) {
+      const int i = idx / w, c = idx - i * w;
+      blk[i * ld + c] = G[(long long)(kb + i) * p + kb + c];
+    }
+    __syncthreads();
+    if (tid < IRA_WAVE) {
+      double v = tid < w ? vec[kb + tid] : 0.0;
+      for (int c = w - 1; c >= 0; --c) {
+        const double ac = __shfl(v, c, IRA_WAVE) / blk[c * ld + c];
+        if (tid == c) v = ac;
+        else if (tid < c) v -= blk[c * ld + tid] * ac;
+      }
+      if (tid < w) vec[kb + tid] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < kb; i += SV_THREADS) {
+      double sacc = vec[i];
+      for (int c = 0; c < w; ++c) sacc -= G[(long long)(kb + c) * p + i] * vec[kb + c];
+      vec[i] = sacc;
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(SV_THREADS) void ar_solve_kernel(const double* __restrict__ part,
                                                               const int32_t* __restrict__ nlen, int p,
                                                               int nchunks_max, double ridge,
@@ -510,6 +641,12 @@ __global__ __launch_bounds__(SV_THREADS) void ar_solve_kernel(const double* __re
   double dmax = 0.0, dmin = INFINITY;
 
   // ---- Cholesky, right-looking, lower triangle in place ---------------------------------------------------
+  const bool in_lds = p <= SV_LDS_P;
+  double* pan = vec + p;                                        // blocked path: panel, then the diagonal block (LDS)
+  double* blk = pan + (size_t)p * (sv_block(p) + 1);
+  if (!in_lds) {
+    chol_factor_blocked(G, p, pan, tid, &piv, &fail, dmax, dmin);
+  } else
   for (int k = 0; k < p; ++k) {
     if (tid == 0) {
       const double d = G[k * p + k];
@@ -531,7 +668,7 @@ __global__ __launch_bounds__(SV_THREADS) void ar_solve_kernel(const double* __re
     }
     __syncthreads();
   }
-  chol_solve_inplace(G, vec, p, tid);
+  if (in_lds) chol_solve_inplace(G, vec, p, tid); else chol_solve_blocked(G, vec, p, blk, tid);
   double* co = coeffs + (long long)e * (p + 1);
   if (gpart != nullptr) {
     if (!fail)
@@ -560,7 +697,7 @@ __global__ __launch_bounds__(SV_THREADS) void ar_solve_kernel(const double* __re
       const double inv = 1.0 / nrm_s;
       for (int j = tid; j < p; j += SV_THREADS) vec[j] *= inv;
       __syncthreads();
-      chol_solve_inplace(G, vec, p, tid);
+      if (in_lds) chol_solve_inplace(G, vec, p, tid); else chol_solve_blocked(G, vec, p, blk, tid);
     }
     if (tid == 0) {
       double q = 0.0;
@@ -1332,6 +1469,7 @@ extern "C" int32_t ira_ar_solve(const double* partial_dev, const int32_t* len_de
   const int nchunks = (int)(((int64_t)max_len - order + GR_CHUNK - 1) / GR_CHUNK);
   size_t lds = sizeof(double) * (size_t)order;
   if (order <= SV_LDS_P) lds += sizeof(double) * (size_t)order * order;
+  else lds += sizeof(double) * sv_blocked_lds_doubles(order);        // panel + diagonal block of the blocked factorisation
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ar_solve_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1417,6 +1555,7 @@ extern "C" int32_t ira_ar_refine(const float* x_dev, const double* x64_dev, cons
   const int nchunks = (int)(((int64_t)max_len - order + GR_CHUNK - 1) / GR_CHUNK);
   size_t lds_s = sizeof(double) * (size_t)order;
   if (order <= SV_LDS_P) lds_s += sizeof(double) * (size_t)order * order;
+  else lds_s += sizeof(double) * sv_blocked_lds_doubles(order);
   if (lds_s > 64 * 1024) {
     hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&ar_solve_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
