@@ -37,7 +37,26 @@ def init_process_group(backend: Optional[str] = None):
             backend = os.environ.get("IRA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # The gloo transport announces its connections on the process's STDOUT ("[Gloo] Rank 0 is connected to ..."), from
+        # C++: it would precede the one JSON line a benchmark's rank 0 prints.  File descriptor 1 points at stderr while
+        # the group is set up (Python's sys.stdout is flushed first and keeps its own descriptor number).
+        saved = None
+        if backend == "gloo":
+            import sys
+            try:
+                sys.stdout.flush()
+                saved = os.dup(1)
+                os.dup2(2, 1)
+            except OSError:
+                saved = None
+        try:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            if saved is not None:
+                dist.barrier()                       # (the announcements are printed when the first collective connects)
+        finally:
+            if saved is not None:
+                os.dup2(saved, 1)
+                os.close(saved)
     return rank, local_rank, world
 
 
