@@ -169,13 +169,25 @@ def run_bundle_metrics(bundle_root: str | Path, settings=None, use_mono_downmix_
     # (IRA_BUNDLE_DEPTH submitted steps in flight before the oldest is read back: 2 or 3 were measured against 1 at the end
     # of round 4 -- no gain, the loop is bound by the host's ~10 ms of work per 256 channels either way)
     depth = max(1, int(os.environ.get("IRA_BUNDLE_DEPTH", "1")))
+    # The reader thread runs `ahead_n` groups ahead (default 2; IRA_BUNDLE_PREFETCH is the A/B switch).  With one group ahead
+    # the reader only starts on group k+1 when the main thread picks up group k, and then has to win the interpreter lock
+    # back from a main thread that spends the next milliseconds in pure Python (submit).  Measured, config 5 on one GPU,
+    # alternating (profiles/r05_bundle_ab.txt): one group ahead 9.6 k stereo taps/s, two 10.8 k, three 10.0-10.2 k.  A shorter
+    # interpreter switch interval for the duration of the loop (IRA_BUNDLE_SWITCH_US, default off) was measured too:
+    # 0.5 ms 9.8-10.7 k, 0.1 ms 9.2-9.3 k -- not adopted.
+    ahead_n = max(1, int(os.environ.get("IRA_BUNDLE_PREFETCH", "2")))
+    switch_before = sys.getswitchinterval()
+    switch_us = float(os.environ.get("IRA_BUNDLE_SWITCH_US", "0"))
+    if switch_us > 0:
+        sys.setswitchinterval(switch_us * 1e-6)
     with ThreadPoolExecutor(max_workers=1, thread_name_prefix="ira-prefetch") as ahead:
-        nxt_set = ahead.submit(host_half, groups[0]) if groups else None
+        queue = [ahead.submit(host_half, groups[i]) for i in range(min(ahead_n, len(groups)))]
         for gi, names in enumerate(groups):
             t0 = time.perf_counter() if timing is not None else 0.0
-            tapset = nxt_set.result()
+            tapset = queue.pop(0).result()
             t0 = lap("wait for the reader thread", t0)
-            nxt_set = ahead.submit(host_half, groups[gi + 1]) if gi + 1 < len(groups) else None
+            if gi + ahead_n < len(groups):
+                queue.append(ahead.submit(host_half, groups[gi + ahead_n]))
             batch, lab = tapset.view(use_mono_downmix_for_stereo)
             labels += [(names[i], ch) for i, ch in lab]
             t0 = lap("view (upload + conversion enqueued)", t0)
@@ -188,6 +200,7 @@ def run_bundle_metrics(bundle_root: str | Path, settings=None, use_mono_downmix_
                     rows.append(fr.finish(pending.pop(0)))
                     t0 = lap("finish", t0)
             uploaded = batch
+        sys.setswitchinterval(switch_before)
         if timing is not None and groups:
             print("[bundle] host ms per group: " + ", ".join(f"{k} {1e3 * v / len(groups):.2f}" for k, v in timing.items()),
                   file=sys.stderr)
