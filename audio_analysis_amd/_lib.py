@@ -13,7 +13,7 @@ _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libira.so"
 _lib = None
 # must equal IRA_ABI_VERSION of include/ira.h: a stale .so called with this file's prototypes would read shifted
 # arguments or undersized scratch (memory corruption on the GPU instead of a clean error)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_f32p = C.c_void_p
 c_i64p = C.c_void_p
@@ -34,7 +34,7 @@ PROTOTYPES = {
                              f64, f64, vp, vp, vp]),
     "ira_edc_box_smooth": (i32, [vp, vp, vp, i32, C.c_int64, i32, f64, vp, vp]),
     "ira_edc_fits": (i32, [vp, vp, vp, i32, C.c_int64, f64, f64, f32, f32, C.POINTER(f64), i32, i32, C.POINTER(f64), i32,
-                           vp, vp, vp, vp, vp, vp]),
+                           vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "ira_stft_mag_db": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, f64, vp, vp, vp, vp, vp]),
     "ira_stft_logbin": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, f64, i32, vp, vp, i32, vp, vp, vp]),
     "ira_stft_mag_db_tf": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, f64, vp, vp, vp, vp, vp]),
@@ -49,7 +49,8 @@ PROTOTYPES = {
     "ira_group_delay": (i32, [vp, vp, vp, i32, i32, vp, f64, vp, i32, vp, vp]),
     "ira_fft_smooth_split": (i32, [i32, vp, vp]),
     "ira_rfft_smooth": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
-    "ira_band_irfft_smooth": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]),
+    "ira_band_irfft_smooth": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]),
+    "ira_band_tile_layout": (i32, [i32, i32, C.POINTER(i32), C.POINTER(i32)]),
     "ira_wav_probe": (i32, [C.c_char_p, vp, vp, vp, vp]),
     "ira_wav_read_pcm16": (i32, [C.c_char_p, C.c_int64, C.c_int64, i32, vp]),
     "ira_wav_probe_batch": (i32, [vp, i32, i32, vp, vp, vp, vp, vp]),

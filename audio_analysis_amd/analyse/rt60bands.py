@@ -250,8 +250,13 @@ def rt60_bands_device(eng, batch, sample_rate_hz: int, settings: Rt60BandsAnalys
         # one entry per (channel, band); the engine pairs entries of equal length two per inverse transform
         fv_of = {int(v): rfft_bin_step(int(v), sample_rate_hz) for v in np.unique(n64)}
         fv = np.array([fv_of[int(v)] for v in n64], dtype=np.float64)
-        eng.band_irfft(spec, np.repeat(np.asarray(spec_off, dtype=np.int64), nb), np.repeat(n64, nb).astype(np.int32),
-                       np.tile(records, (nch, 1)), np.repeat(fv, nb), y, y_off.reshape(-1))
+        # (the inverses also leave the energies of every band signal's EDC tiles: the fused fits below then read a band
+        # signal once less -- not for the smoothed-curve path, which materialises the curve through ira_edc_db)
+        band_tiles = eng.band_irfft(spec, np.repeat(np.asarray(spec_off, dtype=np.int64), nb),
+                                    np.repeat(n64, nb).astype(np.int32), np.tile(records, (nch, 1)), np.repeat(fv, nb), y,
+                                    y_off.reshape(-1), want_tiles=smooth <= 1)
+    else:
+        band_tiles = None
 
     # Schroeder EDC + fits on every (channel, band) tail with at least 8 samples
     tail_c = n64 - start.astype(np.int64)
@@ -277,8 +282,12 @@ def rt60_bands_device(eng, batch, sample_rate_hz: int, settings: Rt60BandsAnalys
         else:
             # fused EDC -> crossings -> fits (ira_edc_fits): a band's EDC curve only feeds its fits (reference
             # rt60bands.py:272-321), so it is never written
+            seg_tiles = None
+            if band_tiles is not None:
+                entry = seg_c * nb + seg_b                     # the (channel, band) entry of every segment; a segment ends
+                seg_tiles = (band_tiles[0], band_tiles[1][entry], band_tiles[2][entry], band_tiles[3][entry])   # where its signal ends
             fit_dev, _, _, _ = eng.edc_fits(y, seg_off_a, seg_len_a, dec.edc_epsilon, dec.edc_floor_db, 1.0,
-                                            float(sample_rate_hz), ranges, 8)
+                                            float(sample_rate_hz), ranges, 8, tiles=seg_tiles)
         ci, bi = seg_c, seg_b
         have[ci, bi] = True
 

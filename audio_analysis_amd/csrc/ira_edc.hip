@@ -173,13 +173,16 @@ __device__ __forceinline__ void tile_suffix_scan(const float x[EDC_PER_THREAD], 
 
 __global__ __launch_bounds__(EDC_THREADS) void edc_sums_kernel(
     const float* __restrict__ x, const int64_t* __restrict__ off, const int64_t* __restrict__ len,
-    double* __restrict__ scratch) {
+    double* __restrict__ scratch, const int64_t* __restrict__ part_off) {
   __shared__ EdcShared sh;
   const int seg = blockIdx.y;
   const int64_t j = blockIdx.x;
   const int64_t n = len[seg];
   const int64_t ntiles = (n + EDC_TILE - 1) / EDC_TILE;
   if (j >= ntiles) return;
+  // segments whose producer delivered tile energies (edc_tiles_from_parts_kernel) scan only the tile that holds their first
+  // sample: the normaliser edc[0] = tot[T-1] + carry[T-1] must be the value the emit / fit scans form at index 0
+  if (part_off != nullptr && part_off[seg] >= 0 && j < ntiles - 1) return;
   const int64_t hi = n - j * EDC_TILE;
   const int64_t lo = hi - EDC_TILE > 0 ? hi - EDC_TILE : 0;
   float xv[EDC_PER_THREAD];
@@ -187,6 +190,33 @@ __global__ __launch_bounds__(EDC_THREADS) void edc_sums_kernel(
   double s[EDC_PER_THREAD];
   tile_suffix_scan(xv, sh, 0, s);
   if (threadIdx.x == 0) scratch[(int64_t)seg * IRA_EDC_SCRATCH_DOUBLES + j] = s[0];
+}
+
+// Tile totals from the partial energies the band inverse's second pass left behind (ira_fftsmooth.hip, band_tile_partials):
+// part[part_off[seg] + w * tiles + j], w < wgs, is workgroup w's share of the energy of the signal's tile j (tiles of EDC_TILE
+// samples counted from the END of the signal -- which is the end of the segment, so segment tile j IS signal tile j for every
+// tile but the one that holds the segment's first sample; `tiles` = the SIGNAL's tile count, which the segment's last sample
+// index gives: the signal is the segment plus what was trimmed in front of it ... the caller passes it per segment).
+// One thread per tile adds the wgs partials in ascending order (coalesced: the threads of a workgroup read neighbouring
+// tiles of the same producer workgroup): the total does not depend on scheduling.
+__global__ __launch_bounds__(128) void edc_tiles_from_parts_kernel(const int64_t* __restrict__ len,
+                                                                   const double* __restrict__ part,
+                                                                   const int64_t* __restrict__ part_off,
+                                                                   const int32_t* __restrict__ part_wgs,
+                                                                   const int32_t* __restrict__ part_tiles,
+                                                                   double* __restrict__ scratch) {
+  const int seg = blockIdx.y;
+  const int64_t n = len[seg];
+  const int64_t ntiles = (n + EDC_TILE - 1) / EDC_TILE;
+  const int64_t po = part_off[seg];
+  if (po < 0) return;
+  const int wgs = part_wgs[seg], tiles = part_tiles[seg];
+  const double* p = part + po;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < ntiles - 1; j += (int64_t)gridDim.x * blockDim.x) {
+    double acc = 0.0;
+    for (int w = 0; w < wgs; ++w) acc += p[(int64_t)w * tiles + j];
+    scratch[(int64_t)seg * IRA_EDC_SCRATCH_DOUBLES + j] = acc;
+  }
 }
 
 // numpy.maximum semantics: a NaN operand gives NaN (fmax would drop it).  A NaN sample makes the reference's whole
@@ -1078,7 +1108,7 @@ extern "C" int32_t ira_edc_db(const float* x_dev, const int64_t* off_dev, const 
   hipStream_t st = (hipStream_t)stream;
   const int ntiles = (int)((max_len + EDC_TILE - 1) / EDC_TILE);
   if (nseg > 65535) return IRA_E_SIZE;
-  edc_sums_kernel<<<dim3(ntiles, nseg), EDC_THREADS, 0, st>>>(x_dev, off_dev, len_dev, scratch_dev);
+  edc_sums_kernel<<<dim3(ntiles, nseg), EDC_THREADS, 0, st>>>(x_dev, off_dev, len_dev, scratch_dev, nullptr);
   edc_carry_kernel<<<nseg, IRA_WAVE, 0, st>>>(len_dev, nseg, eps, scratch_dev);
   edc_emit_kernel<<<dim3(ntiles, nseg), EDC_THREADS, 0, st>>>(x_dev, off_dev, len_dev, eps, floor_db, edc_db_dev,
                                                               edc_db64_dev, edc_off_dev, scratch_dev);
@@ -1090,7 +1120,8 @@ extern "C" int32_t ira_edc_fits(const float* x_dev, const int64_t* off_dev, cons
                                 const double* ranges_hi_lo, int32_t nranges, int32_t min_points,
                                 const double* cross_targets, int32_t ncross, double* fit_out_dev,
                                 double* cross_out_dev, float* edc_db_dev, const int64_t* edc_off_dev,
-                                double* scratch_dev, void* stream) {
+                                double* scratch_dev, const double* tile_part_dev, const int64_t* part_off_dev,
+                                const int32_t* part_wgs_dev, const int32_t* part_tiles_dev, void* stream) {
   IRA_CHECK_PTR(x_dev); IRA_CHECK_PTR(off_dev); IRA_CHECK_PTR(len_dev); IRA_CHECK_PTR(scratch_dev);
   if (nranges < 0 || nranges > FIT_MAX_RANGES || ncross < 0 || ncross > FIT_MAX_CROSS) return IRA_E_SIZE;
   if (nranges > 0) { IRA_CHECK_PTR(ranges_hi_lo); IRA_CHECK_PTR(fit_out_dev); }
@@ -1111,7 +1142,13 @@ extern "C" int32_t ira_edc_fits(const float* x_dev, const int64_t* off_dev, cons
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(EdcFitShared));
     if (e != hipSuccess) return ira_hip_status(e);
   }
-  edc_sums_kernel<<<dim3(ntiles, nseg), EDC_THREADS, 0, st>>>(x_dev, off_dev, len_dev, scratch_dev);
+  if (tile_part_dev != nullptr && (part_off_dev == nullptr || part_wgs_dev == nullptr || part_tiles_dev == nullptr))
+    return IRA_E_NULL;
+  edc_sums_kernel<<<dim3(ntiles, nseg), EDC_THREADS, 0, st>>>(x_dev, off_dev, len_dev, scratch_dev,
+                                                              tile_part_dev ? part_off_dev : nullptr);
+  if (tile_part_dev != nullptr && ntiles > 1)
+    edc_tiles_from_parts_kernel<<<dim3((ntiles - 1 + 127) / 128, nseg), 128, 0, st>>>(len_dev, tile_part_dev, part_off_dev,
+                                                                                      part_wgs_dev, part_tiles_dev, scratch_dev);
   edc_carry_kernel<<<nseg, IRA_WAVE, 0, st>>>(len_dev, nseg, eps, scratch_dev);
   if (nranges + ncross > 0)
     edc_fit_kernel<<<nseg, EDC_THREADS, sizeof(EdcFitShared), st>>>(x_dev, off_dev, len_dev, eps, floor_db, P,

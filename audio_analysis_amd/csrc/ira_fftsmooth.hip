@@ -292,6 +292,9 @@ struct SJobs {
   // inverse, optional (null = off): per-job record of the NARROW-band path (SparseInfo below), written by
   // band_compact_kernel and read by the three kernels that follow it
   int32_t* info;
+  // inverse, optional (null = off; round 5): energies of the Schroeder-EDC tiles of every band signal, one partial per
+  // (signal, tile, workgroup of the second pass) -- see band_tile_partials
+  double* tile_part;
 };
 
 // ---- narrow bands: the first pass is a handful of terms per point, not a transform ---------------------------------------
@@ -661,6 +664,64 @@ __global__ __launch_bounds__(SM_THREADS, ((MODE == SM_SIGNAL || !HALF) ? 6 : 5))
 }
 
 // ---- pass 2: N2-point transforms for C adjacent k1.  grid (N1 / C, jobs) --------------------------------------------------
+// ---- tile energies of the band signals, from the second pass's own output stage (round 5) ---------------------------------
+// The Schroeder EDC of a band signal (ira_edc.hip) starts from the energies of its 4096-sample tiles, counted from the END
+// of the signal; edc_sums_kernel got them by reading every band signal again right after this pass had written it (config
+// 3: 12.8 GB per step).  The values are all here: after the in-LDS transform the tile `r` holds the workgroup's N2 x C
+// outputs k = k1 + N1 k2 (a comb through the whole signal), and what was stored is float32(re / n), float32(-im / n).
+// Thread j sums the squares of the workgroup's samples that fall into EDC tile j, in a fixed order (columns, then k2
+// ascending), in float64 (the square of a float32 value is exact) -> part[((job * 2 + signal) * wgs + bx) * ntile + j];
+// edc_tiles_from_parts_kernel adds the wgs partials of a tile in a fixed order.  No atomics: the totals do not depend on
+// scheduling.  (A half_out job writes ONE signal of 2 n samples, 2 k and 2 k + 1 from re and im: both go to signal 0.)
+constexpr int SM_EDC_TILE = 4096;                           // = EDC_TILE of ira_edc.hip (checked by ira_edc_fits's caller contract)
+__device__ __forceinline__ void band_tile_partials(const SmoothPlan& P, const SJobs& J, const cd* r, int LD, int k1_0, int e,
+                                                   unsigned bx, bool second, int tid) {
+  const long long n = P.n;
+  const int C = P.c2, N1 = P.n1, N2 = P.n2;
+  const bool half = J.half_out != 0;
+  const long long len = half ? 2 * n : n;
+  const int ntile = (int)((len + SM_EDC_TILE - 1) / SM_EDC_TILE), wgs = N1 / C;
+  const double sc = 1.0 / (double)n;
+  // layout [job][signal][workgroup][tile]: a workgroup's partials of one signal are contiguous (first version: [tile][workgroup],
+  // 2 x 118 scattered 8-byte stores per workgroup -- the pass lost more than ira_edc_fits gained)
+  double* base = J.tile_part + ((long long)e * 2 * wgs + bx) * ntile;
+  // two neighbouring lanes share a tile: lane parity = the first column each of them takes (the columns of a tile are dealt to
+  // the two, then added in lane order -- a fixed order); all 256 lanes work when the signal has >= 128 tiles
+  const int CS = C >= 2 ? 2 : 1;
+  for (int idx = tid; idx < ((ntile * CS + 1) & ~1); idx += SM_THREADS) {
+    const int j = idx / CS, cs = idx - j * CS;
+    double s1 = 0.0, s2 = 0.0;
+    if (j < ntile) {
+      const long long hi = len - (long long)j * SM_EDC_TILE, lo = hi > SM_EDC_TILE ? hi - SM_EDC_TILE : 0;   // samples [lo, hi)
+      const long long klo = half ? lo / 2 : lo, khi = half ? hi / 2 : hi;      // (len and the tile length are even: so are lo, hi)
+      for (int c = cs; c < C; c += CS) {
+        const long long k1 = k1_0 + c, a = klo - k1, b = khi - k1;
+        const int k2a = a <= 0 ? 0 : (int)fdiv((unsigned)(a + N1 - 1), P.dn1);
+        int k2b = b <= 0 ? 0 : (int)fdiv((unsigned)(b + N1 - 1), P.dn1);
+        k2b = k2b < N2 ? k2b : N2;
+        for (int k2 = k2a; k2 < k2b; ++k2) {
+          const cd v = r[c * LD + dif_slot(k2, P.p2)];
+          const double y1 = (double)(float)(v.re * sc), y2 = (double)(float)(-v.im * sc);
+          s1 = fma(y1, y1, s1);
+          s2 = fma(y2, y2, s2);
+        }
+      }
+    }
+    if (CS == 2) {                                             // even lane: its columns + the odd neighbour's
+      s1 += __shfl_down(s1, 1, 64);
+      s2 += __shfl_down(s2, 1, 64);
+    }
+    if (cs == 0 && j < ntile) {
+      if (half) {
+        base[j] = s1 + s2;
+      } else {
+        base[j] = s1;
+        if (second) base[(long long)wgs * ntile + j] = s2;
+      }
+    }
+  }
+}
+
 template <int OUT>
 __global__ __launch_bounds__(SM_THREADS) void smooth_rows_kernel(SmoothPlan P, SJobs J, const cd* __restrict__ work) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -786,6 +847,7 @@ __global__ __launch_bounds__(SM_THREADS) void smooth_rows_kernel(SmoothPlan P, S
       if (out2 >= 0) J.y[out2 + ko] = (float)(-v.im * sc);
     }
   }
+  if (OUT == SM_OUT_BANDS && J.tile_part != nullptr) band_tile_partials(P, J, r, LD, k1_0, e, bx, out2 >= 0, tid);
   if (IRA_ABL(P.stamp)) {
     SM_STAMP(s3);
     if (tid == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2)
@@ -921,6 +983,7 @@ __global__ __launch_bounds__(SM_THREADS, 5) void smooth_rows_sparse_kernel(Smoot
       if (out2 >= 0) J.y[out2 + k] = (float)(-v.im * sc);
     }
   }
+  if (J.tile_part != nullptr) band_tile_partials(P, J, r, LD, k1_0, e, bx, out2 >= 0, tid);
 }
 
 // split of Z = DFT(x1 + i x2) into the two half spectra (same convention as pair_split_kernel in ira_fftlong.hip)
@@ -1185,12 +1248,24 @@ extern "C" int32_t ira_rfft_smooth(const float* x_dev, const int64_t* xoff_dev, 
   IRA_RETURN_LAUNCH();
 }
 
+extern "C" int32_t ira_band_tile_layout(int32_t n, int32_t half_out, int32_t* tiles, int32_t* workgroups) {
+  IRA_CHECK_PTR(tiles); IRA_CHECK_PTR(workgroups);
+  SmoothPlan P;
+  const double dummy[2] = {0.0, 0.0};                            // make_smooth_plan only stores the table pointers
+  const int32_t rc = make_smooth_plan(n, dummy, dummy, dummy, &P);
+  if (rc != IRA_OK) return rc;
+  const long long len = half_out ? 2ll * n : (long long)n;
+  *tiles = (int32_t)((len + SM_EDC_TILE - 1) / SM_EDC_TILE);
+  *workgroups = P.n1 / P.c2;
+  return IRA_OK;
+}
+
 extern "C" int32_t ira_band_irfft_smooth(const double* spec_dev, const int64_t* spec_off_dev, int32_t n, int32_t nb,
                                          const double* band_params_dev, const double* freq_val_dev,
                                          const void* t1_dev, const void* t2_dev, const void* tf_dev, double* work_dev,
                                          float* y_dev, const int64_t* y1_off_dev, const int64_t* y2_off_dev,
                                          const int64_t* spec_off2_dev, int32_t half_out, int32_t* job_info_dev,
-                                         void* stream) {
+                                         double* tile_part_dev, void* stream) {
   IRA_CHECK_PTR(spec_dev); IRA_CHECK_PTR(spec_off_dev); IRA_CHECK_PTR(band_params_dev); IRA_CHECK_PTR(freq_val_dev);
   IRA_CHECK_PTR(t1_dev); IRA_CHECK_PTR(t2_dev); IRA_CHECK_PTR(tf_dev); IRA_CHECK_PTR(work_dev); IRA_CHECK_PTR(y_dev);
   IRA_CHECK_PTR(y1_off_dev); IRA_CHECK_PTR(y2_off_dev);
@@ -1205,6 +1280,7 @@ extern "C" int32_t ira_band_irfft_smooth(const double* spec_dev, const int64_t* 
   J.bands = reinterpret_cast<const BandMaskS*>(band_params_dev); J.freq_val = freq_val_dev;
   J.y = y_dev; J.y1_off = y1_off_dev; J.y2_off = y2_off_dev;
   J.half_out = half_out ? 1 : 0;
+  J.tile_part = tile_part_dev;
   if (half_out && spec_off2_dev != nullptr) return IRA_E_UNSUPPORTED;       // one band of one spectrum per job
   hipStream_t st = (hipStream_t)stream;
   const size_t l1 = ((size_t)P.c1 * P.ld1 + SM_TW) * sizeof(cd), l2 = ((size_t)P.c2 * P.ld2 + SM_TW) * sizeof(cd);

@@ -145,6 +145,11 @@ class Engine:
         self._filter_pools: Dict[tuple, dict] = {}      # (M, stream) -> pool, see _filter_pool
         self._filter_tick = 0
         self._ring = None
+        # round 5: the band inverses can leave the energies of their signals' EDC tiles for ira_edc_fits, which then reads a
+        # band signal once less.  Measured (profiles/r05_tile_energies.txt, config 3): ira_edc_fits 6.66 -> 5.40 ms per step,
+        # but the second pass pays 1.6 ms for forming the partials (a serial tail of every tile): 28.2 -> 28.6 ms of device
+        # time.  OFF by default; IRA_BAND_TILE_ENERGIES=1 / this attribute is the A/B switch.
+        self.band_tile_energies = os.environ.get("IRA_BAND_TILE_ENERGIES", "0") == "1"
         if os.environ.get("IRA_WORKSPACE_MB"):            # tuning knob: long-FFT jobs per launch (see workspace_budget_bytes)
             self.workspace_budget_bytes = int(float(os.environ["IRA_WORKSPACE_MB"]) * (1 << 20))
 
@@ -441,10 +446,12 @@ class Engine:
     # ------------------------------------------------------------------ a3-a6 fused
     def edc_fits(self, x_dev, seg_off: np.ndarray, seg_len: np.ndarray, eps: float, floor_db: float,
                  t_mul: float, t_div: float, ranges: Sequence[Tuple[float, float]], min_points: int,
-                 cross: Sequence[float] = (), want_edc: bool = False):
+                 cross: Sequence[float] = (), want_edc: bool = False, tiles=None):
         """Schroeder EDC crossings + decay-line fits straight from the samples (ira_edc_fits).
         Returns (fits (n, nranges, 8) f64 device | None, cross (n, ncross) f64 device | None, edc f32 device | None,
-        edc_off host int64): the EDC curve is only written when want_edc."""
+        edc_off host int64): the EDC curve is only written when want_edc.
+        tiles = (part device, part_off int64, part_wgs int32, part_tiles int32 per segment): partial tile energies the producer of
+        the segments left behind (band_irfft(want_tiles=True)); every such segment must END where its signal ends."""
         t = self.torch
         n = int(seg_off.size)
         seg_len = np.ascontiguousarray(seg_len, dtype=np.int64)
@@ -459,12 +466,18 @@ class Engine:
         out = self.empty(int(seg_len.sum()), t.float32) if want_edc else None
         scratch = self.empty(n * EDC_SCRATCH_DOUBLES, t.float64)
         flat = [v for r in ranges for v in r]
-        d_off, d_len, d_eoff = self.job_tables(np.ascontiguousarray(seg_off, np.int64), seg_len,
-                                                edc_off if want_edc else None)
+        part, p_off, p_wgs, p_tiles = tiles if tiles is not None else (None, None, None, None)
+        d_off, d_len, d_eoff, d_poff, d_pwgs, d_ptiles = self.job_tables(
+            np.ascontiguousarray(seg_off, np.int64), seg_len, edc_off if want_edc else None,
+            None if part is None else np.ascontiguousarray(p_off, np.int64),
+            None if part is None else np.ascontiguousarray(p_wgs, np.int32),
+            None if part is None else np.ascontiguousarray(p_tiles, np.int32))
         check(self.lib.ira_edc_fits(_ptr(x_dev), _ptr(d_off), _ptr(d_len), n, int(seg_len.max()) if n else 0,
                                     float(eps), float(floor_db), float(t_mul), float(t_div), _lib.dbl_array(flat), nr,
                                     int(min_points), _lib.dbl_array(list(cross)), nc, _ptr(fit), _ptr(cr), _ptr(out),
-                                    _ptr(d_eoff), _ptr(scratch), self.stream), "ira_edc_fits")
+                                    _ptr(d_eoff), _ptr(scratch), _ptr(part), _ptr(d_poff), _ptr(d_pwgs), _ptr(d_ptiles),
+                                    self.stream),
+              "ira_edc_fits")
         return (fit[: n * nr * FIT_DOUBLES].view(n, nr, FIT_DOUBLES) if nr else None,
                 cr[: n * nc].view(n, nc) if nc else None, out, edc_off)
 
@@ -1010,8 +1023,19 @@ class Engine:
                   "ira_rfft_any")
         return spec, spec_off, (packed if (packed_ok and packed.any()) else None)
 
+    def band_tile_layout(self, nt: int, half_out: bool):
+        """(tiles, workgroups) of the partial tile energies ira_band_irfft_smooth leaves per signal (ira.h; cached)."""
+        key = ("tiles", int(nt), bool(half_out))
+        if key not in self._tables:
+            import ctypes
+            a, b = ctypes.c_int32(0), ctypes.c_int32(0)
+            check(self.lib.ira_band_tile_layout(int(nt), 1 if half_out else 0, ctypes.byref(a), ctypes.byref(b)),
+                  "ira_band_tile_layout")
+            self._tables[key] = (a.value, b.value)
+        return self._tables[key]
+
     def band_irfft(self, spec_dev, spec_off: np.ndarray, lengths: np.ndarray, band_params: np.ndarray,
-                   freq_val: np.ndarray, y_dev, y_off: np.ndarray):
+                   freq_val: np.ndarray, y_dev, y_off: np.ndarray, want_tiles: bool = False):
         """
         Masked inverse transforms, ONE BAND PER ENTRY: entry j filters the half spectrum at spec_off[j] (length
         lengths[j], bin step freq_val[j]) with the 8-double mask record band_params[j] and writes lengths[j]
@@ -1019,6 +1043,9 @@ class Engine:
         ira_band_irfft in include/ira.h); a band left over takes a half-length inverse when its length allows it (smooth
         family, even length) and a full-length one otherwise.  (pair_across_channels = True: round 2's pairing of entries
         with the same length and bin step from different channels.)
+        want_tiles (round 5): the smooth-length inverses also leave the partial energies of every band signal's EDC tiles;
+        returns (part float64 device, part_off int64 per entry (-1: none, e.g. Bluestein lengths), part_wgs and part_tiles
+        int32 per entry) for edc_fits(tiles=...), else None.
         """
         t = self.torch
         self.last_band_info = []          # the job_info records of this call's launches (tests, diagnostics) ...
@@ -1054,6 +1081,7 @@ class Engine:
         el_so2 = np.where(has2, spec_off[safe], spec_off[j1]).astype(np.int64)
         el_y2 = np.where(has2, y_off[safe], -1).astype(np.int64)
         rest = np.ones(j1.size, dtype=bool)
+        launches = []                                         # (jobs, half-length?, transform length) of the smooth family
         for L in np.unique(jl):
             full_ok = self.smooth_split(int(L)) is not None
             half_ok = (int(L) % 2 == 0 and int(L) >= 128 and self.half_real_ffts
@@ -1069,8 +1097,34 @@ class Engine:
                     continue
                 rest[grp] = False
                 nt = int(L) // 2 if halves else int(L)
-                t1, t2, tf = self.smooth_tables(nt)
                 for sel in self._chunks_of(grp, 16 * nt):
+                    launches.append((sel, halves, nt))
+        # partial tile energies: one block of 2 x tiles x workgroups doubles per job, launch after launch in ONE buffer
+        part = part_off = part_wgs = part_tiles = None
+        bases = [0] * len(launches)
+        if want_tiles and self.band_tile_energies:
+            part_off = np.full(lengths.size, -1, dtype=np.int64)
+            part_wgs = np.zeros(lengths.size, dtype=np.int32)
+            part_tiles = np.zeros(lengths.size, dtype=np.int32)
+            total = 0
+            for li, (sel, halves, nt) in enumerate(launches):
+                tiles, wgs = self.band_tile_layout(nt, halves)
+                bases[li] = total
+                blk = tiles * wgs
+                first = total + np.arange(sel.size, dtype=np.int64) * (2 * blk)
+                part_off[j1[sel]] = first
+                part_wgs[j1[sel]] = wgs
+                part_tiles[j1[sel]] = tiles
+                two = has2[sel]
+                part_off[j2[sel][two]] = first[two] + blk
+                part_wgs[j2[sel][two]] = wgs
+                part_tiles[j2[sel][two]] = tiles
+                total += int(sel.size) * 2 * blk
+            part = self.empty(total, t.float64) if total else None
+        if True:
+            if True:
+                for li, (sel, halves, nt) in enumerate(launches):
+                    t1, t2, tf = self.smooth_tables(nt)
                     work = self.empty(int(sel.size) * 2 * nt, t.float64)
                     d_so, d_bp, d_fv, d_y1, d_y2, d_so2 = self.job_tables(
                         spec_off[j1][sel], np.ascontiguousarray(el_par[sel]), np.ascontiguousarray(freq_val[j1][sel]),
@@ -1081,11 +1135,13 @@ class Engine:
                     check(self.lib.ira_band_irfft_smooth(_ptr(spec_dev), _ptr(d_so), nt, int(sel.size), _ptr(d_bp),
                                                          _ptr(d_fv), _ptr(t1), _ptr(t2), _ptr(tf), _ptr(work), _ptr(y_dev),
                                                          _ptr(d_y1), _ptr(d_y2), _ptr(d_so2), 1 if halves else 0,
-                                                         _ptr(info), self.stream), "ira_band_irfft_smooth")
+                                                         _ptr(info), (_ptr(part) + 8 * bases[li]) if part is not None else None,
+                                                         self.stream), "ira_band_irfft_smooth")
                     self.last_band_info.append(info)
                     self.last_band_info_half.append(bool(halves))
+        tiles_out = (part, part_off, part_wgs, part_tiles) if part is not None else None
         if not rest.any():
-            return
+            return tiles_out
         rest_idx = np.nonzero(rest)[0]
         for lm, sub in self._chunks_by_size(2 * jl[rest_idx].astype(np.int64) - 1):
             sel = rest_idx[sub]
@@ -1103,6 +1159,7 @@ class Engine:
                                           lm, _ptr(t1), _ptr(t2), _ptr(tf), _ptr(bf), _ptr(d_bi), _ptr(work),
                                           _ptr(y_dev), _ptr(d_y1), _ptr(d_y2), _ptr(d_so2), self.stream),
                   "ira_band_irfft")
+        return tiles_out
 
     def spectrum_mag_phase(self, spec_dev, spec_off: np.ndarray, lengths: np.ndarray, floor_db: float,
                            want_phase: bool, packed: Optional[np.ndarray] = None):

@@ -33,7 +33,7 @@ extern "C" {
 #define IRA_E_FORMAT (-5)     /* a file is not RIFF/WAVE (host-side ingest entry points only) */
 #define IRA_E_HIP_BASE (-1000)
 
-#define IRA_ABI_VERSION 7   /* bumped whenever an exported signature or a scratch-size constant changes */
+#define IRA_ABI_VERSION 8   /* bumped whenever an exported signature or a scratch-size constant changes */
 
 int32_t ira_abi_version(void);
 const char* ira_error_string(int32_t code);
@@ -106,12 +106,21 @@ int32_t ira_edc_box_smooth(const double* edc_db64_dev, const int64_t* off_dev, c
  * _compute_band_metrics_from_samples (analyse/rt60bands.py:272-321), whose EDC curve is never a result.
  * edc_db_dev (optional, may be NULL): also write the float32 dB curve at edc_off_dev[s] (the decay block returns it).
  * fit_out_dev / cross_out_dev: records exactly as ira_curve_fits writes them.  ranges_hi_lo / cross_targets: HOST arrays.
- * scratch_dev: nseg * IRA_EDC_SCRATCH_DOUBLES doubles.  max_len as for ira_edc_db. */
+ * scratch_dev: nseg * IRA_EDC_SCRATCH_DOUBLES doubles.  max_len as for ira_edc_db.
+ * tile_part_dev (optional, may be NULL; round 5): partial tile energies a producer of the segments left behind
+ * (ira_band_irfft_smooth, tile_part_dev): segment s with part_off_dev[s] >= 0 takes the energy of its tile j (4096 samples,
+ * counted from the END of the segment) as the sum over w < part_wgs_dev[s] of tile_part_dev[part_off_dev[s] +
+ * w * part_tiles_dev[s] + j] (part_tiles_dev[s] = tiles of the producer's whole signal), for every tile but the one that holds its first sample (that one is scanned, so that edc[0] stays
+ * the value the curve has at index 0) -- instead of reading its samples once more (rt60bands.py:272-321 through
+ * decay.py:115-170: a band's signal is written by the inverse transform a moment earlier).  CONTRACT: such a segment ends
+ * where the producer's signal ends (a band signal from its start index on).  part_off_dev[s] < 0: the samples are read. */
 int32_t ira_edc_fits(const float* x_dev, const int64_t* off_dev, const int64_t* len_dev, int32_t nseg,
                      int64_t max_len, double eps, double floor_db, float t_mul, float t_div,
                      const double* ranges_hi_lo, int32_t nranges, int32_t min_points,
                      const double* cross_targets, int32_t ncross, double* fit_out_dev, double* cross_out_dev,
-                     float* edc_db_dev, const int64_t* edc_off_dev, double* scratch_dev, void* stream);
+                     float* edc_db_dev, const int64_t* edc_off_dev, double* scratch_dev, const double* tile_part_dev,
+                     const int64_t* part_off_dev, const int32_t* part_wgs_dev, const int32_t* part_tiles_dev,
+                     void* stream);
 
 /* ---- a11: STFT magnitude in dB -------------------------------------------------------------------
  * Valid framing (no padding), frame f of segment s starts at off[s] + f*hop, nframes[s] frames.
@@ -400,8 +409,15 @@ int32_t ira_fir_numerator(const double* coeffs_dev, int32_t order, const float* 
  *     the second pass sums the <= 2 x 9 terms of the pruned first pass per point in its input stage.  Which jobs are narrow
  *     is decided on the device from the mask records (job_info_dev[4e .. 4e+3] = {narrow, first bin, bins, terms}, an
  *     output for the curious).  Same results up to float64 rounding of a different summation order; NULL = every job
- *     takes both passes. */
+ *     takes both passes.
+ *   ira_band_irfft_smooth(..., tile_part_dev) (round 5; may be NULL): the second pass also leaves the ENERGIES of the
+ *     4096-sample tiles (counted from the end of each band signal) of what it writes, as partial sums per workgroup:
+ *     job e, signal s (0: y1, 1: y2; a half_out job has signal 0 only), tile j, workgroup w at
+ *     tile_part_dev[((e * 2 + s) * workgroups + w) * tiles + j], with (tiles, workgroups) = ira_band_tile_layout(n, half_out):
+ *     nb * 2 * tiles * workgroups doubles.  ira_edc_fits(tile_part_dev ...) turns them into its tile totals and no longer
+ *     reads every band signal twice (reference rt60bands.py:170-175 -> :272-321). */
 int32_t ira_fft_smooth_split(int32_t n, int32_t* n1, int32_t* n2);
+int32_t ira_band_tile_layout(int32_t n, int32_t half_out, int32_t* tiles, int32_t* workgroups);
 int32_t ira_rfft_smooth(const float* x_dev, const int64_t* xoff_dev, int32_t n, int32_t nb, int32_t use_hann,
                         const void* t1_dev, const void* t2_dev, const void* tf_dev, double* work_dev,
                         double* spec_out_dev, const int64_t* spec_off_dev, const int64_t* x2off_dev,
@@ -412,7 +428,7 @@ int32_t ira_band_irfft_smooth(const double* spec_dev, const int64_t* spec_off_de
                               const double* band_params_dev, const double* freq_val_dev, const void* t1_dev,
                               const void* t2_dev, const void* tf_dev, double* work_dev, float* y_dev,
                               const int64_t* y1_off_dev, const int64_t* y2_off_dev, const int64_t* spec_off2_dev,
-                              int32_t half_out, int32_t* job_info_dev, void* stream);
+                              int32_t half_out, int32_t* job_info_dev, double* tile_part_dev, void* stream);
 
 /* k-th smallest values (0-based ranks, clipped to the segment) of float64 segments values_dev + off_dev[e], count_dev[e]
  * long: out_dev[e*nranks + j] = sorted(segment)[ranks_dev[e*nranks + j]], 1 <= nranks <= 8 (radix select, exact).

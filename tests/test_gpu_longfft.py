@@ -598,6 +598,62 @@ def test_narrow_bands_skip_the_first_pass():
             assert np.mean(outs[True][i] == outs[False][i]) > 0.95, (n, bands[i].name)
 
 
+def test_band_tile_energies_come_from_the_inverse_and_the_fits_agree():
+    """Round 5: the second pass of the smooth band inverses leaves the energies of the 4096-sample EDC tiles of every band
+    signal it writes (partials per workgroup, ira.h: ira_band_irfft_smooth tile_part_dev), and ira_edc_fits takes its tile
+    totals from them instead of reading every band signal again.  (1) The partials, added up, ARE the tile energies of the
+    float32 signals (float64 sums of exact squares: 1e-12 relative) -- pairs, half-length singles, narrow jobs, lengths whose
+    last tile is partial; (2) the band RT60s with and without them agree to 1e-9 relative (the carries differ by float64
+    rounding of another summation order), None patterns identical; (3) runs are bit-reproducible."""
+    from audio_analysis_amd.engine import get_engine
+    from audio_analysis_amd.analyse import rt60bands as rb
+    from audio_analysis_amd.analyse.frequency_response import rfft_bin_step
+    from audio_analysis_amd.synth import synth_ir
+    eng = get_engine()
+    t = eng.torch
+    for n, mode in ((96000, "third"), (48000, "three"), (28800, "octave")):
+        st = rb.Rt60BandsAnalysisSettings(band_mode=mode)
+        bands = rb._build_band_definitions(st, SR)
+        nb = len(bands)
+        x = [synth_ir(40 + i, 0, n, rt60_seconds=0.5 + 0.2 * i) for i in range(3)]
+        fv = rfft_bin_step(n, SR)
+        recs = np.stack([rb.band_mask_record(b, st.transition_width_octaves, 0.5 * SR) for b in bands])
+        b = eng.upload(x)
+        spec, spec_off = eng.rfft_any(b.x, b.off, b.length, use_hann=False)
+        y = eng.empty(3 * nb * n, t.float32)
+        yoff = np.arange(3 * nb, dtype=np.int64) * n
+        try:
+            eng.band_tile_energies = True                     # (off by default: see Engine.band_tile_energies)
+            tiles = eng.band_irfft(spec, np.repeat(spec_off, nb), np.full(3 * nb, n, np.int32), np.tile(recs, (3, 1)),
+                                   np.full(3 * nb, fv), y, yoff, want_tiles=True)
+        finally:
+            eng.band_tile_energies = False
+        assert tiles is not None
+        part, poff, pwgs, ptiles = tiles
+        assert np.all(poff >= 0) and np.all(pwgs > 0) and np.all(ptiles == (n + 4095) // 4096)
+        ph, yh = part.cpu().numpy(), y.cpu().numpy().astype(np.float64).reshape(3 * nb, n)
+        ntile = (n + 4095) // 4096
+        for e in range(3 * nb):
+            got = ph[poff[e] : poff[e] + ntile * pwgs[e]].reshape(pwgs[e], ntile).sum(axis=0)
+            want = np.array([np.sum(yh[e, max(0, n - (j + 1) * 4096) : n - j * 4096] ** 2) for j in range(ntile)])
+            assert np.allclose(got, want, rtol=1e-12, atol=1e-300), (n, mode, e, float(np.abs(got - want).max()))
+        # the whole block, both ways
+        res = {}
+        for on in (True, False, True):
+            try:
+                eng.band_tile_energies = on
+                _, vals, have = rb.rt60_bands_device(eng, b, SR, st)
+                res.setdefault(on, []).append((vals.copy(), have.copy()))
+            finally:
+                eng.band_tile_energies = False
+        (v1, h1), (v1b, h1b) = res[True]
+        (v0, h0), = res[False]
+        assert np.array_equal(h1, h0) and np.array_equal(np.isnan(v1), np.isnan(v0))
+        assert v1.tobytes() == v1b.tobytes()                                            # run to run: the same bits
+        ok = ~np.isnan(v0)
+        assert ok.any() and np.all(np.abs(v1[ok] - v0[ok]) <= 1e-9 * np.abs(v0[ok])), (n, mode, float(np.nanmax(np.abs(v1 - v0))))
+
+
 def test_band_bank_with_edc_smoothing_vs_oracle():
     """The default-off dB smoothing of the EDC (decay.py:161-164) inside the band filter bank (rt60bands.py:356-360 hands the
     decay settings through): smoothed on the device (ira_edc_box_smooth), fitted on the smoothed curve."""
