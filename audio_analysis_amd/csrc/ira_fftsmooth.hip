@@ -76,7 +76,7 @@ struct SmoothPlan {
                                     // written tile-major (contiguous per workgroup), 2 pass-1 output contiguous, 4 pass-1
                                     // spectrum gather contiguous, 8 / 16 no transform in pass 1 / 2, 32 no input arithmetic
                                     // in pass 1, 64 no output-twiddle loads in pass 1, 128 no digit-reversed slot lookups
-                                    // (tools/smooth_ablate.sh, profiles/r03_smooth_ablation.txt); narrow-band kernel: 256 no
+                                    // (tools/experiments/smooth_ablate.sh, profiles/r03_smooth_ablation.txt); narrow-band kernel: 256 no
                                     // terms, 512 no W_n^(k1 n2) loads, 1024 no transform, 2048 no output stores
 };
 
@@ -904,7 +904,7 @@ __global__ __launch_bounds__(SM_THREADS, 5) void smooth_rows_sparse_kernel(Smoot
   __syncthreads();
   // A thread owns COLUMNS: n2 = tid, tid + 256, ... for a pair of rows at a time -- the cluster values are the same for every
   // row, so one load feeds both rows' sums, and the whole tile is one batch (Q dependent round trips to L2 per tile instead
-  // of 2 Q: what this stage costs is their latency, tools/r4_sparse_ablate.sh).
+  // of 2 Q: what this stage costs is their latency, tools/experiments/r4_sparse_ablate.sh).
   constexpr int NU = 3;                                    // columns per thread and batch (750 = 3 x 256 - 18)
   constexpr int RS = SM_SPARSE_R + SM_TW;                  // table entries per row
   for (int cg = 0; cg < C; cg += 2) {

@@ -501,7 +501,7 @@ def make_roof(ev, roof_steps, settings, L, n, nchan, traffic_tab):
 def load_traffic(cfg: str):
     """Per-call HBM traffic from the PMC passes committed under profiles/ (tools/profile_config.sh + traffic_profile.py;
     MI355X_MICROARCH.md's 2 x FETCH_SIZE + WRITE_SIZE rule): the newest round's table for this configuration."""
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         try:
             return json.load(open(os.path.join(REPO, "profiles", f"{rnd}_traffic_{cfg}.json")))["calls"]
         except Exception:
@@ -607,6 +607,17 @@ def roofline_kernel(cfg, tot, roof, geom=None):
     if dom is None:
         return None
     kname, share, src, targs, avg_ms, calls = dom
+    # launches and milliseconds per step of that kernel from the per-kernel table of the same profile (tools/traffic_profile.py)
+    per_step = None
+    try:
+        import csv
+        tab = os.path.join(REPO, "profiles", src.replace("_kernel_stats_", "_per_kernel_"))
+        for r in csv.DictReader(open(tab)):
+            if r["kernel"].strip('"').replace(" ", "") == (kname + targs).replace(" ", ""):
+                per_step = {"launches_per_step": float(r["launches_per_step"]), "ms_per_step": float(r["ms_per_step"])}
+                break
+    except Exception:
+        per_step = None
     call = next((c for c, k in SINGLE_KERNEL_CALLS.items() if k == kname), None)
     live = next((n for n in tot if call and n.startswith(call)), None)
     out = {"kernel": kname + targs, "share_of_device_time_in_profile": share, "profile": f"profiles/{src}"}
@@ -615,7 +626,10 @@ def roofline_kernel(cfg, tot, roof, geom=None):
         mlive = next((n for n in tot if mcall and n.startswith(mcall)), None)
         out.update(duration_source=f"average of {calls} launches in profiles/{src} (rocprofv3 --kernel-trace --stats): its call "
                                    f"{mcall} is several launches, so HIP events around the call do not time one kernel",
-                   avg_launch_ms=avg_ms, call=mcall)
+                   avg_launch_ms=avg_ms, call=mcall,
+                   ms_per_step=None if per_step is None else per_step["ms_per_step"],
+                   launches_per_step=None if per_step is None else per_step["launches_per_step"],
+                   ms_per_step_source=f"profiles/{src.replace('_kernel_stats_', '_per_kernel_')} (same profiled run)")
         if geom is not None and mcall is not None:
             nchan, n, nb = geom["channels"], geom["n"], geom["bands"]
             b, what = None, None

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Kernel durations + SQ counters of ONE report block (tools/block_probe.py), with derived utilisation figures.  One runner for
-# what tools/r2_block_profile.sh, r2_pmc_block.sh and r3_block_counters.sh did; environment assignments select the build/knobs.
+# what tools/blockprof.sh, r2_pmc_block.sh and r3_block_counters.sh did; environment assignments select the build/knobs.
 #   bash tools/blockprof.sh <block> <outdir> [--batch N] [VAR=value ...]      e.g.
 #   bash tools/blockprof.sh spectrum gpurun_out/r5_k3g/glds1 --batch 256 IRA_TUNING=1 IRA_LIBRARY=$PWD/audio_analysis_amd/csrc/libira_tuning.so IRA_FFT_GLDS=1
 # Passes: rocprofv3 --kernel-trace --stats, then three --pmc groups, each its own run (never combined with other trace domains).

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 3: one GPU call = GPU tests, then the bench lines and profile passes asked for.
-#     bash tools/r3_runs.sh <tag> [test] [bench:<cfg>...] [prof:<cfg>...]
+#     bash tools/experiments/r3_runs.sh <tag> [test] [bench:<cfg>...] [prof:<cfg>...]
 R=$GRAFT_REPO_ROOT; tag=$1; shift; O=$R/gpurun_out/$tag; mkdir -p $O
 for a in "$@"; do
   case $a in

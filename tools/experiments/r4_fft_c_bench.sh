@@ -1,6 +1,6 @@
 #!/bin/bash
 # Headline bench (two lanes, H2D included) with the Bluestein column passes at 2 and at 4 columns per workgroup, alternating
-# (tuning build: IRA_FFT_C sets both passes).  bash tools/r4_fft_c_bench.sh <outdir>
+# (tuning build: IRA_FFT_C sets both passes).  bash tools/experiments/r4_fft_c_bench.sh <outdir>
 R=$GRAFT_REPO_ROOT; O=$R/${1:-gpurun_out/r4_fft_c}; mkdir -p $O
 export IRA_TUNING=1 IRA_LIBRARY=$R/audio_analysis_amd/csrc/libira_tuning.so
 for rep in 1 2 3; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Bluestein passes: tile widths of the forward (IRA_FFT_C) and inverse (IRA_FFT_C3) column passes chosen separately, rows per
 # workgroup of the row pass (IRA_FFT_R; 0 = the plan's choice) -- tuning build.
-#   bash tools/r4_fft_c_sweep.sh [batch] [list of C:C3:R ...]
+#   bash tools/experiments/r4_fft_c_sweep.sh [batch] [list of C:C3:R ...]
 export IRA_TUNING=1 IRA_LIBRARY=$GRAFT_REPO_ROOT/audio_analysis_amd/csrc/libira_tuning.so
 B=${1:-256}; shift
 LIST=${@:-2:2:0 4:4:0 2:2:0 4:2:0 4:4:0 4:4:2 4:4:8 2:2:2 2:2:8 2:2:0 4:4:0}

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Narrow-band kernel: what its time is made of (timing-only ablations of the tuning build; results are wrong by construction).
-# bash tools/r4_sparse_ablate.sh <outdir>
+# bash tools/experiments/r4_sparse_ablate.sh <outdir>
 R=$GRAFT_REPO_ROOT; O=$R/${1:-gpurun_out/r4_sparse_abl}; mkdir -p $O
 export IRA_TUNING=1 IRA_LIBRARY=$R/audio_analysis_amd/csrc/libira_tuning.so IRA_STREAMS=1
 cd /tmp && export TMPDIR=/tmp

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Narrow-band path of ira_band_irfft_smooth: device time of the call in config 3 (26 third-octave bands, 256 x 10 s) as a
 # function of the largest number of terms per cluster a job may have and still skip pass 1 (IRA_SPARSE_Q, tuning build; 0 = off).
-# bash tools/r4_sparse_q.sh <outdir> [q ...]
+# bash tools/experiments/r4_sparse_q.sh <outdir> [q ...]
 R=$GRAFT_REPO_ROOT; O=$R/${1:-gpurun_out/r4_sparse_q}; mkdir -p $O; shift
 export IRA_TUNING=1 IRA_LIBRARY=$R/audio_analysis_amd/csrc/libira_tuning.so
 for q in ${@:-0 1 2 4 6 9 12 14}; do

@@ -1,6 +1,6 @@
 #!/bin/bash
 # float32 STFT, persistent kernel: time and L2->fabric fetch traffic as a function of the waves' re-sync interval
-# (IRA_STFT6_RESYNC, tuning build).  bash tools/r4_stft_resync.sh <outdir>
+# (IRA_STFT6_RESYNC, tuning build).  bash tools/experiments/r4_stft_resync.sh <outdir>
 R=$GRAFT_REPO_ROOT; O=$R/${1:-gpurun_out/r4_resync}; mkdir -p $O
 export IRA_TUNING=1 IRA_LIBRARY=$R/audio_analysis_amd/csrc/libira_tuning.so
 for rs in 0 1 2 4 8 16; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B on one box: Bluestein K3 by LDS-DMA (cols_inv_glds_kernel, IRA_FFT_GLDS=1) against the register-staged kernel
 # (IRA_FFT_GLDS=0), tuning build, kernel-trace statistics of tools/fft_probe.py (256 fr/filter spectra of ~10 s).
-#   bash tools/r5_k3g_ab.sh <outdir> [extra env assignments for the glds arm, e.g. IRA_FFT_GLDS_WG=2]
+#   bash tools/experiments/r5_k3g_ab.sh <outdir> [extra env assignments for the glds arm, e.g. IRA_FFT_GLDS_WG=2]
 R=$GRAFT_REPO_ROOT; O=$R/${1:-gpurun_out/r5_k3g}; shift; mkdir -p $O
 export IRA_TUNING=1 IRA_LIBRARY=$R/audio_analysis_amd/csrc/libira_tuning.so
 cd /tmp && export TMPDIR=/tmp

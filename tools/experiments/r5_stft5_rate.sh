@@ -2,7 +2,7 @@
 # float64 modal STFT (stft5_kernel, ira_stft_logbin): its own instruction stream with and without memory, split into
 # transform / conversion / aggregation by the tuning build's timing-only switches (IRA_STFT5_ABLATE: 1 no window loads,
 # 2 no sample loads, 4 no dB -> float32 -> linear conversion), 256 x 10 s, + SQ counters of the product kernel.
-#   bash tools/r5_stft5_rate.sh <outdir>
+#   bash tools/experiments/r5_stft5_rate.sh <outdir>
 R=$GRAFT_REPO_ROOT; O=$R/${1:-gpurun_out/r5_stft5}; mkdir -p $O
 export IRA_TUNING=1 IRA_LIBRARY=$R/audio_analysis_amd/csrc/libira_tuning.so
 for rep in 1 2; do

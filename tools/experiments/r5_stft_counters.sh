@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counters of the float32 STFT kernel (tools/stft_probe.py --tf --batch 256), builds x ablations on one box.
-#   bash tools/r5_stft_counters.sh <outdir> <other tuning .so>
+#   bash tools/experiments/r5_stft_counters.sh <outdir> <other tuning .so>
 R=$GRAFT_REPO_ROOT; O=$R/${1:-gpurun_out/r5_stft_cnt}; other=$2; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for arm in "new:audio_analysis_amd/csrc/libira_tuning.so:0" "new:audio_analysis_amd/csrc/libira_tuning.so:7" "poly:audio_analysis_amd/csrc/libira_tuning.so:16" "poly:audio_analysis_amd/csrc/libira_tuning.so:23" "prev:$other:0" "prev:$other:7"; do

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Config 3 (third-octave RT60 bank + waterfall, 256 x 10 s per step) and the report step with and without the band inverses'
-# tile energies (IRA_BAND_TILE_ENERGIES), alternating on one box.   bash tools/r5_tile_energy_ab.sh
+# tile energies (IRA_BAND_TILE_ENERGIES), alternating on one box.   bash tools/experiments/r5_tile_energy_ab.sh
 R=$GRAFT_REPO_ROOT
 for rep in 1 2; do
   for cfg in 3 report; do

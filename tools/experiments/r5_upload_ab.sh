@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of the float32 upload on ONE box: pieces per batch x copy-stream priority, alternating, headline +
-# resident-input rate from the same process.   bash tools/r5_upload_ab.sh <outdir> [reps]
+# resident-input rate from the same process.   bash tools/experiments/r5_upload_ab.sh <outdir> [reps]
 R=$GRAFT_REPO_ROOT; O=$R/${1:-gpurun_out/r5_upload}; reps=${2:-2}; mkdir -p $O
 for rep in $(seq $reps); do
   for arm in "2" "4" "8" "1" "2 --upload-priority" "4 --upload-priority" "2 --upload pull"; do

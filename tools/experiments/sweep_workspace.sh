@@ -1,6 +1,6 @@
 #!/bin/bash
 # Long-FFT chunking experiment: jobs per launch sized so that a chunk's working set stays in the 256 MB MALL.
-# usage (GPU box): bash tools/sweep_workspace.sh  -> gpurun_out/ws_sweep.txt
+# usage (GPU box): bash tools/experiments/sweep_workspace.sh  -> gpurun_out/ws_sweep.txt
 mkdir -p gpurun_out
 : > gpurun_out/ws_sweep.txt
 for mb in 49152 1024 512 256 192 128 96 64; do

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Kernel-trace of the default (two-lane) bench and the GPU's busy fraction inside the timed region.
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3_gap; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/${1:-gpurun_out/r3_gap}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python3 $R/bench.py --steps 12 --warmup 3 --variants value --no-cpu-baseline --literal-steps 0 --roofline-steps 1 > $O/bench.json 2> $O/bench.err
 python3 - $O <<'PY'
@@ -11,7 +11,10 @@ rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:4
 rows.sort()
 # the timed region: the 12 steps before the serialised roofline pass; take the window between the 4th and the 15th peak_decode
 pk = [s for s, e, n, st in rows if "peak_decode" in n]
-t0, t1 = pk[4], pk[14]
+# the timed region: the ten consecutive steps (peak picks) that take the least time -- warm-up, plan and tuning passes and the
+# serialised roofline pass are all slower
+best = min(range(len(pk) - 10), key=lambda i: pk[i + 10] - pk[i])
+t0, t1 = pk[best], pk[best + 10]
 sel = [(s, e, n, st) for s, e, n, st in rows if s >= t0 and e <= t1]
 busy, cur_s, cur_e = 0, None, None
 for s, e, n, st in sel:

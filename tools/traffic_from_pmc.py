@@ -69,7 +69,7 @@ for call in sorted(set(per.get("FETCH_SIZE", {})) | set(per.get("WRITE_SIZE", {}
                    "hbm_bytes_per_channel": (2.0 * f + w) * 1024.0 / batch}
 json.dump({
     "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 "
-              f"--warmup 1 --batch {batch} --no-cpu-baseline   (tools/profile_round.sh)",
+              f"--warmup 1 --batch {batch} --no-cpu-baseline   (tools/profile_config.sh)",
     "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE under-counts wide reads by 2x)",
     "batch": batch, "calls": calls}, open(os.path.join(d, "traffic.json"), "w"), indent=1)
 print(json.dumps(calls, indent=1))
