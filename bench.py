@@ -1125,8 +1125,9 @@ def main():
         if res_ms is not None:
             up["GBps_needed_for_resident_rate"] = B * n * 4.0 / (res_ms * 1e-3) / 1e9
             up["resident_ms_per_step"] = res_ms
-        # a step waits for its upload when the copy of one batch takes (nearly) as long as the step itself
-        out["bound"] = "pcie" if busy >= 0.9 else "compute"
+        # a step waits for its upload when the copy of one batch takes (nearly) as long as the step itself -- or longer than
+        # the same step takes with its inputs already resident
+        out["bound"] = "pcie" if (busy >= 0.85 or (res_ms is not None and upload_timed["ms_per_upload"] >= 0.95 * res_ms)) else "compute"
         out["bound_reason"] = (f"one batch's upload takes {upload_timed['ms_per_upload']:.2f} ms under the kernels "
                                f"({upload_timed['GBps']:.1f} GB/s; {upload_alone['GBps']:.1f} GB/s alone) of a "
                                f"{step_ms:.2f} ms step" + ("" if res_ms is None else f"; the same steps with resident inputs take {res_ms:.2f} ms"))
