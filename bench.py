@@ -912,9 +912,11 @@ def main():
     upload_tuning = None
     if a.upload == "auto":
         def tune_steps(c):
+            # (records dropped, no collective: ranks may try different numbers of arms, and the final gather expects every
+            # rank to hold the same number of rows)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            run_fed(c, host_f32)
+            run_pipelined(report, feed, (host_f32[i % K] for i in range(c)), None)
             torch.cuda.synchronize()
             return time.perf_counter() - t0
         upload_tuning = feed.autotune(tune_steps, upload_alone["GBps"] if upload_alone else None)
