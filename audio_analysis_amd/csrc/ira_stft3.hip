@@ -390,7 +390,8 @@ __device__ __forceinline__ T& at32(T* base, unsigned byte_off) {
 //     stored, half 1 before half 0 is transformed.  gfx950 counts loads and stores in ONE in-order counter, so a load
 //     issued after a frame's 33 stores cannot be consumed before those stores are acknowledged; issued before them it can.
 // AB: ablation bits, instantiated only by the tuning build (IRA_STFT6_ABLATE): 1 no sample loads, 2 no window reads,
-//     4 no stores, 8 post-stage twiddles without the scalar table loads, 16 polynomial logarithm.  The product runs AB = 0.
+//     4 no stores, 8 post-stage twiddles without the scalar table loads, 16 polynomial logarithm, 32 E3 through LDS (the
+//     pre-round-5 mirror exchange).  The product runs AB = 0.
 template <int NT, bool PF, int AB>
 __global__ __launch_bounds__(64 * NT) void stft6_kernel(
     const float* __restrict__ x, const int64_t* __restrict__ off, const int32_t* __restrict__ nframes, int hop,
@@ -574,34 +575,50 @@ __global__ __launch_bounds__(64 * NT) void stft6_kernel(
 #pragma unroll
     for (int hh = 0; hh < 4; ++hh) dft_dif<float, 8>(z3[hh]);
 
-    // ---- E3 ------------------------------------------------------------------------------------------------------------
+    // ---- E3: the mirror partner Z[M - k] of every bin the lane holds.  After step 3 the lane already holds Z[q + 64 i'],
+    // i' = hh + 4 k3 < 32, in natural order; the partner of k = q + 64 i (i < 16) is register 31 - i of lane (64 - q) & 63 --
+    // and for lane 0 its OWN register 32 - i (register 0 for i = 0).  Round 5: a lane permutation through the LDS crossbar
+    // (ds_bpermute_b32: no LDS memory, no wave_sync) instead of writing real parts, then imaginary parts, through a
+    // 2048-float buffer and reading both orders back: 32 permutes + 32 selects for 130 LDS accesses and four round trips
+    // (tools/micro/stft_epilogue_rate.hip: -540 SIMD-cycles per frame; profiles/r05_stft_epilogue.txt).  Pure data movement:
+    // the same float32 values as before.  AB & 32 (tuning build) keeps the LDS form as the A/B.
     float zkr[16], zpr[16], zki[16], zpi[16], midr, midi;
+    if (AB & 32) {
 #pragma unroll
-    for (int hh = 0; hh < 4; ++hh)
+      for (int hh = 0; hh < 4; ++hh)
 #pragma unroll
-      for (int k3 = 0; k3 < 8; ++k3) exf[q + 64 * hh + 256 * k3] = z3[hh][brev_bits(k3, 3)].re;
-    wave_sync();
+        for (int k3 = 0; k3 < 8; ++k3) exf[q + 64 * hh + 256 * k3] = z3[hh][brev_bits(k3, 3)].re;
+      wave_sync();
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int k = q + 64 * i;
-      zkr[i] = exf[k];
-      zpr[i] = exf[(M3 - k) & (M3 - 1)];
+      for (int i = 0; i < 16; ++i) {
+        const int k = q + 64 * i;
+        zkr[i] = exf[k];
+        zpr[i] = exf[(M3 - k) & (M3 - 1)];
+      }
+      midr = exf[M3 / 2];
+      wave_sync();
+#pragma unroll
+      for (int hh = 0; hh < 4; ++hh)
+#pragma unroll
+        for (int k3 = 0; k3 < 8; ++k3) exf[q + 64 * hh + 256 * k3] = z3[hh][brev_bits(k3, 3)].im;
+      wave_sync();
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int k = q + 64 * i;
+        zki[i] = exf[k];
+        zpi[i] = exf[(M3 - k) & (M3 - 1)];
+      }
+      midi = exf[M3 / 2];
+      wave_sync();                                          // the next frame's step 1 writes this buffer again
+    } else {
+      // (the permutes are issued inside the post loop below, bin pair by bin pair: holding all 64 partner values beside the
+      // lane's own 64 spills)
+      zkr[0] = z3[0][0].re; zki[0] = z3[0][0].im;           // the NaN flag below reads Z[0]
+      midr = z3[0][brev_bits(4, 3)].re;                     // Z[1024] = lane 0's register 16 (only lane 0 stores the bin)
+      midi = z3[0][brev_bits(4, 3)].im;
+      wave_sync();                                          // the next frame's step 1 writes the exchange buffer again
     }
-    midr = exf[M3 / 2];
-    wave_sync();
-#pragma unroll
-    for (int hh = 0; hh < 4; ++hh)
-#pragma unroll
-      for (int k3 = 0; k3 < 8; ++k3) exf[q + 64 * hh + 256 * k3] = z3[hh][brev_bits(k3, 3)].im;
-    wave_sync();
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int k = q + 64 * i;
-      zki[i] = exf[k];
-      zpi[i] = exf[(M3 - k) & (M3 - 1)];
-    }
-    midi = exf[M3 / 2];
-    wave_sync();                                          // the next frame's step 1 writes this buffer again
+    const int perm_src = ((64 - q) & 63) << 2;              // byte address of the partner lane for ds_bpermute
 
     // ---- next frame, half 0 (PF): requested BEFORE this frame's results are computed and stored ---------------------------
     if (PF) {
@@ -632,7 +649,16 @@ __global__ __launch_bounds__(64 * NT) void stft6_kernel(
       for (int i = 0; i < 16; ++i) {
         const cf wk = ira::cmul(wlane, (AB & 8) ? cf{wlane.im * (float)(i + 1), wlane.re} : wuni[i]);
         float lo, hi;
-        untangle_db<(AB & 16) != 0>(zkr[i], zpr[i], zki[i], zpi[i], wk, floor_db, lo, hi);
+        if (AB & 32) {
+          untangle_db<(AB & 16) != 0>(zkr[i], zpr[i], zki[i], zpi[i], wk, floor_db, lo, hi);
+        } else {
+          const int ip = 31 - i, il = (32 - i) & 31;        // partner register of lanes q > 0 / of lane 0
+          const cf own = z3[i & 3][brev_bits(i >> 2, 3)];
+          const cf pv = z3[ip & 3][brev_bits(ip >> 2, 3)], lv = z3[il & 3][brev_bits(il >> 2, 3)];
+          const float pr = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_src, __float_as_int(pv.re)));
+          const float pi = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_src, __float_as_int(pv.im)));
+          untangle_db<(AB & 16) != 0>(own.re, q == 0 ? lv.re : pr, own.im, q == 0 ? lv.im : pi, wk, floor_db, lo, hi);
+        }
         if (AB & 4) { sacc += lo + hi; continue; }
         flo[64 * i] = lo;
         fhi[-64 * i] = hi;                                    // k = 0 -> bin M (Nyquist)
@@ -686,6 +712,8 @@ int32_t launch6(const float* x, const int64_t* off, const int32_t* nframes, int3
     case 7: IRA_LAUNCH6(7); break;
     case 16: IRA_LAUNCH6(16); break;
     case 23: IRA_LAUNCH6(23); break;
+    case 32: IRA_LAUNCH6(32); break;
+    case 39: IRA_LAUNCH6(39); break;
     default: IRA_LAUNCH6(0); break;
   }
 #else

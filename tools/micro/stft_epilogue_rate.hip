@@ -10,6 +10,7 @@
 //   6 post_poly  variant 3 with v_log_f32 replaced by v_frexp_mant / v_frexp_exp + a degree-6 polynomial (full-rate instructions)
 //   7 frame_poly steps 1-3 + variant 6
 //   8 / 9 / 10   variants 0 / 7 / 5 with the kernel's LDS exchanges E1 / E2 / E3 between the steps (wave-private buffers)
+//   11 / 12      variants 8 / (steps + restructured epilogue) with E3 replaced by a lane permutation (ds_bpermute_b32)
 // All on synthetic registers, no memory; 1..4 waves per SIMD, one 16-wave workgroup per CU at most.
 //   hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -I audio_analysis_amd/csrc tools/micro/stft_epilogue_rate.hip -o /tmp/stft_epilogue_rate
 #include <hip/hip_runtime.h>
@@ -39,6 +40,7 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 // steps 1-3 with the kernel's half-size LDS exchanges E1 / E2 / E3 (wave-private buffers, the kernel's strides)
+template <bool PERM = false>
 __device__ __forceinline__ void steps123_lds(cf (&v)[16], cf w1, cf w2, cf w3, cf wl, float (&zkr)[16], float (&zpr)[16],
                                              float (&zki)[16], float (&zpi)[16], cf* ex, int q) {
   float* exf = reinterpret_cast<float*>(ex);
@@ -105,6 +107,24 @@ __device__ __forceinline__ void steps123_lds(cf (&v)[16], cf w1, cf w2, cf w3, c
   wave_sync();
 #pragma unroll
   for (int hh = 0; hh < 4; ++hh) dft_dif<float, 8>(z3[hh]);
+  if (PERM) {
+    // E3 without LDS: the lane already holds Z[q + 64 i'], i' = hh + 4 k3 < 32; the mirror Z[2048 - k], k = q + 64 i (i < 16),
+    // sits in lane (64 - q) & 63 as its register 31 - i -- except for lane 0, whose mirror is its OWN register 32 - i (i >= 1)
+    // or register 0 (i = 0).  32 ds_bpermute_b32 (the LDS crossbar, no memory) + 32 selects instead of 130 LDS accesses.
+    const int src = ((64 - q) & 63) << 2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const cf own = z3[i & 3][brev_bits(i >> 2, 3)];
+      const int ip = 31 - i, il = (32 - i) & 31;             // partner register of lanes q > 0 / of lane 0
+      const cf pv = z3[ip & 3][brev_bits(ip >> 2, 3)], lv = z3[il & 3][brev_bits(il >> 2, 3)];
+      const float pr = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(pv.re)));
+      const float pi = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(pv.im)));
+      zkr[i] = own.re; zki[i] = own.im;
+      zpr[i] = q == 0 ? lv.re : pr;
+      zpi[i] = q == 0 ? lv.im : pi;
+    }
+    return;
+  }
 #pragma unroll
   for (int hh = 0; hh < 4; ++hh)
 #pragma unroll
@@ -266,12 +286,13 @@ __global__ __launch_bounds__(1024) void k(float* out, const cf* __restrict__ tw,
     PIN(w1.re); PIN(w1.im); PIN(w2.re); PIN(w2.im); PIN(w3.re); PIN(w3.im); PIN(wl.re); PIN(wl.im);
     float sl = seed, sh = seed;
     if (VAR == 0 || VAR == 4 || VAR == 5 || VAR == 7) steps123(v, w1, w2, w3, wl, zkr, zpr, zki, zpi);
+    else if (VAR == 11 || VAR == 12) steps123_lds<true>(v, w1, w2, w3, wl, zkr, zpr, zki, zpi, ex, q);
     else if (VAR >= 8) steps123_lds(v, w1, w2, w3, wl, zkr, zpr, zki, zpi, ex, q);
     else {
 #pragma unroll
       for (int i = 0; i < 16; ++i) { PIN(zkr[i]); PIN(zpr[i]); PIN(zki[i]); PIN(zpi[i]); }
     }
-    if (VAR == 0 || VAR == 8) {
+    if (VAR == 0 || VAR == 8 || VAR == 11) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) { sl += zkr[i] + zpr[i]; sh += zki[i] + zpi[i]; }    // keep the 64 results live (64 adds)
     } else if (VAR == 1 || VAR == 5 || VAR == 10) post_old<true>(zkr, zpr, zki, zpi, wl, wuni, sl, sh);
@@ -320,10 +341,10 @@ void run(const char* name, int threads, int valu_per_iter, int iters) {
 }
 
 int main(int argc, char** argv) {
-  int cnt[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int cnt[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (argc > 1) {
     FILE* f = fopen(argv[1], "r");
-    if (f) { for (int i = 0; i < 11; ++i) if (fscanf(f, "%d", &cnt[i]) != 1) break; fclose(f); }
+    if (f) { for (int i = 0; i < 13; ++i) if (fscanf(f, "%d", &cnt[i]) != 1) break; fclose(f); }
   }
   for (int th : {512, 1024}) {
     run<0>("nopost", th, cnt[0], 400);
@@ -337,6 +358,8 @@ int main(int argc, char** argv) {
     run<8>("nopost+lds", th, cnt[8], 400);
     run<9>("f_poly+lds", th, cnt[9], 400);
     run<10>("frame+lds", th, cnt[10], 400);
+    run<11>("nopost+perm", th, cnt[11], 400);
+    run<12>("f_new+perm", th, cnt[12], 400);
   }
   return 0;
 }
