@@ -378,6 +378,46 @@ def test_ragged_batches_through_the_feed_on_one_stream():
         assert a.tobytes() == b.tobytes(), g
 
 
+def test_feed_times_its_uploads_and_picks_an_upload_method():
+    """Round 5: DeviceFeed.timing brackets every upload piece with events on its copy stream (what bench.py reports as
+    upload_ms_per_step / h2d_*_GBps), and DeviceFeed.autotune tries two pieces, one piece and the pull kernel under the job's
+    own kernels, keeps one of them -- and the records do not depend on which (the upload method moves bytes, nothing else)."""
+    import time
+    from audio_analysis_amd import pipeline as P
+    from audio_analysis_amd.engine import get_engine
+    from audio_analysis_amd.feed import DeviceFeed, HostBatch, run_pipelined
+    from audio_analysis_amd.synth import synth_ir
+    eng = get_engine()
+    chans = [synth_ir(1300 + i, 0, 48000, rt60_seconds=0.2) for i in range(4)]
+    hb = [HostBatch(eng, np.stack(chans)) for _ in range(2)]
+    rep = P.FullReport(eng)
+    want = rep.run(eng.upload(chans))
+    feed = DeviceFeed(eng, 4 * 48000, depth=4)
+    feed.split_bytes = 1 << 10                           # (these small batches would go as one copy otherwise)
+    feed.timing = []
+    got = []
+    run_pipelined(rep, feed, [hb[i % 2] for i in range(4)], got.append)
+    eng.torch.cuda.synchronize()
+    up = feed.upload_times()
+    assert up["uploads"] == 4 and up["pieces_per_upload"] == 2 and up["bytes_per_upload"] == 4 * 48000 * 4
+    assert up["ms_per_upload"] > 0.0 and up["GBps"] > 0.01 and 0.0 < up["busy_fraction_of_stretch"] <= 1.0
+    feed.timing = None
+    assert all(r.tobytes() == want.tobytes() for r in got)
+
+    def steps(c):
+        t0 = time.perf_counter()
+        run_pipelined(rep, feed, [hb[i % 2] for i in range(c)], got.append)
+        eng.torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    tried = feed.autotune(steps, alone_GBps=1e9, steps=2)             # an unreachable link rate: every arm is tried
+    assert len(tried) == 3 and sum(1 for r in tried if r["chosen"]) == 1
+    assert {r["mode"] for r in tried} == {"copy engine, 2 piece(s)", "copy engine, 1 piece(s)", "pull kernel"}
+    assert feed.mode() == next(r["mode"] for r in tried if r["chosen"])
+    steps(2)
+    assert all(r.tobytes() == want.tobytes() for r in got)
+
+
 def test_filter_block_reads_the_raw_spectrum_when_fr_smoothing_is_on():
     """Round-2 advisor finding: with frequency-response log smoothing on, the fr block smooths its dB curve in place on
     the device; the filter block (reference filterplot.py: no smoothing) must not share that curve."""

@@ -127,6 +127,32 @@ def test_ar_lag_path_matches_dense_mfma_gram():
                 assert np.max(np.abs(a[i, 1:] - ref)) / np.max(np.abs(ref)) < 1e-6, (order, i)
 
 
+def test_blocked_solver_above_order_128_matches_lstsq():
+    """Round 5: above order 128 the Gram matrix lives in global scratch and is factored in PANELS (32 columns up to order 384,
+    16 above; ira_ar.hip: chol_factor_blocked / chol_solve_blocked).  Orders on both sides of every boundary (129: a one-column
+    last panel; 160, 256; 384 / 385: the panel width changes; 500: ragged last panel of 16-wide panels) against numpy's lstsq
+    on the explicit matrix (float64), for well-conditioned responses: coefficients to 1e-7 of the largest one, the condition
+    estimate finite and the status 'analysed' (0) or 'refined' (2)."""
+    from audio_analysis_amd.engine import get_engine
+    from audio_analysis_amd.synth import synth_ir
+    eng = get_engine()
+    chans = [synth_ir(90 + i, 0, 9000 + 700 * i, rt60_seconds=0.25 + 0.05 * i) for i in range(3)]
+    b = eng.upload(chans)
+    lens = b.length.astype(np.int32)
+    for order in (129, 160, 256, 384, 385, 500):
+        c, info = eng.ar_fit(b.x, b.off, lens, None, order)
+        a = c.cpu().numpy().reshape(len(chans), order + 1)
+        inf = info.cpu().numpy().reshape(len(chans), -1)
+        assert np.all(a[:, 0] == 1.0)
+        assert np.all((inf[:, 0] == 0.0) | (inf[:, 0] == 2.0)) and np.all(np.isfinite(inf[:, 3])), (order, inf[:, :4])
+        for i, x in enumerate(chans):
+            s = x.astype(np.float64)
+            n = np.arange(order, s.size)
+            A = np.stack([s[n - k] for k in range(1, order + 1)], axis=1)
+            ref = np.linalg.lstsq(A, -s[n], rcond=None)[0]
+            assert np.max(np.abs(a[i, 1:] - ref)) / np.max(np.abs(ref)) < 1e-7, (order, i, float(np.max(np.abs(a[i, 1:] - ref))))
+
+
 def _band_limited(seed, b, a, n=48000):
     from scipy.signal import lfilter
     from audio_analysis_amd.synth import synth_ir
