@@ -19,6 +19,8 @@ from typing import List, Optional
 from .. import dist as _dist
 from .report import ReportSettings
 
+LAST_HOST_MS_PER_GROUP = None     # IRA_BUNDLE_TIMING=1: host milliseconds per group and phase of the last run_bundle_metrics call
+
 
 @dataclass(frozen=True)
 class BundleRunSettings:
@@ -202,6 +204,8 @@ def run_bundle_metrics(bundle_root: str | Path, settings=None, use_mono_downmix_
             uploaded = batch
         sys.setswitchinterval(switch_before)
         if timing is not None and groups:
+            global LAST_HOST_MS_PER_GROUP            # for callers that report it (bench.py, config 5)
+            LAST_HOST_MS_PER_GROUP = {k: 1e3 * v / len(groups) for k, v in timing.items()}
             print("[bundle] host ms per group: " + ", ".join(f"{k} {1e3 * v / len(groups):.2f}" for k, v in timing.items()),
                   file=sys.stderr)
     if uploaded is not None:

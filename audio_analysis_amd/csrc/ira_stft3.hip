@@ -391,7 +391,7 @@ __device__ __forceinline__ T& at32(T* base, unsigned byte_off) {
 //     issued after a frame's 33 stores cannot be consumed before those stores are acknowledged; issued before them it can.
 // AB: ablation bits, instantiated only by the tuning build (IRA_STFT6_ABLATE): 1 no sample loads, 2 no window reads,
 //     4 no stores, 8 post-stage twiddles without the scalar table loads, 16 polynomial logarithm, 32 E3 through LDS (the
-//     pre-round-5 mirror exchange).  The product runs AB = 0.
+//     pre-round-5 mirror exchange), 64 samples from LDS + emulated staging (timing only: see load_half).  The product runs AB = 0.
 template <int NT, bool PF, int AB>
 __global__ __launch_bounds__(64 * NT) void stft6_kernel(
     const float* __restrict__ x, const int64_t* __restrict__ off, const int32_t* __restrict__ nframes, int hop,
@@ -430,7 +430,13 @@ __global__ __launch_bounds__(64 * NT) void stft6_kernel(
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) {
       const unsigned n = (unsigned)(n1 * 128 + qq + 64 * h);        // unsigned 32-bit lane offsets: scalar base + offset
-      if (AB & 1) { xa[n1] = __uint_as_float(0x3f800000u + n); xb[n1] = __uint_as_float(0x3f000000u + n); }
+      if (AB & 64) {
+        // timing only: the frame's samples as 8-byte LDS reads (from the window copy: wrong values, right instruction mix) --
+        // what a tile's sample span staged ONCE in LDS would make of the 32 global loads per frame-wave; the staging itself
+        // is emulated below (three 16-byte global loads + LDS writes per frame-wave)
+        const float2 v2 = *reinterpret_cast<const float2*>(winl + ((2u * n) & 4094u));
+        xa[n1] = v2.x; xb[n1] = v2.y;
+      } else if (AB & 1) { xa[n1] = __uint_as_float(0x3f800000u + n); xb[n1] = __uint_as_float(0x3f000000u + n); }
       else { xa[n1] = at32(fxp, 8u * n); xb[n1] = at32(fxp, 8u * n + 4u); }
     }
   };
@@ -478,6 +484,16 @@ __global__ __launch_bounds__(64 * NT) void stft6_kernel(
     // as in the one-frame kernels: three 8-byte L1 hits and ~220 multiply-adds per frame instead of scratch traffic.
     int q = q0;
     asm volatile("" : "+v"(q));
+    if (AB & 64) {
+      // the emulated share of the cooperative staging: 3 x 16 bytes per lane from the frame's own samples into the free tail of LDS
+      typedef float f4 __attribute__((ext_vector_type(4), aligned(4)));
+      float* tail = reinterpret_cast<float*>(smem_raw + win_lds_off) + 2 * M3;       // behind the window copy (4 KB are free)
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const f4 v4 = *reinterpret_cast<const f4*>(fx + 4u * (unsigned)(q + 64 * u));
+        *reinterpret_cast<f4*>(tail + 4 * (q + 64 * (u & 3))) = v4;
+      }
+    }
     const int k1l = q & 15, n3a = q >> 4;
     const cf wlane = tw[(unsigned)q];
 
@@ -681,7 +697,11 @@ int32_t launch6(const float* x, const int64_t* off, const int32_t* nframes, int3
                 const void* window, const void* tw, double floor_db, float* out, const int64_t* out_off,
                 const int32_t* frame_sel, const int64_t* sel_off, hipStream_t st) {
   constexpr size_t lds_main = ((size_t)NT * EXC * sizeof(cf) + 15) & ~(size_t)15;
+#ifdef IRA_TUNING_BUILD
+  constexpr size_t lds = lds_main + (size_t)2 * M3 * sizeof(float) + 4096;   // + the scratch tail of the AB & 64 emulation
+#else
   constexpr size_t lds = lds_main + (size_t)2 * M3 * sizeof(float);
+#endif
   static_assert(lds <= 160 * 1024, "one workgroup must fit the CU's LDS");
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
@@ -714,6 +734,8 @@ int32_t launch6(const float* x, const int64_t* off, const int32_t* nframes, int3
     case 23: IRA_LAUNCH6(23); break;
     case 32: IRA_LAUNCH6(32); break;
     case 39: IRA_LAUNCH6(39); break;
+    case 64: IRA_LAUNCH6(64); break;
+    case 68: IRA_LAUNCH6(68); break;
     default: IRA_LAUNCH6(0); break;
   }
 #else

@@ -310,7 +310,9 @@ def config_table():
                   excluded=["png rendering"]),
         # 128 taps (256 channels) per step: the host side (probe + read + ~150 launches per step) is what binds this
         # configuration; measured 32 / 64 / 128 taps per step: 3.5 / 4.0 / 4.6 k taps/s
-        "5": dict(settings=full, batch=128, seconds=5.0, steps=8, cpu_s=1.4,
+        # (24 steps: one GPU's share of the configuration is 8192 taps = 64 steps; with 8 the first group's unoverlapped read
+        # and the last groups' drain were a tenth of the timed region)
+        "5": dict(settings=full, batch=128, seconds=5.0, steps=24, cpu_s=1.4,
                   metric="stereo taps/sec bundle report (full pipeline), 48 kHz 5 s stereo PCM16 taps (BASELINE config 5)",
                   what="bundle.run_bundle_metrics over stereo PCM16 tap files (native ingest, int16 upload, device "
                        "conversion, full metrics-only report of both channels)",
@@ -1214,11 +1216,15 @@ def bench_bundle(a, cfg, eng, rank, world, B, n, steps, blocks, affinity=None, c
         run(os.path.join(base, "warm"))
         D.barrier(); torch.cuda.synchronize()
         eng.events = []
+        os.environ["IRA_BUNDLE_TIMING"] = "1"          # host milliseconds per phase of the loop (a dozen clock reads per group)
         t0 = time.perf_counter()
         labels, local = run(os.path.join(base, "timed"))
         gathered = D.gather_metrics(local, eng.device)
         D.barrier(); torch.cuda.synchronize()
         elapsed = D.max_over_ranks(time.perf_counter() - t0, eng.device)
+        os.environ.pop("IRA_BUNDLE_TIMING", None)
+        from audio_analysis_amd.analyse import bundle as _bundle
+        host_phases = _bundle.LAST_HOST_MS_PER_GROUP
         ev_timed = eng.collect_events()
         eng.events = None
         # serialised pass for the per-call durations
@@ -1262,7 +1268,14 @@ def bench_bundle(a, cfg, eng, rank, world, B, n, steps, blocks, affinity=None, c
         "lanes": lanes_used,
         "device_ms_per_step_by_call": {k: v / roof_steps for k, v in sorted(tot.items(), key=lambda kv: -kv[1])},
         "device_ms_per_step": sum(tot.values()) / roof_steps,
+        "host_ms_per_step_by_phase": host_phases,
     }
+    # what binds the step: the serialised kernels' time against the step (two lanes overlap them further), beside the host's
+    # own phases -- the host thread enqueues `view` + `prepare` + `submit` and blocks in `finish` / for the reader thread
+    dev = out["device_ms_per_step"]
+    out["bound"] = "compute" if dev >= 0.97 * out["ms_per_step"] else "host"
+    out["bound_reason"] = (f"{out['ms_per_step']:.2f} ms per step against {dev:.2f} ms of kernels when they run one at a time "
+                           f"(less on two lanes); host phases per step: {host_phases}")
     if not a.no_cpu_baseline:
         base, oracle_values, _ = cpu_baseline(n / 48000, blocks, settings.rt60_bands.band_mode, True, cfg["cpu_s"],
                                               "stereo taps/s", first_index=200000, pcm16=True,
