@@ -180,19 +180,22 @@ class DeviceFeed:
         return "pull kernel" if self.pull else f"copy engine, {len(self.side_streams) + 1} piece(s)"
 
     def autotune(self, run_steps: Callable[[int], float], alone_GBps: Optional[float], steps: int = 4,
-                 accept: float = 0.75):
+                 accept: float = 0.75, first_pieces: int = 2):
         """
         Pick the upload method on THIS box, under THIS job's kernels (untimed warm-up work, like a transform plan).  Why: the
         same build uploads a 492 MB batch at 55 GB/s under the report's kernels on one MI355X box and at 26 GB/s on another
         (and at 26 GB/s on the first one as four pieces): whether an asynchronous copy rides a DMA engine or falls back to a
         copy kernel that queues behind the analysis kernels is the runtime's choice per stream, and it differs between hosts
         (profiles/r05_upload_ab.txt).  run_steps(n) must run n pipelined steps through this feed and return their wall
-        seconds.  Arms, in order: two pieces (the default), one piece, the pull kernel.  The first copy-engine arm whose
+        seconds.  Arms, in order: `first_pieces` pieces (two: the default), one piece, the pull kernel.  The first copy-engine arm whose
         rate UNDER the kernels reaches `accept` x the link's rate alone is kept without trying the rest; otherwise the arm
         with the shortest step wins.  Returns the list of arms tried (mode, ms per step, upload ms, GB/s) for the bench line.
         """
         tried = []
-        for streams, pull in ((2, False), (1, False), (2, True)):
+        arms = [(max(1, int(first_pieces)), False), (1, False), (2, True)]
+        if arms[0] == arms[1]:
+            arms.pop(1)
+        for streams, pull in arms:
             self.set_mode(copy_streams=streams, pull=pull)
             run_steps(1)
             self.eng.sync()

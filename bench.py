@@ -921,7 +921,8 @@ def main():
             run_pipelined(report, feed, (host_f32[i % K] for i in range(c)), None)
             torch.cuda.synchronize()
             return time.perf_counter() - t0
-        upload_tuning = feed.autotune(tune_steps, upload_alone["GBps"] if upload_alone else None)
+        upload_tuning = feed.autotune(tune_steps, upload_alone["GBps"] if upload_alone else None,
+                                      first_pieces=a.upload_streams)
         note("upload: " + "; ".join(f"{r['mode']} {r['ms_per_step']:.2f} ms/step" + (" (chosen)" if r["chosen"] else "") for r in upload_tuning))
         flush()
         D.barrier(); torch.cuda.synchronize()
