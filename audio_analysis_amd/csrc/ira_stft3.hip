@@ -95,6 +95,18 @@ __device__ __forceinline__ void untangle_db(float zkr, float zpr, float zki, flo
   hi = db_quarter<POLY>(e.re - pp.re, e.im - pp.im, floor_db);
 }
 
+// p[k] = W_N^(k idx), k < 16, read from the table (tw[j] = exp(-2 pi i j / N), j < N / 2; the other half by symmetry) instead of
+// formed by powers16's product tree: a MEASUREMENT aid (tuning build, IRA_STFT6_ABLATE=128) -- is the float32 spectrogram's
+// worst-bin error (2.6e-3 dB) set by the up-to-four chained float32 products per twiddle, or by the transform itself?
+__device__ __forceinline__ void powers16_exact(const cf* __restrict__ tw, unsigned idx, cf (&p)[16]) {
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const unsigned j = ((unsigned)k * idx) & 4095u;
+    const cf w = tw[j & 2047u];
+    p[k] = (j & 2048u) ? cf{-w.re, -w.im} : w;
+  }
+}
+
 template <int NT3, bool TF>
 __global__ __launch_bounds__(64 * NT3) void stft3_kernel(
     const float* __restrict__ x, const int64_t* __restrict__ off, const int32_t* __restrict__ nframes, int hop,
@@ -391,7 +403,8 @@ __device__ __forceinline__ T& at32(T* base, unsigned byte_off) {
 //     issued after a frame's 33 stores cannot be consumed before those stores are acknowledged; issued before them it can.
 // AB: ablation bits, instantiated only by the tuning build (IRA_STFT6_ABLATE): 1 no sample loads, 2 no window reads,
 //     4 no stores, 8 post-stage twiddles without the scalar table loads, 16 polynomial logarithm, 32 E3 through LDS (the
-//     pre-round-5 mirror exchange), 64 samples from LDS + emulated staging (timing only: see load_half).  The product runs AB = 0.
+//     pre-round-5 mirror exchange), 64 samples from LDS + emulated staging (timing only: see load_half),
+//     128 every twiddle read from the table instead of formed by products (error measurement).  The product runs AB = 0.
 template <int NT, bool PF, int AB>
 __global__ __launch_bounds__(64 * NT) void stft6_kernel(
     const float* __restrict__ x, const int64_t* __restrict__ off, const int32_t* __restrict__ nframes, int hop,
@@ -523,7 +536,8 @@ __global__ __launch_bounds__(64 * NT) void stft6_kernel(
       }
       dft_dif<float, 16>(v);
       cf p[16];
-      powers16<float>(tw[(unsigned)(2 * m)], p);           // W_M^m = W_N^(2m)
+      if (AB & 128) powers16_exact(tw, (unsigned)(2 * m), p);
+      else powers16<float>(tw[(unsigned)(2 * m)], p);      // W_M^m = W_N^(2m)
       if (h == 0) {
 #pragma unroll
         for (int k1 = 0; k1 < 16; ++k1) {
@@ -561,14 +575,16 @@ __global__ __launch_bounds__(64 * NT) void stft6_kernel(
     {
       cf p[16];
       dft_dif<float, 16>(b2[0]);
-      powers16<float>(tw[(unsigned)(32 * n3a)], p);
+      if (AB & 128) powers16_exact(tw, (unsigned)(32 * n3a), p);
+      else powers16<float>(tw[(unsigned)(32 * n3a)], p);
 #pragma unroll
       for (int k2 = 0; k2 < 16; ++k2) {
         const cf a = b2[0][brev_bits(k2, 4)];
         ex[k1l + 16 * k2 + E2N3 * n3a] = (k2 == 0) ? a : ira::cmul(a, p[k2]);
       }
       dft_dif<float, 16>(b2[1]);
-      powers16<float>(tw[(unsigned)(32 * (n3a + 4))], p);
+      if (AB & 128) powers16_exact(tw, (unsigned)(32 * (n3a + 4)), p);
+      else powers16<float>(tw[(unsigned)(32 * (n3a + 4))], p);
 #pragma unroll
       for (int k2 = 1; k2 < 16; ++k2) b2[1][brev_bits(k2, 4)] = ira::cmul(b2[1][brev_bits(k2, 4)], p[k2]);
     }
@@ -663,7 +679,8 @@ __global__ __launch_bounds__(64 * NT) void stft6_kernel(
       float sacc = 0.0f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const cf wk = ira::cmul(wlane, (AB & 8) ? cf{wlane.im * (float)(i + 1), wlane.re} : wuni[i]);
+        const cf wk = (AB & 128) ? tw[(unsigned)(q + 64 * i)]
+                                 : ira::cmul(wlane, (AB & 8) ? cf{wlane.im * (float)(i + 1), wlane.re} : wuni[i]);
         float lo, hi;
         if (AB & 32) {
           untangle_db<(AB & 16) != 0>(zkr[i], zpr[i], zki[i], zpi[i], wk, floor_db, lo, hi);
@@ -735,6 +752,7 @@ int32_t launch6(const float* x, const int64_t* off, const int32_t* nframes, int3
     case 32: IRA_LAUNCH6(32); break;
     case 39: IRA_LAUNCH6(39); break;
     case 64: IRA_LAUNCH6(64); break;
+    case 128: IRA_LAUNCH6(128); break;
     case 68: IRA_LAUNCH6(68); break;
     default: IRA_LAUNCH6(0); break;
   }
